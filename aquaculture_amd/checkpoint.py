@@ -1,0 +1,411 @@
+"""YOLOv5 checkpoint import (no upstream code needed), BN folding, synthetic checkpoints.
+
+Reference call site: ``--weights output/model_weights/multilabel_farms_exp2.pt``
+(reference README.md:60,77).  The file is a pickled ``nn.Module`` tree whose
+classes live in the un-vendored ultralytics/yolov5 submodule (``models.yolo.*``,
+``models.common.*``) [UPSTREAM models/experimental.py attempt_load:
+``ckpt = torch.load(w); model = (ckpt.get('ema') or ckpt['model']).float()``,
+then ``.fuse().eval()``].  We unpickle with stand-in ``nn.Module`` subclasses for
+every class that is not importable, which is enough to call ``state_dict()`` and
+read ``names``/``stride``/``anchors``/BN ``eps`` from the tree.
+
+The real weights are absent from the reference snapshot
+(reference .MISSING_LARGE_BLOBS:3), so ``write_synthetic_checkpoint`` produces a
+seeded checkpoint in the same on-disk format (same class paths, same tensor
+names/shapes, fp16 storage) for tests and benchmarks.
+"""
+from __future__ import annotations
+
+import io
+import json
+import os
+import pickle
+import sys
+import types
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import spec as _spec
+
+BN_EPS_DEFAULT = 1e-3  # [UPSTREAM models/yolo.py initialize_weights sets BatchNorm2d.eps = 1e-3]
+SYNTH_SEED = 0x5EED
+
+
+# --------------------------------------------------------------------------------------
+# import
+# --------------------------------------------------------------------------------------
+_STUB_CACHE: Dict[Tuple[str, str], type] = {}
+
+
+def _stub_class(module: str, name: str) -> type:
+    key = (module, name)
+    if key not in _STUB_CACHE:
+        cls = type(name.split(".")[-1], (nn.Module,), {"__module__": module, "_aq_stub": True})
+        _STUB_CACHE[key] = cls
+    return _STUB_CACHE[key]
+
+
+class _StubUnpickler(pickle.Unpickler):
+    """Resolves classes normally; anything under models.* / utils.* / ultralytics.* that is
+    not importable becomes an ``nn.Module`` stand-in (state is restored by nn.Module.__setstate__)."""
+
+    _FOREIGN = ("models.", "utils.", "ultralytics.", "yolov5.")
+
+    def find_class(self, module, name):
+        if module == "models" or module == "utils" or module.startswith(self._FOREIGN):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError, ModuleNotFoundError):
+                return _stub_class(module, name)
+        return super().find_class(module, name)
+
+
+class _StubPickleModule:
+    """Quacks like the ``pickle`` module for ``torch.load(pickle_module=...)``."""
+    __name__ = "aq_stub_pickle"
+    Unpickler = _StubUnpickler
+    load = staticmethod(lambda f, **kw: _StubUnpickler(f, **kw).load())
+    loads = staticmethod(lambda b, **kw: _StubUnpickler(io.BytesIO(b), **kw).load())
+    dump = staticmethod(pickle.dump)
+    dumps = staticmethod(pickle.dumps)
+    Pickler = pickle.Pickler
+    PickleError = pickle.PickleError
+    UnpicklingError = pickle.UnpicklingError
+    HIGHEST_PROTOCOL = pickle.HIGHEST_PROTOCOL
+    DEFAULT_PROTOCOL = pickle.DEFAULT_PROTOCOL
+
+
+@dataclass
+class Checkpoint:
+    """Everything the engine needs from a yolov5 ``.pt``: fp32 state + head metadata."""
+    state: "OrderedDict[str, torch.Tensor]"   # upstream state_dict keys, fp32
+    nc: int
+    names: Dict[int, str]
+    anchors: torch.Tensor                       # (nl, na, 2) in GRID units (upstream Detect.anchors buffer)
+    stride: Tuple[float, ...]
+    bn_eps: float
+    variant: str
+    source: str = ""
+
+    @property
+    def na(self) -> int:
+        return int(self.anchors.shape[1])
+
+    def anchor_grid_px(self) -> torch.Tensor:
+        """anchors * stride in fp32, as [UPSTREAM Detect._make_grid] computes anchor_grid."""
+        s = torch.tensor(self.stride, dtype=torch.float32).view(-1, 1, 1)
+        return self.anchors.float() * s
+
+
+def _infer_variant(state) -> str:
+    c1 = state["model.0.conv.weight"].shape[0]
+    n6 = len({k.split(".")[3] for k in state if k.startswith("model.6.m.")})
+    for name, (gd, gw) in _spec.VARIANTS.items():
+        if _spec.make_divisible(64 * gw) == c1 and _spec.scaled_depth(9, gd) == n6:
+            return name
+    raise ValueError(f"unrecognised YOLOv5 variant: stem width {c1}, layer-6 depth {n6}")
+
+
+def load_checkpoint(path: str) -> Checkpoint:
+    """Restates [UPSTREAM attempt_load]: pick ``ema`` over ``model``, cast to fp32, read head metadata."""
+    ckpt = torch.load(path, map_location="cpu", pickle_module=_StubPickleModule, weights_only=False)
+    if isinstance(ckpt, dict) and ("model" in ckpt or "ema" in ckpt):
+        model = ckpt.get("ema") or ckpt["model"]
+    else:
+        model = ckpt
+    if not isinstance(model, nn.Module):
+        raise ValueError(f"{path}: expected a pickled nn.Module under 'ema'/'model', got {type(model)}")
+    model = model.float()
+    state = OrderedDict((k, v.detach().clone().float() if v.is_floating_point() else v.detach().clone())
+                        for k, v in model.state_dict().items())
+    # Detect is the last child of model.model
+    seq = model._modules["model"]
+    det = list(seq._modules.values())[-1]
+    det_idx = len(seq._modules) - 1
+    anchors = state[f"model.{det_idx}.anchors"].float()
+    nc = int(getattr(det, "nc", state[f"model.{det_idx}.m.0.bias"].numel() // anchors.shape[1] - 5))
+    stride = getattr(det, "stride", None)
+    if stride is None:
+        stride = getattr(model, "stride", torch.tensor(_spec.STRIDES, dtype=torch.float32))
+    stride = tuple(float(s) for s in stride)
+    names = getattr(model, "names", None) or {i: f"class{i}" for i in range(nc)}
+    if isinstance(names, (list, tuple)):
+        names = dict(enumerate(names))
+    eps = BN_EPS_DEFAULT
+    for m in model.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            eps = float(m.eps)
+            break
+    variant = _infer_variant(state)
+    ck = Checkpoint(state=state, nc=nc, names=dict(names), anchors=anchors, stride=stride, bn_eps=eps,
+                    variant=variant, source=str(path))
+    validate_against_plan(ck)
+    return ck
+
+
+def expected_state_shapes(variant: str, nc: int, na: int = 3) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Tensor names/shapes the v6 architecture must have (conv + BN + Detect), from the plan."""
+    plan = _spec.build_plan(variant, nc, na)
+    shapes: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    for op in plan.conv_ops():
+        cin_total = op.meta.get("true_cin", op.src.channels)
+        k = op.meta.get("true_k", op.k)
+        for key in op.weight_keys:
+            if key.startswith("model.24.m."):
+                cout = op.meta["true_cout"]
+                shapes[f"{key}.weight"] = (cout, cin_total, 1, 1)
+                shapes[f"{key}.bias"] = (cout,)
+            else:
+                cout = op.dst.channels // len(op.weight_keys)
+                shapes[f"{key}.conv.weight"] = (cout, cin_total, k, k)
+                for bn in ("weight", "bias", "running_mean", "running_var"):
+                    shapes[f"{key}.bn.{bn}"] = (cout,)
+    shapes["model.24.anchors"] = (3, na, 2)
+    return shapes
+
+
+def validate_against_plan(ck: Checkpoint) -> None:
+    """Zero missing keys and matching shapes against the restated architecture."""
+    want = expected_state_shapes(ck.variant, ck.nc, ck.na)
+    missing = [k for k in want if k not in ck.state]
+    bad = [(k, tuple(ck.state[k].shape), s) for k, s in want.items() if k in ck.state and tuple(ck.state[k].shape) != s]
+    extra = [k for k in ck.state if k not in want and not k.endswith("num_batches_tracked")
+             and not k.endswith("anchor_grid")]
+    if missing or bad or extra:
+        raise ValueError(f"checkpoint does not match the restated {ck.variant} architecture: "
+                         f"missing={missing[:5]} shape_mismatch={bad[:5]} unexpected={extra[:5]}")
+
+
+# --------------------------------------------------------------------------------------
+# BN folding + per-op weight packing (host, fp32)
+# --------------------------------------------------------------------------------------
+def fuse_conv_bn(state, key: str, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[UPSTREAM utils/torch_utils.py fuse_conv_and_bn], fp32:
+    W' = diag(gamma / sqrt(var + eps)) W ;  b' = beta - gamma * mean / sqrt(var + eps)  (conv has no bias)."""
+    w = state[f"{key}.conv.weight"].float()
+    g, b = state[f"{key}.bn.weight"].float(), state[f"{key}.bn.bias"].float()
+    mu, var = state[f"{key}.bn.running_mean"].float(), state[f"{key}.bn.running_var"].float()
+    w_bn = torch.diag(g.div(torch.sqrt(eps + var)))
+    w_f = torch.mm(w_bn, w.view(w.shape[0], -1)).view(w.shape)
+    b_conv = torch.zeros(w.shape[0], dtype=torch.float32)
+    b_bn = b - g.mul(mu).div(torch.sqrt(var + eps))
+    b_f = torch.mm(w_bn, b_conv.reshape(-1, 1)).reshape(-1) + b_bn
+    return w_f, b_f
+
+
+def stem_to_s2d(w: torch.Tensor) -> torch.Tensor:
+    """Rewrite the 6x6/s2/p2 stem kernel (Cout,3,6,6) as a 3x3/s1/p1 kernel over the 2x2
+    space-to-depth image: s2d channel = (dy*2 + dx)*3 + c for input pixel (2Y+dy, 2X+dx).
+    Output (Cout, 16, 3, 3), channels 12..15 zero."""
+    co = w.shape[0]
+    out = torch.zeros(co, _spec.STEM_S2D_CH, 3, 3, dtype=w.dtype)
+    for ky in range(6):
+        for kx in range(6):
+            # input row = 2*y - 2 + ky = 2*(y - 1 + ky//2) + ky%2
+            ty, dy, tx, dx = ky // 2, ky % 2, kx // 2, kx % 2
+            for c in range(3):
+                out[:, (dy * 2 + dx) * 3 + c, ty, tx] = w[:, c, ky, kx]
+    return out
+
+
+@dataclass
+class PackedConv:
+    """Fused fp32 weights of one plan conv: KRSC (Cout, KH, KW, Cin) + bias, Cout padded with zeros."""
+    weight: np.ndarray   # float32 (cout, k, k, cin) C-contiguous
+    bias: np.ndarray     # float32 (cout,)
+
+
+def pack_plan_weights(ck: Checkpoint, plan: _spec.Plan) -> List[PackedConv]:
+    packed = []
+    for op in plan.conv_ops():
+        ws, bs = [], []
+        for key in op.weight_keys:
+            if key.startswith("model.24.m."):
+                w, b = ck.state[f"{key}.weight"].float(), ck.state[f"{key}.bias"].float()
+            else:
+                w, b = fuse_conv_bn(ck.state, key, ck.bn_eps)
+            if op.meta.get("stem_s2d"):
+                w = stem_to_s2d(w)
+            ws.append(w)
+            bs.append(b)
+        w = torch.cat(ws, 0)
+        b = torch.cat(bs, 0)
+        cout = op.dst.channels
+        if w.shape[0] < cout:  # detect head: pad Cout to the buffer width
+            w = torch.cat([w, torch.zeros(cout - w.shape[0], *w.shape[1:])], 0)
+            b = torch.cat([b, torch.zeros(cout - b.shape[0])], 0)
+        assert w.shape[0] == cout and w.shape[1] == op.src.channels and w.shape[2] == op.k, (op.name, w.shape)
+        packed.append(PackedConv(np.ascontiguousarray(w.permute(0, 2, 3, 1).numpy(), dtype=np.float32),
+                                 np.ascontiguousarray(b.numpy(), dtype=np.float32)))
+    return packed
+
+
+# --------------------------------------------------------------------------------------
+# synthetic checkpoint (seeded; same file format as upstream)
+# --------------------------------------------------------------------------------------
+CLASS_NAMES = {0: "circle_farm", 1: "square_farm", 2: "triangle_farm", 3: "other_farm", 4: "rectangle_farm"}
+"""class ids the consumer accepts (reference src/process_yolo/geocode_results.py:24-30)."""
+
+
+_CALIB_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "synth_head_calib.json")
+
+
+def _load_calib(variant: str, nc: int, seed: int):
+    """Per-channel (gain, bias) of the synthetic Detect head, measured once by
+    tests/golden/make_synth_calib.py; None if this (variant, nc, seed) was never calibrated."""
+    try:
+        with open(_CALIB_FILE) as f:
+            return json.load(f).get(f"{variant}:nc{nc}:seed{seed:#x}")
+    except FileNotFoundError:
+        return None
+
+
+def synthetic_state(variant: str = "yolov5m", nc: int = 5, seed: int = SYNTH_SEED,
+                    obj_bias: float = -4.0, cls_bias: float = 1.0, calib="auto") -> "OrderedDict[str, torch.Tensor]":
+    """Seeded weights with upstream names/shapes: conv W ~ N(0, 2/(k^2 Cin)) stored fp16,
+    BN gamma~U(.8,1.2) beta~N(0,.1) mean~N(0,.1) var~U(.5,1.5); Detect head rescaled per channel by the
+    committed calibration table so that O(1%) of the candidates pass obj > 0.25 (exercises NMS)."""
+    if calib == "auto":
+        calib = _load_calib(variant, nc, seed)
+    g = torch.Generator().manual_seed(seed)
+    shapes = expected_state_shapes(variant, nc)
+    st: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for k, s in shapes.items():
+        if k.endswith("conv.weight"):
+            fan = s[1] * s[2] * s[3]
+            st[k] = (torch.randn(s, generator=g) * (2.0 / fan) ** 0.5).half()
+        elif k.endswith("bn.weight"):
+            st[k] = (0.8 + 0.4 * torch.rand(s, generator=g)).half()
+        elif k.endswith("bn.bias") or k.endswith("bn.running_mean"):
+            st[k] = (0.1 * torch.randn(s, generator=g)).half()
+        elif k.endswith("bn.running_var"):
+            st[k] = (0.5 + torch.rand(s, generator=g)).half()
+        elif k.endswith(".weight"):   # Detect 1x1
+            st[k] = (torch.randn(s, generator=g) * (4.0 / s[1]) ** 0.5).half()
+        elif k.endswith(".bias"):     # Detect bias: (na, no) rows [x y w h obj cls...]
+            b = (0.1 * torch.randn(s, generator=g)).view(3, -1)
+            b[:, 4] += obj_bias
+            b[:, 5:] += cls_bias
+            st[k] = b.view(-1).half()
+        elif k.endswith("anchors"):
+            a = torch.tensor(_spec.DEFAULT_ANCHORS, dtype=torch.float32).view(3, 3, 2)
+            st[k] = (a / torch.tensor(_spec.STRIDES, dtype=torch.float32).view(3, 1, 1)).half()
+    if calib is not None:
+        for lvl, c in enumerate(calib):
+            gain = torch.tensor(c["gain"], dtype=torch.float32)
+            w = st[f"model.24.m.{lvl}.weight"].float() * gain.view(-1, 1, 1, 1)
+            st[f"model.24.m.{lvl}.weight"] = w.half()
+            st[f"model.24.m.{lvl}.bias"] = torch.tensor(c["bias"], dtype=torch.float32).half()
+    return st
+
+
+def synthetic_checkpoint(variant="yolov5m", nc=5, seed=SYNTH_SEED, **kw) -> Checkpoint:
+    st = synthetic_state(variant, nc, seed, **kw)
+    state = OrderedDict((k, v.float()) for k, v in st.items())
+    return Checkpoint(state=state, nc=nc, names={i: CLASS_NAMES.get(i, f"class{i}") for i in range(nc)},
+                      anchors=state["model.24.anchors"], stride=tuple(float(s) for s in _spec.STRIDES),
+                      bn_eps=BN_EPS_DEFAULT, variant=variant, source=f"synthetic:{variant}:nc{nc}:seed{seed:#x}")
+
+
+def _module_tree_from_state(state, variant: str, nc: int) -> nn.Module:
+    """Build an nn.Module tree whose class paths and attribute names equal upstream's, holding ``state``."""
+    def mk(module, name):
+        return _stub_class(module, name)()
+
+    def conv_block(prefix):
+        m = mk("models.common", "Conv")
+        w = state[f"{prefix}.conv.weight"]
+        c = nn.Conv2d(w.shape[1], w.shape[0], w.shape[2], bias=False)
+        c.weight = nn.Parameter(w.clone(), requires_grad=False)
+        bn = nn.BatchNorm2d(w.shape[0], eps=BN_EPS_DEFAULT, momentum=0.03)
+        bn.weight = nn.Parameter(state[f"{prefix}.bn.weight"].clone(), requires_grad=False)
+        bn.bias = nn.Parameter(state[f"{prefix}.bn.bias"].clone(), requires_grad=False)
+        bn.running_mean = state[f"{prefix}.bn.running_mean"].clone()
+        bn.running_var = state[f"{prefix}.bn.running_var"].clone()
+        m.add_module("conv", c)
+        m.add_module("bn", bn)
+        m.add_module("act", nn.SiLU())
+        return m
+
+    def c3_block(prefix):
+        m = mk("models.common", "C3")
+        for cv in ("cv1", "cv2", "cv3"):
+            m.add_module(cv, conv_block(f"{prefix}.{cv}"))
+        n = len({k.split(".")[3] for k in state if k.startswith(f"{prefix}.m.")})
+        seq = nn.Sequential()
+        for j in range(n):
+            bt = mk("models.common", "Bottleneck")
+            bt.add_module("cv1", conv_block(f"{prefix}.m.{j}.cv1"))
+            bt.add_module("cv2", conv_block(f"{prefix}.m.{j}.cv2"))
+            seq.add_module(str(j), bt)
+        m.add_module("m", seq)
+        return m
+
+    root = mk("models.yolo", "DetectionModel")
+    seq = nn.Sequential()
+    kinds = {0: "conv", 1: "conv", 2: "c3", 3: "conv", 4: "c3", 5: "conv", 6: "c3", 7: "conv", 8: "c3",
+             9: "sppf", 10: "conv", 11: "up", 12: "cat", 13: "c3", 14: "conv", 15: "up", 16: "cat", 17: "c3",
+             18: "conv", 19: "cat", 20: "c3", 21: "conv", 22: "cat", 23: "c3", 24: "detect"}
+    for i, kind in kinds.items():
+        p = f"model.{i}"
+        if kind == "conv":
+            mod = conv_block(p)
+        elif kind == "c3":
+            mod = c3_block(p)
+        elif kind == "sppf":
+            mod = mk("models.common", "SPPF")
+            mod.add_module("cv1", conv_block(f"{p}.cv1"))
+            mod.add_module("cv2", conv_block(f"{p}.cv2"))
+            mod.add_module("m", nn.MaxPool2d(kernel_size=5, stride=1, padding=2))
+        elif kind == "up":
+            mod = nn.Upsample(scale_factor=2.0, mode="nearest")
+        elif kind == "cat":
+            mod = mk("models.common", "Concat")
+            mod.d = 1
+        else:
+            mod = mk("models.yolo", "Detect")
+            ml = nn.ModuleList()
+            for l in range(3):
+                w = state[f"{p}.m.{l}.weight"]
+                c = nn.Conv2d(w.shape[1], w.shape[0], 1)
+                c.weight = nn.Parameter(w.clone(), requires_grad=False)
+                c.bias = nn.Parameter(state[f"{p}.m.{l}.bias"].clone(), requires_grad=False)
+                ml.append(c)
+            mod.add_module("m", ml)
+            mod.register_buffer("anchors", state[f"{p}.anchors"].clone())
+            mod.nc, mod.no, mod.nl, mod.na = nc, nc + 5, 3, 3
+            mod.stride = torch.tensor(_spec.STRIDES, dtype=torch.float32)
+        seq.add_module(str(i), mod)
+    root.add_module("model", seq)
+    root.names = {i: CLASS_NAMES.get(i, f"class{i}") for i in range(nc)}
+    root.stride = torch.tensor(_spec.STRIDES, dtype=torch.float32)
+    root.nc = nc
+    root.yaml = {"nc": nc, "depth_multiple": _spec.VARIANTS[variant][0], "width_multiple": _spec.VARIANTS[variant][1]}
+    return root
+
+
+def write_synthetic_checkpoint(path: str, variant="yolov5m", nc=5, seed=SYNTH_SEED, **kw) -> None:
+    """torch.save a checkpoint dict in upstream's layout: {'model': <pickled DetectionModel, fp16>, 'ema': None, ...}."""
+    st = synthetic_state(variant, nc, seed, **kw)
+    root = _module_tree_from_state(st, variant, nc).half()
+    # pickle resolves classes by module path at save time: expose the stand-ins under fake modules
+    saved = {}
+    try:
+        for (mod, name), cls in _STUB_CACHE.items():
+            parts = mod.split(".")
+            for i in range(1, len(parts) + 1):
+                mname = ".".join(parts[:i])
+                if mname not in sys.modules:
+                    saved[mname] = None
+                    sys.modules[mname] = types.ModuleType(mname)
+            setattr(sys.modules[mod], name, cls)
+        torch.save({"epoch": -1, "best_fitness": None, "model": root, "ema": None, "updates": None,
+                    "optimizer": None, "opt": None, "git": None, "date": None}, path)
+    finally:
+        for mname in saved:
+            sys.modules.pop(mname, None)

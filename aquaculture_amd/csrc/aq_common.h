@@ -1,0 +1,66 @@
+// Shared declarations for the HIP translation units of libaqengine.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/aq_engine.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+void aq_set_error(const char* fmt, ...);
+#define AQ_CHECK_HIP(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            aq_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return AQ_ERR_HIP;                                                          \
+        }                                                                               \
+    } while (0)
+#define AQ_REQUIRE(cond, ...)                                                           \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            aq_set_error(__VA_ARGS__);                                                  \
+            return AQ_ERR_INVALID;                                                      \
+        }                                                                               \
+    } while (0)
+
+static inline int aq_elem_bytes(int precision) { return precision == AQ_FP32 ? 4 : 2; }
+
+// f32 -> bf16 round-to-nearest-even (finite inputs; NaN stays NaN via the quiet bit)
+__host__ __device__ static inline bf16_t aq_f2bf(float f) {
+    union { float f; uint32_t u; } v; v.f = f;
+    if ((v.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((v.u >> 16) | 0x40);
+    return (bf16_t)((v.u + 0x7fffu + ((v.u >> 16) & 1u)) >> 16);
+}
+__host__ __device__ static inline float aq_bf2f(bf16_t h) {
+    union { float f; uint32_t u; } v; v.u = ((uint32_t)h) << 16; return v.f;
+}
+
+// ---- conv kernel parameter block (conv_igemm.hip) ----
+struct ConvParams {
+    const char* in;      // input tensor base + first-channel offset (bytes)
+    char* out;
+    const char* res;     // nullptr: none
+    const char* w;       // packed [cout_pad][kgroups_pad] x 16 B
+    const float* bias;   // [cout_pad]
+    const char* zero;    // >= 16 zero bytes
+    int in_ld_b, out_ld_b, res_ld_b;   // pixel strides in BYTES
+    int B, H, W, Ho, Wo;
+    int cout;            // real cout (multiple of 4)
+    int k, stride, pad, taps;
+    int G;               // 16-byte groups per tap = cin * sizeof(T) / 16
+    int kgroups;         // taps * G
+    int kgroups_pad;     // multiple of 8
+    int nchunks;         // kgroups_pad / 8
+    int npix;            // B * Ho * Wo
+    int act;
+    int n_tiles_m, n_tiles_n;
+};
+
+int aq_launch_conv(const ConvParams& p, int precision, int out_f32, int cfg, hipStream_t stream);
+int aq_conv_pick_config(int cout, int npix, int precision);
+extern "C" int aq_conv_config_tiles(int cfg, int* bm, int* bn);
+extern "C" int aq_conv_num_configs(void);

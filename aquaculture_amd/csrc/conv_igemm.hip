@@ -1,0 +1,309 @@
+// Implicit-GEMM convolution for gfx950 (CDNA4), NHWC, im2col-free.
+//
+// Replaces Conv.forward_fuse / Bottleneck.forward of the reference's yolov5 dependency
+// ([UPSTREAM models/common.py]; invoked by reference README.md:77):  out = (res +) SiLU(conv(x, W') + b').
+//
+//   D[cout][pixel] = sum_{tap, cin} W[cout][tap][cin] * X[pixel + tap][cin]
+//
+// GEMM view: M = Cout (MFMA A operand = weights), N = B*Ho*Wo output pixels (MFMA B operand = activations),
+// K = taps*Cin.  Both operands are K-contiguous in HBM (weights packed [Cout][tap][Cin], activations NHWC),
+// so one 16-byte "group" = 8 bf16 (4 f32) consecutive input channels is the unit of every transfer.
+//
+// Data movement per K chunk of 8 groups (128 B per row): every lane issues LDS-DMA loads
+// (global_load_lds_dwordx4, 1 KiB per wave-instruction) with a PER-LANE SOURCE address, which is what makes
+// the im2col gather free: lane (row, slot) fetches group (slot ^ swz(row)) of its pixel's tap, or 16 zero
+// bytes from a zero page when the tap falls in the padding.  The LDS image is therefore lane-linear
+// [row][8 slots x 16 B] with the XOR swizzle applied on the SOURCE side; fragment reads apply the same XOR
+// and are ds_read_b128 bank-conflict-free (rows are 128 B; slot ^= (row >> 1) & 7).
+// Two LDS buffers: chunk c+1 streams in while chunk c feeds the MFMAs.
+//
+// fp32 parity mode uses the same byte geometry (a 16-byte group = 4 floats) on v_mfma_f32_32x32x2_f32,
+// which is bit-for-bit an fmaf chain (exact fp32 products, fp32 accumulate).
+#include "aq_common.h"
+
+namespace {
+
+__device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <bool F32>
+__device__ __forceinline__ float silu(float v) {
+    // [UPSTREAM nn.SiLU]: v * sigmoid(v) = v / (1 + exp(-v))
+    if (F32) return v / (1.0f + expf(-v));
+    return v / (1.0f + __expf(-v));
+}
+
+template <bool F32, int BM, int BN, int WM, int WN, bool OUT_F32>
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int NW = WM * WN;
+    constexpr int ROWB = 128;                 // LDS bytes per row = one K chunk
+    constexpr int NIW = BM / 8, NIX = BN / 8; // 1-KiB LDS-DMA instructions per chunk (weights, activations)
+    constexpr int JW = (NIW + NW - 1) / NW, JX = NIX / NW;
+    static_assert(BN % (8 * NW) == 0, "BN must split evenly over the waves");
+    static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "wave tiles are 32x32 MFMA blocks");
+    static_assert(NW % 2 == 0, "swizzle phase assumes an even wave count");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int BUF = (BM + BN) * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // XCD-aware, bijective block -> tile map: blocks that share an XCD (same blockIdx % 8) get a contiguous
+    // run of tiles, so neighbouring pixel tiles (shared 3x3 halo rows) and the weight panel hit one L2.
+    int wg;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = wg % p.n_tiles_m, tile_n = wg / p.n_tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---------------- loader state ----------------
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int gs = lslot ^ (((wave & 1) << 2) | (lrow >> 1));   // source group of this lane's LDS slot
+    long long xbase[JX];
+    unsigned xmask[JX];
+    {
+        const int hw = p.Ho * p.Wo;
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+            const int r = 8 * (wave + NW * j) + lrow;
+            const int P = n0 + r;
+            unsigned mask = 0;
+            long long base = 0;
+            if (P < p.npix) {
+                const int b = P / hw, rem = P - b * hw;
+                const int y = rem / p.Wo, x = rem - y * p.Wo;
+                const int iy0 = y * p.stride - p.pad, ix0 = x * p.stride - p.pad;
+                base = ((long long)(b * p.H + iy0) * p.W + ix0) * p.in_ld_b;
+                for (int t = 0; t < p.taps; ++t) {
+                    const int ky = t / p.k, kx = t - ky * p.k;
+                    const int iy = iy0 + ky, ix = ix0 + kx;
+                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
+                }
+            }
+            xbase[j] = base;
+            xmask[j] = mask;
+        }
+    }
+    const char* wsrc = p.w + ((long long)(m0 + 8 * wave + lrow) * p.kgroups_pad + gs) * 16;
+    const long long wstep = (long long)8 * NW * p.kgroups_pad * 16;   // bytes between this lane's weight rows
+
+    auto stage = [&](int chunk, char* buf) {
+        // weights: rows [0, BM)
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            const int q = wave + NW * j;
+            if (NIW % NW == 0 || q < NIW)
+                glds16(wsrc + j * wstep + (long long)chunk * 128, buf + q * 1024);
+        }
+        // activations: rows [BM, BM+BN)
+        const int kg = chunk * 8 + gs;
+        const int tap = kg / p.G;
+        const int cg = kg - tap * p.G;
+        const int ky = tap / p.k, kx = tap - ky * p.k;
+        const long long tapoff = (long long)(ky * p.W + kx) * p.in_ld_b + cg * 16;
+        const bool kvalid = kg < p.kgroups;
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+            const bool ok = kvalid && ((xmask[j] >> tap) & 1u);
+            const char* src = ok ? p.in + xbase[j] + tapoff : p.zero;
+            glds16(src, buf + BM * ROWB + (wave + NW * j) * 1024);
+        }
+    };
+
+    // ---------------- MFMA state ----------------
+    const int wm = wave / WN, wn = wave % WN;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int sw = (l31 >> 1) & 7;
+    const int a_off = (wm * (BM / WM) + l31) * ROWB;
+    const int b_off = BM * ROWB + (wn * (BN / WN) + l31) * ROWB;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    auto compute = [&](const char* buf) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int so = (((2 * ks + h) ^ sw) << 4);
+            if constexpr (!F32) {
+                bf16x8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8*)(buf + a_off + i * 32 * ROWB + so);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8*)(buf + b_off + j * 32 * ROWB + so);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            } else {
+                f32x4 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(buf + a_off + i * 32 * ROWB + so);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(buf + b_off + j * 32 * ROWB + so);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---------------- main loop: 2 LDS buffers, chunk c+1 in flight under chunk c's MFMAs ----------------
+    stage(0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < p.nchunks; ++c) {
+        char* cur = smem + (c & 1) * BUF;
+        char* nxt = smem + ((c & 1) ^ 1) * BUF;
+        if (c + 1 < p.nchunks) stage(c + 1, nxt);
+        compute(cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: +bias, SiLU, +residual, store NHWC ----------------
+    // MFMA C/D map (32x32): column (pixel) = lane & 31, row (cout) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int P = n0 + wn * (BN / WN) + j * 32 + l31;
+        if (P >= p.npix) continue;
+        char* orow = p.out + (long long)P * p.out_ld_b;
+        const char* rrow = p.res ? p.res + (long long)P * p.res_ld_b : nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = m0 + wm * (BM / WM) + i * 32 + 8 * g + 4 * h;
+                if (c0 >= p.cout) continue;
+                const f32x4 bv = *(const f32x4*)(p.bias + c0);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[i][j][4 * g + e] + bv[e];
+                    if (p.act) v[e] = silu<F32>(v[e]);
+                }
+                if (F32) {
+                    if (rrow) {
+                        const f32x4 rv = *(const f32x4*)(rrow + c0 * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    }
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(orow + c0 * 4) = o;
+                } else {
+                    if (rrow) {
+                        const uint2 rv = *(const uint2*)(rrow + c0 * 2);
+                        v[0] += aq_bf2f((bf16_t)(rv.x & 0xffff));
+                        v[1] += aq_bf2f((bf16_t)(rv.x >> 16));
+                        v[2] += aq_bf2f((bf16_t)(rv.y & 0xffff));
+                        v[3] += aq_bf2f((bf16_t)(rv.y >> 16));
+                    }
+                    if (OUT_F32) {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        *(f32x4*)(orow + c0 * 4) = o;
+                    } else {
+                        uint2 o;
+                        o.x = (uint32_t)aq_f2bf(v[0]) | ((uint32_t)aq_f2bf(v[1]) << 16);
+                        o.y = (uint32_t)aq_f2bf(v[2]) | ((uint32_t)aq_f2bf(v[3]) << 16);
+                        *(uint2*)(orow + c0 * 2) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct ConvConfig {
+    int bm, bn, threads;
+    void (*bf16)(const ConvParams);
+    void (*bf16_f32out)(const ConvParams);
+    void (*f32)(const ConvParams);
+};
+
+#define CFG(BM, BN, WM, WN)                                                                    \
+    { BM, BN, WM * WN * 64, conv_igemm_kernel<false, BM, BN, WM, WN, false>,                   \
+      conv_igemm_kernel<false, BM, BN, WM, WN, true>, conv_igemm_kernel<true, BM, BN, WM, WN, true> }
+
+const ConvConfig kConfigs[] = {
+    CFG(256, 256, 2, 4),   // 0: per-wave 128x64
+    CFG(192, 256, 2, 4),   // 1: per-wave  96x64
+    CFG(128, 256, 2, 4),   // 2: per-wave  64x64
+    CFG(96, 512, 1, 8),    // 3: per-wave  96x64
+    CFG(64, 512, 1, 8),    // 4: per-wave  64x64
+    CFG(32, 512, 1, 8),    // 5: per-wave  32x64  (detect heads, cout padded to 32)
+    CFG(192, 128, 2, 4),   // 6: per-wave  96x32  (small-M layers: more tiles)
+    CFG(128, 128, 2, 2),   // 7: per-wave  64x64, 4 waves
+    CFG(64, 256, 1, 4),    // 8: per-wave  64x64, 4 waves
+    CFG(96, 256, 1, 4),    // 9: per-wave  96x64, 4 waves
+    CFG(64, 128, 1, 4),    // 10: per-wave 64x32, 4 waves
+};
+constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
+bool g_attr_set[kNumConfigs][3];
+
+}  // namespace
+
+extern "C" int aq_conv_num_configs(void) { return kNumConfigs; }
+
+extern "C" int aq_conv_config_tiles(int cfg, int* bm, int* bn) {
+    if (cfg < 0 || cfg >= kNumConfigs) return AQ_ERR_INVALID;
+    *bm = kConfigs[cfg].bm;
+    *bn = kConfigs[cfg].bn;
+    return AQ_OK;
+}
+
+// Heuristic tile choice: fit Cout without waste, then prefer the tile that fills 256 CUs with the least tail.
+int aq_conv_pick_config(int cout, int npix, int precision) {
+    (void)precision;
+    int best = -1;
+    double best_cost = 1e30;
+    for (int c = 0; c < kNumConfigs; ++c) {
+        const ConvConfig& k = kConfigs[c];
+        const int tm = (cout + k.bm - 1) / k.bm, tn = (npix + k.bn - 1) / k.bn;
+        const double waste = (double)(tm * k.bm) / cout;              // padded MFMA rows
+        const int lds = 2 * (k.bm + k.bn) * 128;
+        const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
+        const double slots = 256.0 * wg_per_cu;
+        const double tiles = (double)tm * tn;
+        const double rounds = (double)((long long)((tiles + slots - 1) / slots));
+        const double tail = rounds * slots / tiles;                    // >= 1
+        // bigger tiles amortise LDS-DMA issue; score = relative time estimate
+        const double eff = (k.bm * k.bn >= 192 * 256) ? 1.0 : (k.bm * k.bn >= 128 * 256 ? 1.1 : (k.bm * k.bn >= 64 * 256 ? 1.3 : 1.6));
+        const double cost = waste * tail * eff;
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
+}
+
+int aq_launch_conv(const ConvParams& p_in, int precision, int out_f32, int cfg, hipStream_t stream) {
+    if (cfg < 0 || cfg >= kNumConfigs) { aq_set_error("conv: bad config %d", cfg); return AQ_ERR_INVALID; }
+    const ConvConfig& k = kConfigs[cfg];
+    ConvParams p = p_in;
+    p.n_tiles_m = (p.cout + k.bm - 1) / k.bm;
+    p.n_tiles_n = (p.npix + k.bn - 1) / k.bn;
+    const int variant = precision == AQ_FP32 ? 2 : (out_f32 ? 1 : 0);
+    auto fn = variant == 2 ? k.f32 : (variant == 1 ? k.bf16_f32out : k.bf16);
+    const size_t lds = (size_t)2 * (k.bm + k.bn) * 128;
+    if (!g_attr_set[cfg][variant]) {
+        AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        g_attr_set[cfg][variant] = true;
+    }
+    const long long grid = (long long)p.n_tiles_m * p.n_tiles_n;
+    if (grid <= 0 || grid > 0x7fffffffLL) { aq_set_error("conv: bad grid %lld", grid); return AQ_ERR_INVALID; }
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(k.threads), lds, stream, p);
+    AQ_CHECK_HIP(hipGetLastError());
+    return AQ_OK;
+}

@@ -1,0 +1,416 @@
+// Host side of libaqengine.so: C ABI (include/aq_engine.h), plan executor, weight packing, profiling.
+// The engine allocates device memory only in aq_engine_create (packed weights, zero page, events);
+// every launch-path function only enqueues work on the caller's stream.
+#include "aq_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+void aq_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* aq_last_error(void) { return g_err; }
+extern "C" int aq_version(void) { return 1; }
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr size_t kAlign = 256;
+constexpr int kCoutSlack = 256;   // packed weight rows beyond cout so any BM tile may over-read zeros
+
+struct PackedW {
+    void* w = nullptr;      // [cout_rows][kgroups_pad] x 16 B
+    float* bias = nullptr;  // [cout_rows]
+    int kgroups = 0, kgroups_pad = 0, G = 0, cout_rows = 0;
+};
+
+// Host-side packing: KRSC fp32 -> [cout_rows][kgroups_pad*16 B] of bf16 / fp32, zero padded.
+void pack_host(const float* w, int cout, int k, int cin, int precision, std::vector<unsigned char>& out,
+               int* kgroups, int* kgroups_pad, int* G, int* cout_rows) {
+    const int eb = aq_elem_bytes(precision);
+    const int g = cin * eb / 16;
+    const int kg = k * k * g;
+    const int kgp = (kg + 7) / 8 * 8;
+    const int rows = (cout + kCoutSlack + 31) / 32 * 32;
+    out.assign((size_t)rows * kgp * 16, 0);
+    const int kelems = k * k * cin;
+    for (int co = 0; co < cout; ++co) {
+        unsigned char* dst = out.data() + (size_t)co * kgp * 16;
+        const float* src = w + (size_t)co * kelems;
+        if (precision == AQ_FP32) {
+            memcpy(dst, src, (size_t)kelems * 4);
+        } else {
+            bf16_t* d = (bf16_t*)dst;
+            for (int e = 0; e < kelems; ++e) d[e] = aq_f2bf(src[e]);
+        }
+    }
+    *kgroups = kg; *kgroups_pad = kgp; *G = g; *cout_rows = rows;
+}
+
+struct TensorPlace { size_t offset = 0; size_t bytes = 0; int h = 0, w = 0, elem = 0; };
+
+}  // namespace
+
+struct aq_engine {
+    int device = 0;
+    aq_model_desc desc{};
+    std::vector<aq_tensor_desc> tensors;
+    std::vector<aq_op_desc> ops;
+    std::vector<PackedW> packed;        // per op (conv ops only)
+    std::vector<int> conv_cfg;          // per op override, -1 = heuristic
+    void* zero_page = nullptr;
+    // workspace layout of the last sizing / call
+    int lay_B = 0, lay_H = 0, lay_W = 0;
+    std::vector<TensorPlace> place;
+    size_t off_pred = 0, off_cand = 0, off_cand_count = 0, off_nms = 0, total_bytes = 0;
+    int N = 0;
+    void* last_ws = nullptr;
+    const uint8_t* last_tiles = nullptr;
+    // profiling
+    bool prof = false;
+    int ring = 0;
+    long long prof_calls = 0;
+    std::vector<hipEvent_t> ev;         // [ring][n_ops + 1]
+};
+
+namespace {
+
+int layout(aq_engine* e, int B, int H, int W) {
+    AQ_REQUIRE(B > 0 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0,
+               "tile size must be a positive multiple of the max stride 32 (got B=%d H=%d W=%d)", B, H, W);
+    if (e->lay_B == B && e->lay_H == H && e->lay_W == W) return AQ_OK;
+    const int eb = aq_elem_bytes(e->desc.precision);
+    size_t off = 0;
+    e->place.assign(e->tensors.size(), TensorPlace());
+    for (size_t t = 0; t < e->tensors.size(); ++t) {
+        const aq_tensor_desc& td = e->tensors[t];
+        TensorPlace& pl = e->place[t];
+        pl.h = H / td.down; pl.w = W / td.down;
+        pl.elem = td.dtype == AQ_T_F32 ? 4 : (td.dtype == AQ_T_U8 ? 1 : eb);
+        pl.bytes = (size_t)B * pl.h * pl.w * td.channels * pl.elem;
+        if ((int)t == e->desc.input_tensor) { pl.offset = (size_t)-1; continue; }   // caller's tiles
+        pl.offset = off;
+        off += align_up(pl.bytes, kAlign);
+    }
+    int N = 0;
+    for (int l = 0; l < e->desc.nl; ++l) {
+        const int s = (int)e->desc.stride[l];
+        N += e->desc.na * (H / s) * (W / s);
+    }
+    e->N = N;
+    e->off_pred = off; off += align_up((size_t)B * N * (e->desc.nc + 5) * sizeof(float), kAlign);
+    e->off_cand = off; off += align_up((size_t)B * N * sizeof(int32_t), kAlign);
+    e->off_cand_count = off; off += align_up((size_t)B * sizeof(int32_t), kAlign);
+    e->off_nms = off; off += align_up(aq_nms_scratch_bytes(B, N), kAlign);
+    e->total_bytes = off;
+    e->lay_B = B; e->lay_H = H; e->lay_W = W;
+    return AQ_OK;
+}
+
+inline char* tptr(aq_engine* e, void* ws, const uint8_t* tiles, int t) {
+    if (t == e->desc.input_tensor) return (char*)tiles;
+    return (char*)ws + e->place[t].offset;
+}
+
+int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStream_t stream) {
+    const aq_op_desc& op = e->ops[oi];
+    const PackedW& pw = e->packed[oi];
+    const int prec = e->desc.precision;
+    const TensorPlace& ps = e->place[op.src.tensor];
+    const TensorPlace& pd = e->place[op.dst.tensor];
+    const int eb = aq_elem_bytes(prec);
+    const int out_f32 = e->tensors[op.dst.tensor].dtype == AQ_T_F32;
+    ConvParams p{};
+    p.in = tptr(e, ws, tiles, op.src.tensor) + (size_t)op.src.ch_off * eb;
+    p.in_ld_b = e->tensors[op.src.tensor].channels * eb;
+    p.out = tptr(e, ws, tiles, op.dst.tensor) + (size_t)op.dst.ch_off * pd.elem;
+    p.out_ld_b = e->tensors[op.dst.tensor].channels * pd.elem;
+    if (op.res.tensor >= 0) {
+        p.res = tptr(e, ws, tiles, op.res.tensor) + (size_t)op.res.ch_off * eb;
+        p.res_ld_b = e->tensors[op.res.tensor].channels * eb;
+    }
+    p.w = (const char*)pw.w; p.bias = pw.bias; p.zero = (const char*)e->zero_page;
+    p.B = B; p.H = ps.h; p.W = ps.w; p.Ho = pd.h; p.Wo = pd.w;
+    p.cout = op.dst.channels;
+    p.k = op.k; p.stride = op.stride; p.pad = op.pad; p.taps = op.k * op.k;
+    p.G = pw.G; p.kgroups = pw.kgroups; p.kgroups_pad = pw.kgroups_pad; p.nchunks = pw.kgroups_pad / 8;
+    p.npix = B * pd.h * pd.w;
+    p.act = op.act;
+    int cfg = e->conv_cfg[oi];
+    if (cfg < 0) cfg = aq_conv_pick_config(p.cout, p.npix, prec);
+    return aq_launch_conv(p, prec, out_f32, cfg, stream);
+}
+
+int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, size_t ws_bytes,
+             float* pred_out, aq_det* dets, int32_t* counts, float conf, float iou, int max_det, hipStream_t stream) {
+    AQ_REQUIRE(e && tiles && ws, "infer: null pointer");
+    int rc = layout(e, B, H, W);
+    if (rc) return rc;
+    if (ws_bytes < e->total_bytes) {
+        aq_set_error("workspace too small: need %zu bytes, got %zu", e->total_bytes, ws_bytes);
+        return AQ_ERR_WORKSPACE;
+    }
+    e->last_ws = ws; e->last_tiles = tiles;
+    const int prec = e->desc.precision;
+    const int n_ops = (int)e->ops.size();
+    hipEvent_t* ev = nullptr;
+    if (e->prof && e->ring > 0) ev = e->ev.data() + (size_t)(e->prof_calls % e->ring) * (n_ops + 1);
+    float* pred = pred_out ? pred_out : (float*)((char*)ws + e->off_pred);
+    int32_t* cand = (int32_t*)((char*)ws + e->off_cand);
+    int32_t* cand_count = (int32_t*)((char*)ws + e->off_cand_count);
+    for (int oi = 0; oi < n_ops; ++oi) {
+        const aq_op_desc& op = e->ops[oi];
+        if (ev) AQ_CHECK_HIP(hipEventRecord(ev[oi], stream));
+        switch (op.kind) {
+        case AQ_OP_PREPROCESS:
+            rc = aq_preprocess_s2d(tiles, tptr(e, ws, tiles, op.dst.tensor), B, H, W, prec, stream);
+            break;
+        case AQ_OP_CONV:
+            rc = run_conv(e, oi, ws, tiles, B, stream);
+            break;
+        case AQ_OP_SPPF_POOL: {
+            const TensorPlace& pl = e->place[op.src.tensor];
+            rc = aq_sppf_pool(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
+                              op.src.channels, B, pl.h, pl.w, prec, stream);
+            break;
+        }
+        case AQ_OP_UPSAMPLE2X: {
+            const TensorPlace& pl = e->place[op.src.tensor];
+            rc = aq_upsample2x(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
+                               tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
+                               op.src.channels, B, pl.h, pl.w, prec, stream);
+            break;
+        }
+        case AQ_OP_DECODE: {
+            const float* heads[3];
+            for (int l = 0; l < 3; ++l) heads[l] = (const float*)tptr(e, ws, tiles, e->desc.head_tensor[l]);
+            float anchors[3 * 8 * 2];
+            for (int l = 0; l < 3; ++l)
+                for (int a = 0; a < e->desc.na; ++a) {
+                    anchors[(l * e->desc.na + a) * 2] = e->desc.anchors_px[l][a][0];
+                    anchors[(l * e->desc.na + a) * 2 + 1] = e->desc.anchors_px[l][a][1];
+                }
+            const bool want_nms = dets != nullptr;
+            rc = aq_detect_decode(heads, e->tensors[e->desc.head_tensor[0]].channels, B, H, W, e->desc.nc, e->desc.na,
+                                  anchors, e->desc.stride, pred, conf, want_nms ? cand : nullptr,
+                                  want_nms ? cand_count : nullptr, e->N, stream);
+            break;
+        }
+        case AQ_OP_NMS:
+            if (dets)
+                rc = aq_nms(pred, B, e->N, e->desc.nc, conf, iou, max_det, cand, cand_count, e->N,
+                            (char*)ws + e->off_nms, dets, counts, stream);
+            break;
+        default:
+            aq_set_error("unknown op kind %d", op.kind);
+            rc = AQ_ERR_INVALID;
+        }
+        if (rc) return rc;
+    }
+    if (ev) {
+        AQ_CHECK_HIP(hipEventRecord(ev[n_ops], stream));
+        e->prof_calls++;
+    }
+    return AQ_OK;
+}
+
+}  // namespace
+
+extern "C" int aq_pack_conv_weights(const float* w, int cout, int k, int cin, int precision, void* packed_dev,
+                                    size_t* bytes, void* stream) {
+    AQ_REQUIRE(w && bytes, "pack: null pointer");
+    AQ_REQUIRE(cout > 0 && k > 0 && cin > 0 && (cin * aq_elem_bytes(precision)) % 16 == 0,
+               "pack: cin=%d must make whole 16-byte groups", cin);
+    std::vector<unsigned char> host;
+    int kg, kgp, g, rows;
+    pack_host(w, cout, k, cin, precision, host, &kg, &kgp, &g, &rows);
+    *bytes = host.size();
+    if (packed_dev) {
+        AQ_CHECK_HIP(hipMemcpyAsync(packed_dev, host.data(), host.size(), hipMemcpyHostToDevice, (hipStream_t)stream));
+        AQ_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));   // host staging buffer dies here
+    }
+    return AQ_OK;
+}
+
+extern "C" int aq_conv2d(const void* in_dev, int in_ld, int in_choff, int cin, void* out_dev, int out_ld, int out_choff,
+                         int cout, const void* res_dev, int res_ld, int res_choff, const void* packed_w_dev,
+                         const float* bias_dev, int B, int H, int W, int k, int stride, int pad, int act, int precision,
+                         int out_f32, const void* zero_page_dev, void* stream) {
+    AQ_REQUIRE(in_dev && out_dev && packed_w_dev && bias_dev && zero_page_dev, "conv2d: null pointer");
+    const int eb = aq_elem_bytes(precision);
+    const int oeb = (precision == AQ_FP32 || out_f32) ? 4 : 2;
+    AQ_REQUIRE((cin * eb) % 16 == 0 && (in_ld * eb) % 16 == 0 && (in_choff * eb) % 16 == 0,
+               "conv2d: input channels must be whole 16-byte groups (cin=%d ld=%d off=%d)", cin, in_ld, in_choff);
+    AQ_REQUIRE(cout % 4 == 0 && out_choff % 4 == 0 && out_ld % 4 == 0, "conv2d: cout/out_choff/out_ld must be multiples of 4");
+    AQ_REQUIRE(k >= 1 && k * k <= 25 && stride >= 1 && pad >= 0, "conv2d: unsupported k=%d stride=%d pad=%d", k, stride, pad);
+    AQ_REQUIRE(precision == AQ_BF16 || precision == AQ_FP32, "conv2d: bad precision %d", precision);
+    ConvParams p{};
+    p.in = (const char*)in_dev + (size_t)in_choff * eb; p.in_ld_b = in_ld * eb;
+    p.out = (char*)out_dev + (size_t)out_choff * oeb; p.out_ld_b = out_ld * oeb;
+    if (res_dev) { p.res = (const char*)res_dev + (size_t)res_choff * eb; p.res_ld_b = res_ld * eb; }
+    p.w = (const char*)packed_w_dev; p.bias = bias_dev; p.zero = (const char*)zero_page_dev;
+    p.B = B; p.H = H; p.W = W;
+    p.Ho = (H + 2 * pad - k) / stride + 1; p.Wo = (W + 2 * pad - k) / stride + 1;
+    AQ_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d: empty output");
+    p.cout = cout; p.k = k; p.stride = stride; p.pad = pad; p.taps = k * k;
+    p.G = cin * eb / 16; p.kgroups = p.taps * p.G; p.kgroups_pad = (p.kgroups + 7) / 8 * 8; p.nchunks = p.kgroups_pad / 8;
+    p.npix = B * p.Ho * p.Wo; p.act = act;
+    int cfg = aq_conv_pick_config(cout, p.npix, precision);
+    const char* forced = getenv("AQ_CONV_CFG");
+    if (forced && *forced) cfg = atoi(forced);
+    return aq_launch_conv(p, precision, out_f32, cfg, (hipStream_t)stream);
+}
+
+extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** out) {
+    AQ_REQUIRE(d && out, "engine_create: null pointer");
+    AQ_REQUIRE(d->n_ops > 0 && d->n_tensors > 0 && d->ops && d->tensors, "engine_create: empty plan");
+    AQ_REQUIRE(d->nl == 3 && d->na >= 1 && d->na <= 8 && d->nc >= 1, "engine_create: unsupported head nl=%d na=%d nc=%d", d->nl, d->na, d->nc);
+    AQ_REQUIRE(d->precision == AQ_BF16 || d->precision == AQ_FP32, "engine_create: bad precision %d", d->precision);
+    AQ_CHECK_HIP(hipSetDevice(device));
+    aq_engine* e = new aq_engine();
+    e->device = device;
+    e->desc = *d;
+    e->tensors.assign(d->tensors, d->tensors + d->n_tensors);
+    e->ops.assign(d->ops, d->ops + d->n_ops);
+    e->desc.tensors = e->tensors.data();
+    e->desc.ops = e->ops.data();
+    e->packed.resize(e->ops.size());
+    e->conv_cfg.assign(e->ops.size(), -1);
+    const int eb = aq_elem_bytes(d->precision);
+    auto fail = [&](int rc) { aq_engine_destroy(e); return rc; };
+    if (hipMalloc(&e->zero_page, 4096) != hipSuccess || hipMemset(e->zero_page, 0, 4096) != hipSuccess) {
+        aq_set_error("engine_create: zero page allocation failed");
+        return fail(AQ_ERR_NOMEM);
+    }
+    for (size_t oi = 0; oi < e->ops.size(); ++oi) {
+        aq_op_desc& op = e->ops[oi];
+        for (const aq_slice* s : {&op.src, &op.dst}) {
+            if (op.kind == AQ_OP_DECODE || op.kind == AQ_OP_NMS) continue;
+            if (s->tensor < 0 || s->tensor >= d->n_tensors || s->ch_off < 0 ||
+                s->ch_off + s->channels > e->tensors[s->tensor].channels) {
+                aq_set_error("engine_create: op %zu has a slice outside its tensor", oi);
+                return fail(AQ_ERR_INVALID);
+            }
+        }
+        if (op.kind != AQ_OP_CONV) continue;
+        if (!op.weight || !op.bias || (op.src.channels * eb) % 16 != 0 || op.dst.channels % 4 != 0 || op.k * op.k > 25) {
+            aq_set_error("engine_create: conv op %zu unsupported (cin=%d cout=%d k=%d)", oi, op.src.channels, op.dst.channels, op.k);
+            return fail(AQ_ERR_INVALID);
+        }
+        std::vector<unsigned char> host;
+        PackedW& pw = e->packed[oi];
+        pack_host(op.weight, op.dst.channels, op.k, op.src.channels, d->precision, host, &pw.kgroups, &pw.kgroups_pad, &pw.G, &pw.cout_rows);
+        std::vector<float> bias(pw.cout_rows, 0.0f);
+        memcpy(bias.data(), op.bias, sizeof(float) * op.dst.channels);
+        if (hipMalloc(&pw.w, host.size()) != hipSuccess || hipMalloc((void**)&pw.bias, bias.size() * sizeof(float)) != hipSuccess) {
+            aq_set_error("engine_create: weight allocation failed (op %zu, %zu bytes)", oi, host.size());
+            return fail(AQ_ERR_NOMEM);
+        }
+        if (hipMemcpy(pw.w, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(pw.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            aq_set_error("engine_create: weight upload failed (op %zu)", oi);
+            return fail(AQ_ERR_HIP);
+        }
+        op.weight = nullptr; op.bias = nullptr;   // host pointers are not kept
+    }
+    *out = e;
+    return AQ_OK;
+}
+
+extern "C" void aq_engine_destroy(aq_engine* e) {
+    if (!e) return;
+    for (PackedW& pw : e->packed) {
+        if (pw.w) (void)hipFree(pw.w);
+        if (pw.bias) (void)hipFree(pw.bias);
+    }
+    if (e->zero_page) (void)hipFree(e->zero_page);
+    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    delete e;
+}
+
+extern "C" int aq_engine_workspace_bytes(aq_engine* e, int max_batch, int H, int W, size_t* bytes) {
+    AQ_REQUIRE(e && bytes, "workspace_bytes: null pointer");
+    int rc = layout(e, max_batch, H, W);
+    if (rc) return rc;
+    *bytes = e->total_bytes;
+    return AQ_OK;
+}
+
+extern "C" int aq_engine_infer(aq_engine* e, const uint8_t* tiles_dev, int B, int H, int W, void* ws, size_t ws_bytes,
+                               aq_det* dets_dev, int32_t* counts_dev, float conf, float iou, int max_det, void* stream) {
+    AQ_REQUIRE(dets_dev && counts_dev, "infer: null output pointer");
+    AQ_REQUIRE(max_det > 0 && conf >= 0.f && conf <= 1.f && iou >= 0.f && iou <= 1.f,
+               "infer: bad thresholds conf=%g iou=%g max_det=%d", conf, iou, max_det);
+    return run_plan(e, tiles_dev, B, H, W, ws, ws_bytes, nullptr, dets_dev, counts_dev, conf, iou, max_det, (hipStream_t)stream);
+}
+
+extern "C" int aq_engine_forward_raw(aq_engine* e, const uint8_t* tiles_dev, int B, int H, int W, void* ws, size_t ws_bytes,
+                                     float* pred_dev, void* stream) {
+    AQ_REQUIRE(pred_dev, "forward_raw: null output pointer");
+    return run_plan(e, tiles_dev, B, H, W, ws, ws_bytes, pred_dev, nullptr, nullptr, 0.f, 0.f, 1, (hipStream_t)stream);
+}
+
+extern "C" int aq_engine_tensor_ptr(aq_engine* e, int tensor, void** ptr, int* channels, int* h, int* w, int* elem_bytes) {
+    AQ_REQUIRE(e && ptr && tensor >= 0 && tensor < (int)e->tensors.size(), "tensor_ptr: bad tensor id %d", tensor);
+    AQ_REQUIRE(e->last_ws, "tensor_ptr: no call has run yet");
+    *ptr = tptr(e, e->last_ws, e->last_tiles, tensor);
+    if (channels) *channels = e->tensors[tensor].channels;
+    if (h) *h = e->place[tensor].h;
+    if (w) *w = e->place[tensor].w;
+    if (elem_bytes) *elem_bytes = e->place[tensor].elem;
+    return AQ_OK;
+}
+
+extern "C" int aq_engine_num_ops(aq_engine* e) { return e ? (int)e->ops.size() : 0; }
+
+extern "C" int aq_engine_set_conv_config(aq_engine* e, int op, int cfg) {
+    AQ_REQUIRE(e && op >= 0 && op < (int)e->ops.size() && e->ops[op].kind == AQ_OP_CONV, "set_conv_config: op %d is not a conv", op);
+    AQ_REQUIRE(cfg >= -1 && cfg < aq_conv_num_configs(), "set_conv_config: bad config %d", cfg);
+    e->conv_cfg[op] = cfg;
+    return AQ_OK;
+}
+
+extern "C" int aq_engine_profile(aq_engine* e, int enable, int ring) {
+    AQ_REQUIRE(e, "profile: null engine");
+    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    e->ev.clear();
+    e->prof = false; e->ring = 0; e->prof_calls = 0;
+    if (!enable) return AQ_OK;
+    AQ_REQUIRE(ring > 0 && ring <= 4096, "profile: ring must be in [1, 4096]");
+    const size_t n = (size_t)ring * (e->ops.size() + 1);
+    e->ev.resize(n);
+    for (size_t i = 0; i < n; ++i) AQ_CHECK_HIP(hipEventCreate(&e->ev[i]));
+    e->prof = true; e->ring = ring;
+    return AQ_OK;
+}
+
+extern "C" int aq_engine_op_times(aq_engine* e, float* ms_out, int n_ops, int* calls_recorded) {
+    AQ_REQUIRE(e && ms_out && n_ops == (int)e->ops.size(), "op_times: expected %d slots", e ? (int)e->ops.size() : 0);
+    AQ_REQUIRE(e->prof, "op_times: profiling is off");
+    const int calls = (int)(e->prof_calls < e->ring ? e->prof_calls : e->ring);
+    for (int i = 0; i < n_ops; ++i) ms_out[i] = 0.f;
+    for (int c = 0; c < calls; ++c) {
+        hipEvent_t* ev = e->ev.data() + (size_t)c * (n_ops + 1);
+        AQ_CHECK_HIP(hipEventSynchronize(ev[n_ops]));
+        for (int i = 0; i < n_ops; ++i) {
+            float ms = 0.f;
+            AQ_CHECK_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            ms_out[i] += ms;
+        }
+    }
+    if (calls > 0) for (int i = 0; i < n_ops; ++i) ms_out[i] /= calls;
+    if (calls_recorded) *calls_recorded = calls;
+    return AQ_OK;
+}

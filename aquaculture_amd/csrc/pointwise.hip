@@ -1,0 +1,156 @@
+// Memory-bound NHWC helpers: preprocess (u8 -> space-to-depth /255), SPPF max pools, nearest 2x upsample.
+// All are HBM/L2-bound byte movers: one lane moves one 16-byte group, lanes of a wave cover consecutive
+// groups of a pixel row so every access is coalesced.
+#include "aq_common.h"
+
+namespace {
+
+// [UPSTREAM detect.py run()]: im = torch.from_numpy(im).to(device).float(); im /= 255
+// fused with the 2x2 space-to-depth the stem conv (6x6/s2/p2 == 3x3/s1/p1 on s2d) reads:
+// out[b][Y][X][(dy*2+dx)*3 + c] = in[b][2Y+dy][2X+dx][c] / 255, channels 12..15 = 0.
+template <bool F32>
+__global__ __launch_bounds__(256) void preprocess_s2d_kernel(const uint8_t* __restrict__ in, char* __restrict__ out,
+                                                            int B, int H, int W) {
+    const int H2 = H >> 1, W2 = W >> 1;
+    const long long n = (long long)B * H2 * W2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int X = (int)(i % W2);
+        const long long t = i / W2;
+        const int Y = (int)(t % H2), b = (int)(t / H2);
+        float v[16];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const uint8_t* src = in + (((long long)b * H + 2 * Y + dy) * W + 2 * X) * 3;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) v[dy * 6 + e] = (float)src[e] / 255.0f;
+        }
+        v[12] = v[13] = v[14] = v[15] = 0.0f;
+        if (F32) {
+            f32x4* o = (f32x4*)(out + i * 64);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { f32x4 x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; o[q] = x; }
+        } else {
+            uint4* o = (uint4*)(out + i * 32);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                uint4 x;
+                x.x = aq_f2bf(v[8 * q + 0]) | ((uint32_t)aq_f2bf(v[8 * q + 1]) << 16);
+                x.y = aq_f2bf(v[8 * q + 2]) | ((uint32_t)aq_f2bf(v[8 * q + 3]) << 16);
+                x.z = aq_f2bf(v[8 * q + 4]) | ((uint32_t)aq_f2bf(v[8 * q + 5]) << 16);
+                x.w = aq_f2bf(v[8 * q + 6]) | ((uint32_t)aq_f2bf(v[8 * q + 7]) << 16);
+                o[q] = x;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t max_bf16x2(uint32_t a, uint32_t b) {
+    const float al = aq_bf2f((bf16_t)(a & 0xffff)), ah = aq_bf2f((bf16_t)(a >> 16));
+    const float bl = aq_bf2f((bf16_t)(b & 0xffff)), bh = aq_bf2f((bf16_t)(b >> 16));
+    const uint32_t lo = (bl > al) ? (b & 0xffff) : (a & 0xffff);
+    const uint32_t hi = (bh > ah) ? (b >> 16) : (a >> 16);
+    return lo | (hi << 16);
+}
+
+// nn.MaxPool2d(kernel_size=5, stride=1, padding=2): implicit -inf padding == clipped window.
+// One lane = one 16-byte channel group of one output pixel.
+template <bool F32>
+__global__ __launch_bounds__(256) void maxpool5_kernel(const char* __restrict__ in, char* __restrict__ out,
+                                                      int ld_b, int groups, int B, int H, int W) {
+    const long long n = (long long)B * H * W * groups;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        long long t = i / groups;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        const int y0 = max(y - 2, 0), y1 = min(y + 2, H - 1), x0 = max(x - 2, 0), x1 = min(x + 2, W - 1);
+        uint4 m = *(const uint4*)(in + (((long long)b * H + y) * W + x) * ld_b + g * 16);
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) {
+                const uint4 v = *(const uint4*)(in + (((long long)b * H + yy) * W + xx) * ld_b + g * 16);
+                if (F32) {
+                    m.x = __float_as_uint(fmaxf(__uint_as_float(m.x), __uint_as_float(v.x)));
+                    m.y = __float_as_uint(fmaxf(__uint_as_float(m.y), __uint_as_float(v.y)));
+                    m.z = __float_as_uint(fmaxf(__uint_as_float(m.z), __uint_as_float(v.z)));
+                    m.w = __float_as_uint(fmaxf(__uint_as_float(m.w), __uint_as_float(v.w)));
+                } else {
+                    m.x = max_bf16x2(m.x, v.x); m.y = max_bf16x2(m.y, v.y);
+                    m.z = max_bf16x2(m.z, v.z); m.w = max_bf16x2(m.w, v.w);
+                }
+            }
+        *(uint4*)(out + (((long long)b * H + y) * W + x) * ld_b + g * 16) = m;
+    }
+}
+
+// nn.Upsample(scale_factor=2, mode='nearest'): out[b][y][x] = in[b][y/2][x/2]; H, W are the INPUT size.
+__global__ __launch_bounds__(256) void upsample2x_kernel(const char* __restrict__ in, int in_ld_b,
+                                                        char* __restrict__ out, int out_ld_b,
+                                                        int groups, int B, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long long n = (long long)B * Ho * Wo * groups;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        long long t = i / groups;
+        const int x = (int)(t % Wo); t /= Wo;
+        const int y = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const uint4 v = *(const uint4*)(in + (((long long)b * H + (y >> 1)) * W + (x >> 1)) * in_ld_b + g * 16);
+        *(uint4*)(out + (((long long)b * Ho + y) * Wo + x) * out_ld_b + g * 16) = v;
+    }
+}
+
+inline unsigned grid_for(long long n, int block) {
+    long long g = (n + block - 1) / block;
+    const long long cap = 256 * 16;   // 256 CUs x 16 blocks, grid-stride the rest
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int aq_preprocess_s2d(const uint8_t* tiles_dev, void* out_dev, int B, int H, int W, int precision, void* stream) {
+    AQ_REQUIRE(tiles_dev && out_dev, "preprocess: null pointer");
+    AQ_REQUIRE(B > 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0), "preprocess: bad shape B=%d H=%d W=%d", B, H, W);
+    const long long n = (long long)B * (H / 2) * (W / 2);
+    if (precision == AQ_FP32)
+        hipLaunchKernelGGL(preprocess_s2d_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, tiles_dev, (char*)out_dev, B, H, W);
+    else
+        hipLaunchKernelGGL(preprocess_s2d_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, tiles_dev, (char*)out_dev, B, H, W);
+    AQ_CHECK_HIP(hipGetLastError());
+    return AQ_OK;
+}
+
+extern "C" int aq_sppf_pool(void* buf_dev, int ld, int ch_off, int c, int B, int H, int W, int precision, void* stream) {
+    const int eb = aq_elem_bytes(precision);
+    AQ_REQUIRE(buf_dev, "sppf_pool: null pointer");
+    AQ_REQUIRE((c * eb) % 16 == 0 && (ch_off * eb) % 16 == 0 && (ld * eb) % 16 == 0, "sppf_pool: channels must be 16-byte groups");
+    AQ_REQUIRE(ch_off + 4 * c <= ld, "sppf_pool: slices [x|y1|y2|y3] exceed the buffer width");
+    const int groups = c * eb / 16;
+    const long long n = (long long)B * H * W * groups;
+    char* base = (char*)buf_dev + (long long)ch_off * eb;
+    for (int s = 0; s < 3; ++s) {   // y1 = m(x), y2 = m(y1), y3 = m(y2)  [UPSTREAM SPPF.forward]
+        const char* in = base + (long long)s * c * eb;
+        char* out = base + (long long)(s + 1) * c * eb;
+        if (precision == AQ_FP32)
+            hipLaunchKernelGGL(maxpool5_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, ld * eb, groups, B, H, W);
+        else
+            hipLaunchKernelGGL(maxpool5_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, ld * eb, groups, B, H, W);
+    }
+    AQ_CHECK_HIP(hipGetLastError());
+    return AQ_OK;
+}
+
+extern "C" int aq_upsample2x(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff,
+                             int c, int B, int H, int W, int precision, void* stream) {
+    const int eb = aq_elem_bytes(precision);
+    AQ_REQUIRE(in_dev && out_dev, "upsample2x: null pointer");
+    AQ_REQUIRE((c * eb) % 16 == 0 && (in_choff * eb) % 16 == 0 && (out_choff * eb) % 16 == 0 &&
+               (in_ld * eb) % 16 == 0 && (out_ld * eb) % 16 == 0, "upsample2x: channels must be 16-byte groups");
+    const int groups = c * eb / 16;
+    const long long n = (long long)B * 4 * H * W * groups;
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const char*)in_dev + (long long)in_choff * eb, in_ld * eb,
+                       (char*)out_dev + (long long)out_choff * eb, out_ld * eb, groups, B, H, W);
+    AQ_CHECK_HIP(hipGetLastError());
+    return AQ_OK;
+}

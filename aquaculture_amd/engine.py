@@ -1,0 +1,342 @@
+"""ctypes binding of libaqengine.so (include/aq_engine.h) + the Python-side engine object.
+
+Mirrors the two operator seams of the reference's ``yolov5/detect.py`` (reference README.md:77)
+[UPSTREAM detect.py run()]:
+
+    pred = model(im)                                   -> Engine.forward_raw(tiles_u8)
+    pred = non_max_suppression(pred, conf, iou, ...)   -> Engine.nms(pred, ...)
+    both, fused, from uint8 tiles                      -> Engine.infer(tiles_u8, ...)
+
+PyTorch is used for device memory and streams only.  There is NO fallback: if the HIP library
+cannot be loaded, or no GPU is present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import spec as _spec
+from .checkpoint import Checkpoint, pack_plan_weights
+
+AQ_BF16, AQ_FP32 = 0, 1
+PRECISIONS = {"bf16": AQ_BF16, "fp32": AQ_FP32}
+_DTYPE_CODE = {"act": 0, "f32": 1, "u8": 2}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaqengine.so")
+
+
+class aq_tensor_desc(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("down", C.c_int32), ("dtype", C.c_int32)]
+
+
+class aq_slice(C.Structure):
+    _fields_ = [("tensor", C.c_int32), ("ch_off", C.c_int32), ("channels", C.c_int32)]
+
+
+class aq_op_desc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("src", aq_slice), ("dst", aq_slice), ("res", aq_slice),
+                ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("act", C.c_int32),
+                ("level", C.c_int32), ("weight", C.POINTER(C.c_float)), ("bias", C.POINTER(C.c_float)),
+                ("flops_per_tile", C.c_double)]
+
+
+class aq_model_desc(C.Structure):
+    _fields_ = [("precision", C.c_int32), ("nc", C.c_int32), ("na", C.c_int32), ("nl", C.c_int32),
+                ("anchors_px", C.c_float * 2 * 8 * 3), ("stride", C.c_float * 3),
+                ("head_tensor", C.c_int32 * 3), ("input_tensor", C.c_int32),
+                ("n_tensors", C.c_int32), ("n_ops", C.c_int32),
+                ("tensors", C.POINTER(aq_tensor_desc)), ("ops", C.POINTER(aq_op_desc))]
+
+
+class aq_det(C.Structure):
+    _fields_ = [("x1", C.c_float), ("y1", C.c_float), ("x2", C.c_float), ("y2", C.c_float),
+                ("conf", C.c_float), ("cls", C.c_float)]
+
+
+# every symbol include/aq_engine.h declares (tests check the library exports all of them)
+EXPORTS = (
+    "aq_last_error", "aq_version", "aq_engine_create", "aq_engine_destroy", "aq_engine_workspace_bytes",
+    "aq_engine_infer", "aq_engine_forward_raw", "aq_engine_tensor_ptr", "aq_engine_profile",
+    "aq_engine_op_times", "aq_engine_num_ops", "aq_engine_set_conv_config", "aq_conv_num_configs",
+    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_preprocess_s2d", "aq_sppf_pool",
+    "aq_upsample2x", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
+)
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen libaqengine.so and set argument types.  Raises if it is missing (no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: build it with `python -m aquaculture_amd.build` "
+                           "(there is no CPU/PyTorch fallback for the detect path)")
+    lib = C.CDLL(path)
+    vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    lib.aq_last_error.restype = C.c_char_p
+    lib.aq_engine_create.argtypes = [C.POINTER(aq_model_desc), i32, C.POINTER(vp)]
+    lib.aq_engine_destroy.argtypes = [vp]
+    lib.aq_engine_destroy.restype = None
+    lib.aq_engine_workspace_bytes.argtypes = [vp, i32, i32, i32, C.POINTER(sz)]
+    lib.aq_engine_infer.argtypes = [vp, vp, i32, i32, i32, vp, sz, vp, vp, f32, f32, i32, vp]
+    lib.aq_engine_forward_raw.argtypes = [vp, vp, i32, i32, i32, vp, sz, vp, vp]
+    lib.aq_engine_tensor_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.aq_engine_profile.argtypes = [vp, i32, i32]
+    lib.aq_engine_op_times.argtypes = [vp, C.POINTER(f32), i32, C.POINTER(i32)]
+    lib.aq_engine_num_ops.argtypes = [vp]
+    lib.aq_engine_set_conv_config.argtypes = [vp, i32, i32]
+    lib.aq_conv_config_tiles.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.aq_pack_conv_weights.argtypes = [C.POINTER(f32), i32, i32, i32, i32, vp, C.POINTER(sz), vp]
+    lib.aq_conv2d.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, i32, vp, vp,
+                              i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.aq_preprocess_s2d.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    lib.aq_sppf_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.aq_upsample2x.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.aq_detect_decode.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32),
+                                     vp, f32, vp, vp, i32, vp]
+    lib.aq_nms_scratch_bytes.argtypes = [i32, i32]
+    lib.aq_nms_scratch_bytes.restype = sz
+    lib.aq_nms.argtypes = [vp, i32, i32, i32, f32, f32, i32, vp, vp, i32, vp, vp, vp, vp]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(f"libaqengine error {rc}: {load_library().aq_last_error().decode()}")
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise RuntimeError("aquaculture_amd needs a ROCm GPU (MI355X/gfx950); there is no CPU fallback")
+
+
+def _act_dtype(precision: int) -> torch.dtype:
+    return torch.float32 if precision == AQ_FP32 else torch.bfloat16
+
+
+class Engine:
+    """YOLOv5 tile engine on one GPU.  Owns the C engine (packed weights) and a workspace tensor."""
+
+    def __init__(self, ck: Checkpoint, precision: str = "bf16", device: int = 0):
+        _require_gpu()
+        self.lib = load_library()
+        self.ck = ck
+        self.precision = PRECISIONS[precision]
+        self.device = torch.device("cuda", device)
+        self.plan = _spec.build_plan(ck.variant, ck.nc, ck.na)
+        self.no = ck.nc + 5
+        packed = pack_plan_weights(ck, self.plan)
+        self._keep = packed   # host arrays must outlive aq_engine_create only, kept for debugging
+        tens = (aq_tensor_desc * len(self.plan.tensors))()
+        for i, t in enumerate(self.plan.tensors):
+            tens[i] = aq_tensor_desc(t.channels, t.down, _DTYPE_CODE[t.dtype])
+        ops = (aq_op_desc * len(self.plan.ops))()
+        self.plan.flops(640, 640)
+        ci = 0
+        for i, o in enumerate(self.plan.ops):
+            d = aq_op_desc()
+            d.kind = o.kind
+            for name in ("src", "dst", "res"):
+                s = getattr(o, name)
+                setattr(d, name, aq_slice(s.tensor, s.ch_off, s.channels) if s is not None else aq_slice(-1, 0, 0))
+            d.k, d.stride, d.pad, d.act, d.level = o.k, o.stride, o.pad, o.act, o.level
+            d.flops_per_tile = o.flops_per_tile
+            if o.kind == _spec.OP_CONV:
+                pw = packed[ci]
+                ci += 1
+                d.weight = pw.weight.ctypes.data_as(C.POINTER(C.c_float))
+                d.bias = pw.bias.ctypes.data_as(C.POINTER(C.c_float))
+            ops[i] = d
+        desc = aq_model_desc()
+        desc.precision, desc.nc, desc.na, desc.nl = self.precision, ck.nc, ck.na, 3
+        ag = ck.anchor_grid_px().numpy()
+        for l in range(3):
+            desc.stride[l] = ck.stride[l]
+            desc.head_tensor[l] = self.plan.head_tensors[l]
+            for a in range(ck.na):
+                desc.anchors_px[l][a][0] = float(ag[l, a, 0])
+                desc.anchors_px[l][a][1] = float(ag[l, a, 1])
+        desc.input_tensor = self.plan.input_tensor
+        desc.n_tensors, desc.n_ops = len(self.plan.tensors), len(self.plan.ops)
+        desc.tensors, desc.ops = tens, ops
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.aq_engine_create(C.byref(desc), device, C.byref(h)))
+        self.handle = h
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_key: Optional[Tuple[int, int, int]] = None
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.aq_engine_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- workspace ----
+    def workspace(self, B: int, H: int, W: int) -> torch.Tensor:
+        n = C.c_size_t()
+        _check(self.lib.aq_engine_workspace_bytes(self.handle, B, H, W, C.byref(n)))
+        if self._ws is None or self._ws.numel() < n.value:
+            self._ws = None
+            self._ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def num_candidates(self, H: int, W: int) -> int:
+        return _spec.num_candidates(H, W, self.ck.na)
+
+    @staticmethod
+    def _check_tiles(tiles: torch.Tensor) -> Tuple[int, int, int]:
+        if tiles.dtype != torch.uint8 or tiles.dim() != 4 or tiles.shape[3] != 3 or not tiles.is_cuda or not tiles.is_contiguous():
+            raise ValueError("tiles must be a contiguous CUDA uint8 tensor [B, H, W, 3] (RGB)")
+        return int(tiles.shape[0]), int(tiles.shape[1]), int(tiles.shape[2])
+
+    # ---- S1 + S2 ----
+    def infer(self, tiles: torch.Tensor, conf_thres: float = 0.25, iou_thres: float = 0.45, max_det: int = 1000,
+              out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """uint8 [B,H,W,3] -> (dets float32 [B,max_det,6] = x1,y1,x2,y2,conf,cls ; counts int32 [B])."""
+        B, H, W = self._check_tiles(tiles)
+        ws = self.workspace(B, H, W)
+        if out is None:
+            dets = torch.empty((B, max_det, 6), dtype=torch.float32, device=self.device)
+            counts = torch.empty((B,), dtype=torch.int32, device=self.device)
+        else:
+            dets, counts = out
+        _check(self.lib.aq_engine_infer(self.handle, tiles.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(),
+                                        dets.data_ptr(), counts.data_ptr(), conf_thres, iou_thres, max_det, _stream_ptr()))
+        return dets, counts
+
+    # ---- S1 ----
+    def forward_raw(self, tiles: torch.Tensor) -> torch.Tensor:
+        """uint8 [B,H,W,3] -> pred float32 [B, N, 5+nc] (what Detect.forward returns at inference)."""
+        B, H, W = self._check_tiles(tiles)
+        ws = self.workspace(B, H, W)
+        pred = torch.empty((B, self.num_candidates(H, W), self.no), dtype=torch.float32, device=self.device)
+        _check(self.lib.aq_engine_forward_raw(self.handle, tiles.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(),
+                                              pred.data_ptr(), _stream_ptr()))
+        return pred
+
+    # ---- S2 ----
+    def nms(self, pred: torch.Tensor, conf_thres=0.25, iou_thres=0.45, max_det=1000) -> Tuple[torch.Tensor, torch.Tensor]:
+        return nms(pred, self.ck.nc, conf_thres, iou_thres, max_det)
+
+    # ---- test / tuning hooks ----
+    def tensor(self, tensor_id: int, B: int) -> torch.Tensor:
+        """View of plan tensor ``tensor_id`` ([B,h,w,C]) inside the workspace after a call (tests only)."""
+        p, c, h, w, eb = C.c_void_p(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _check(self.lib.aq_engine_tensor_ptr(self.handle, tensor_id, C.byref(p), C.byref(c), C.byref(h), C.byref(w), C.byref(eb)))
+        off = p.value - self._ws.data_ptr()
+        nbytes = B * h.value * w.value * c.value * eb.value
+        dt = {1: torch.uint8, 2: torch.bfloat16, 4: torch.float32}[eb.value]
+        return self._ws[off:off + nbytes].view(dt).view(B, h.value, w.value, c.value)
+
+    def tensor_by_name(self, name: str, B: int) -> torch.Tensor:
+        ids = [i for i, t in enumerate(self.plan.tensors) if t.name == name]
+        return self.tensor(ids[0], B)
+
+    def set_conv_config(self, op: int, cfg: int) -> None:
+        _check(self.lib.aq_engine_set_conv_config(self.handle, op, cfg))
+
+    def profile(self, enable: bool, ring: int = 32) -> None:
+        _check(self.lib.aq_engine_profile(self.handle, int(enable), ring))
+
+    def op_times_ms(self) -> Tuple[np.ndarray, int]:
+        n = len(self.plan.ops)
+        buf = (C.c_float * n)()
+        calls = C.c_int()
+        _check(self.lib.aq_engine_op_times(self.handle, buf, n, C.byref(calls)))
+        return np.array(buf[:], dtype=np.float64), calls.value
+
+
+# --------------------------------------------------------------------------------------
+# individual kernels (used by the parity tests; same C entry points the engine uses)
+# --------------------------------------------------------------------------------------
+def nms(pred: torch.Tensor, nc: int, conf_thres=0.25, iou_thres=0.45, max_det=1000) -> Tuple[torch.Tensor, torch.Tensor]:
+    """non_max_suppression(pred, conf, iou, classes=None, agnostic=False, multi_label=False, max_det) on device."""
+    _require_gpu()
+    lib = load_library()
+    if pred.dtype != torch.float32 or pred.dim() != 3 or not pred.is_cuda or not pred.is_contiguous():
+        raise ValueError("pred must be a contiguous CUDA float32 tensor [B, N, 5+nc]")
+    B, N, no = pred.shape
+    if no != nc + 5:
+        raise ValueError(f"pred last dim {no} != nc + 5 = {nc + 5}")
+    scratch = torch.empty(lib.aq_nms_scratch_bytes(B, N), dtype=torch.uint8, device=pred.device)
+    dets = torch.empty((B, max_det, 6), dtype=torch.float32, device=pred.device)
+    counts = torch.empty((B,), dtype=torch.int32, device=pred.device)
+    _check(lib.aq_nms(pred.data_ptr(), B, N, nc, conf_thres, iou_thres, max_det, None, None, 0,
+                      scratch.data_ptr(), dets.data_ptr(), counts.data_ptr(), _stream_ptr()))
+    return dets, counts
+
+
+_zero_pages: Dict[int, torch.Tensor] = {}
+
+
+def _zero_page(device) -> torch.Tensor:
+    key = device.index or 0
+    if key not in _zero_pages:
+        _zero_pages[key] = torch.zeros(4096, dtype=torch.uint8, device=device)
+    return _zero_pages[key]
+
+
+def pack_conv_weights(w_oihw: torch.Tensor, precision: str, device) -> torch.Tensor:
+    """fp32 (Cout,Cin,k,k) -> packed device buffer the conv kernels read."""
+    lib = load_library()
+    prec = PRECISIONS[precision]
+    w = np.ascontiguousarray(w_oihw.permute(0, 2, 3, 1).float().cpu().numpy())
+    cout, k, _, cin = w.shape
+    n = C.c_size_t()
+    wp = w.ctypes.data_as(C.POINTER(C.c_float))
+    _check(lib.aq_pack_conv_weights(wp, cout, k, cin, prec, None, C.byref(n), None))
+    buf = torch.empty(n.value, dtype=torch.uint8, device=device)
+    _check(lib.aq_pack_conv_weights(wp, cout, k, cin, prec, buf.data_ptr(), C.byref(n), _stream_ptr()))
+    return buf
+
+
+def conv2d_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, stride=1, pad=None, act=True,
+                residual: Optional[torch.Tensor] = None, precision="bf16", out_f32=False,
+                cfg: Optional[int] = None) -> torch.Tensor:
+    """out = (residual +) SiLU(conv(x, w) + b) on NHWC tensors through aq_conv2d (tests)."""
+    _require_gpu()
+    lib = load_library()
+    prec = PRECISIONS[precision]
+    assert x.is_cuda and x.is_contiguous() and x.dtype == _act_dtype(prec)
+    B, H, W, cin = x.shape
+    cout, _, k, _ = w_oihw.shape
+    pad = k // 2 if pad is None else pad
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    wbuf = pack_conv_weights(w_oihw, precision, x.device)
+    bbuf = torch.zeros(cout + 512, dtype=torch.float32, device=x.device)
+    bbuf[:cout] = bias.float().to(x.device)
+    odt = torch.float32 if (out_f32 or prec == AQ_FP32) else torch.bfloat16
+    out = torch.empty((B, Ho, Wo, cout), dtype=odt, device=x.device)
+    res_ptr = residual.data_ptr() if residual is not None else None
+    old = os.environ.get("AQ_CONV_CFG")
+    if cfg is not None:
+        os.environ["AQ_CONV_CFG"] = str(cfg)
+    try:
+        _check(lib.aq_conv2d(x.data_ptr(), cin, 0, cin, out.data_ptr(), cout, 0, cout, res_ptr, cout, 0,
+                             wbuf.data_ptr(), bbuf.data_ptr(), B, H, W, k, stride, pad, int(act), prec, int(out_f32),
+                             _zero_page(x.device).data_ptr(), _stream_ptr()))
+    finally:
+        if cfg is not None:
+            if old is None:
+                os.environ.pop("AQ_CONV_CFG", None)
+            else:
+                os.environ["AQ_CONV_CFG"] = old
+    torch.cuda.current_stream().synchronize()   # wbuf/bbuf are freed on return
+    return out

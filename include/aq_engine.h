@@ -1,0 +1,163 @@
+/*
+ * aq_engine.h -- C ABI of the MI355X-native YOLOv5 detect path (libaqengine.so).
+ *
+ * What it replaces.  The reference runs the path as a shell command,
+ *     python3 yolov5/detect.py --weights W --source DIR --nosave --save-txt --save-conf
+ * (reference README.md:77); there is no FFI in the reference for it, and the code it
+ * runs is the un-vendored ultralytics/yolov5 submodule (/root/reference/yolov5/yolov5
+ * is empty).  The two operator seams inside that script where a native engine plugs
+ * in are [UPSTREAM detect.py run()]:
+ *     S1  pred = model(im)                      float[B,3,H,W] -> float[B, N, 5+nc]
+ *     S2  pred = non_max_suppression(pred, conf_thres, iou_thres, classes, agnostic, max_det)
+ * aq_engine_infer() is S1+S2 fused (uint8 tiles in, per-tile detections out);
+ * aq_engine_forward_raw() is S1 alone; aq_nms() is S2 alone; the remaining entry points
+ * are the individual kernels, exported so each one can be parity-tested by itself.
+ *
+ * Conventions.
+ *   - plain C, pointers and sizes only; every *_dev pointer is device (HBM) memory owned by
+ *     the caller; nothing here allocates in a launch path (hipGraph-capture safe).
+ *   - all work is enqueued on the hipStream_t passed in (as void*), no host sync.
+ *   - return 0 (AQ_OK) or a negative aq_status; aq_last_error() gives a thread-local message.
+ *   - activations are NHWC; a tensor argument is (base pointer, pixel stride in elements,
+ *     first channel): channel slices of wider buffers are first-class (free Concat).
+ */
+#ifndef AQ_ENGINE_H
+#define AQ_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum aq_status {
+    AQ_OK = 0,
+    AQ_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+    AQ_ERR_HIP = -2,         /* a HIP runtime call failed */
+    AQ_ERR_NOMEM = -3,
+    AQ_ERR_WORKSPACE = -4    /* workspace too small */
+} aq_status;
+
+typedef enum aq_precision {
+    AQ_BF16 = 0,   /* bf16 weights + activations, fp32 accumulate/epilogue/head (throughput mode) */
+    AQ_FP32 = 1    /* fp32 everywhere on f32-input MFMA (parity mode: detect.py without --half) */
+} aq_precision;
+
+typedef enum aq_op_kind {
+    AQ_OP_PREPROCESS = 0, AQ_OP_CONV = 1, AQ_OP_SPPF_POOL = 2, AQ_OP_UPSAMPLE2X = 3,
+    AQ_OP_DECODE = 4, AQ_OP_NMS = 5
+} aq_op_kind;
+
+typedef enum aq_tensor_dtype { AQ_T_ACT = 0, AQ_T_F32 = 1, AQ_T_U8 = 2 } aq_tensor_dtype;
+
+/* One HBM buffer of the plan: NHWC, `channels` contiguous, spatial = (H/down, W/down). */
+typedef struct aq_tensor_desc {
+    int32_t channels;
+    int32_t down;
+    int32_t dtype;            /* aq_tensor_dtype */
+} aq_tensor_desc;
+
+typedef struct aq_slice { int32_t tensor, ch_off, channels; } aq_slice;
+
+/* One step of the plan (see aquaculture_amd/spec.py for how the YOLOv5 graph is flattened). */
+typedef struct aq_op_desc {
+    int32_t kind;             /* aq_op_kind */
+    aq_slice src, dst, res;   /* res.tensor < 0: no residual */
+    int32_t k, stride, pad;
+    int32_t act;              /* 1 = SiLU, 0 = identity */
+    int32_t level;            /* detect level of a head conv, else -1 */
+    const float* weight;      /* host, fp32, KRSC [cout][k][k][cin], BN already folded */
+    const float* bias;        /* host, fp32 [cout] */
+    double flops_per_tile;    /* algorithmic FLOPs of this op for one tile (reporting only) */
+} aq_op_desc;
+
+typedef struct aq_model_desc {
+    int32_t precision;        /* aq_precision */
+    int32_t nc, na, nl;       /* classes, anchors per level, levels (3) */
+    float anchors_px[3][8][2];/* anchor_grid = anchors * stride, pixels, [level][anchor][w,h] */
+    float stride[3];
+    int32_t head_tensor[3];   /* plan tensor ids of the raw fp32 head maps */
+    int32_t input_tensor;     /* plan tensor id of the u8 tiles */
+    int32_t n_tensors, n_ops;
+    const aq_tensor_desc* tensors;
+    const aq_op_desc* ops;
+} aq_model_desc;
+
+/* One output detection, in network-input pixels (before scale_boxes), as NMS returns it:
+ * [UPSTREAM non_max_suppression] rows (x1, y1, x2, y2, conf, cls). */
+typedef struct aq_det { float x1, y1, x2, y2, conf, cls; } aq_det;
+
+typedef struct aq_engine aq_engine;
+
+const char* aq_last_error(void);
+int aq_version(void);
+
+/* ---- engine (S1 + S2) ---------------------------------------------------------------- */
+/* Copies + packs the weights to the device (the only allocation the engine ever does). */
+int aq_engine_create(const aq_model_desc* desc, int device_ordinal, aq_engine** out);
+void aq_engine_destroy(aq_engine* e);
+/* Bytes of caller-provided workspace needed for batches up to max_batch of HxW tiles. */
+int aq_engine_workspace_bytes(aq_engine* e, int max_batch, int H, int W, size_t* bytes);
+/* tiles_dev: uint8 [B][H][W][3] RGB.  dets_dev: [B][max_det].  counts_dev: [B].
+ * Replaces `pred = model(im); pred = non_max_suppression(pred, conf, iou, None, False, max_det)`. */
+int aq_engine_infer(aq_engine* e, const uint8_t* tiles_dev, int B, int H, int W,
+                    void* workspace_dev, size_t workspace_bytes,
+                    aq_det* dets_dev, int32_t* counts_dev,
+                    float conf_thres, float iou_thres, int max_det, void* stream);
+/* S1 only: pred_dev float [B][N][5+nc] (xywh px, obj, cls) exactly as Detect.forward returns it. */
+int aq_engine_forward_raw(aq_engine* e, const uint8_t* tiles_dev, int B, int H, int W,
+                          void* workspace_dev, size_t workspace_bytes, float* pred_dev, void* stream);
+/* Test hook: device address + geometry of plan tensor `tensor` inside the workspace of the last call. */
+int aq_engine_tensor_ptr(aq_engine* e, int tensor, void** ptr, int* channels, int* h, int* w, int* elem_bytes);
+/* Per-op device timing with HIP events on the launch stream (bench.py roofline).  ring = number of
+ * infer calls whose events are kept; aq_engine_op_times returns mean ms per op over recorded calls. */
+int aq_engine_profile(aq_engine* e, int enable, int ring);
+int aq_engine_op_times(aq_engine* e, float* ms_out, int n_ops, int* calls_recorded);
+int aq_engine_num_ops(aq_engine* e);
+/* Tuning hook: force the tile configuration of one conv op (-1 = built-in heuristic). */
+int aq_engine_set_conv_config(aq_engine* e, int op, int cfg);
+int aq_conv_num_configs(void);
+int aq_conv_config_tiles(int cfg, int* bm, int* bn);
+
+/* ---- individual kernels --------------------------------------------------------------- */
+/* Packs fp32 KRSC host weights into the device layout conv kernels read:
+ * [cout_pad][k_pad] elements of `precision`, k = (ky, kx, cin) flattened, zero padded.  Returns the
+ * byte count via *bytes when packed_dev == NULL. */
+int aq_pack_conv_weights(const float* w_krsc_host, int cout, int k, int cin, int precision,
+                         void* packed_dev, size_t* bytes, void* stream);
+/* Implicit-GEMM convolution, NHWC, fused bias + SiLU + residual.  in/out/res element type = precision
+ * (out is fp32 when out_f32 != 0).  Replaces Conv.forward_fuse / Bottleneck.forward of the reference's
+ * yolov5 dependency [UPSTREAM models/common.py]. */
+int aq_conv2d(const void* in_dev, int in_ld, int in_choff, int cin,
+              void* out_dev, int out_ld, int out_choff, int cout,
+              const void* res_dev, int res_ld, int res_choff,
+              const void* packed_w_dev, const float* bias_dev,
+              int B, int H, int W, int k, int stride, int pad, int act,
+              int precision, int out_f32, const void* zero_page_dev, void* stream);
+/* uint8 RGB NHWC -> 2x2 space-to-depth, 16 channels, value/255 ([UPSTREAM detect.py: im.float()/255]). */
+int aq_preprocess_s2d(const uint8_t* tiles_dev, void* out_dev, int B, int H, int W, int precision, void* stream);
+/* SPPF pools: y1 = mp5(x), y2 = mp5(y1), y3 = mp5(y2) written to channel slices c, 2c, 3c of the same buffer. */
+int aq_sppf_pool(void* buf_dev, int ld, int ch_off, int c, int B, int H, int W, int precision, void* stream);
+/* nearest 2x upsample of a channel slice into a channel slice. */
+int aq_upsample2x(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff,
+                  int c, int B, int H, int W, int precision, void* stream);
+/* Detect.forward inference branch on raw fp32 head maps [B][ny][nx][head_ld] (channel = a*no + o):
+ * writes pred [B][N][no] when pred_dev != NULL; when cand_dev != NULL also compacts candidates with
+ * obj > conf_thres into cand_dev[B][cand_cap] (index into N) and cand_count_dev[B]. */
+int aq_detect_decode(const float* const head_dev[3], int head_ld, int B, int H, int W, int nc, int na,
+                     const float* anchors_px /* [3][na][2] host */, const float* stride /* [3] host */,
+                     float* pred_dev, float conf_thres, int32_t* cand_dev, int32_t* cand_count_dev,
+                     int cand_cap, void* stream);
+/* S2: non_max_suppression(pred, conf, iou, classes=None, agnostic=False, multi_label=False, max_det).
+ * scratch_dev: aq_nms_scratch_bytes(B, N).  Deterministic: ties in confidence by ascending candidate index;
+ * no wall-clock time limit. */
+size_t aq_nms_scratch_bytes(int B, int N);
+int aq_nms(const float* pred_dev, int B, int N, int nc, float conf_thres, float iou_thres, int max_det,
+           const int32_t* cand_dev, const int32_t* cand_count_dev, int cand_cap,
+           void* scratch_dev, aq_det* dets_dev, int32_t* counts_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AQ_ENGINE_H */

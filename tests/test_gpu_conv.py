@@ -1,0 +1,77 @@
+"""Parity of the implicit-GEMM conv kernel (aq_conv2d through the C ABI) against torch CPU conv2d.
+
+fp32 mode: exact-fp32 MFMA vs F.conv2d fp32 -> tolerance 2e-5 relative to the output scale (summation order only).
+bf16 mode: the oracle is F.conv2d on bf16-ROUNDED inputs/weights in fp32 (the kernel's own semantics);
+           outputs may differ by one bf16 ulp where the fp32 sums straddle a rounding boundary.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x_nhwc, w, b, stride, pad, act, res, quant):
+    x = x_nhwc.permute(0, 3, 1, 2).float()
+    if quant:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    y = F.conv2d(x, w, b, stride=stride, padding=pad)
+    if act:
+        y = F.silu(y)
+    if res is not None:
+        y = y + res.permute(0, 3, 1, 2).float()
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+CASES = [
+    # B, H, W, cin, cout, k, stride, act, residual
+    (2, 20, 20, 64, 64, 1, 1, True, False),
+    (1, 16, 24, 48, 96, 3, 2, True, False),
+    (2, 20, 20, 192, 192, 3, 1, True, True),
+    (1, 40, 40, 96, 48, 1, 1, True, False),
+    (3, 8, 8, 384, 32, 1, 1, False, False),
+    (1, 32, 32, 16, 48, 3, 1, True, False),
+    (2, 12, 20, 768, 384, 1, 1, True, False),
+    (1, 9, 7, 32, 64, 3, 1, True, True),      # ragged spatial size: tile tail + every border case
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_conv_matches_reference(lib, case, precision):
+    from aquaculture_amd import engine
+    B, H, W, cin, cout, k, stride, act, use_res = case
+    g = torch.Generator().manual_seed(1234 + cin + cout)
+    x = torch.randn(B, H, W, cin, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Ho, Wo, cout, generator=g) if use_res else None
+    dt = torch.float32 if precision == "fp32" else torch.bfloat16
+    xd = x.to(dt).cuda()
+    rd = res.to(dt).cuda() if res is not None else None
+    ref = _ref(xd.cpu(), w, b, stride, pad, act, rd.cpu() if rd is not None else None, precision == "bf16")
+    for cfg in range(lib.aq_conv_num_configs()):
+        out = engine.conv2d_nhwc(xd, w, b, stride=stride, act=act, residual=rd, precision=precision, cfg=cfg).cpu().float()
+        assert out.shape == ref.shape
+        if precision == "fp32":
+            torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-5)
+        else:
+            # within one bf16 ulp (2^-8 relative) of the exactly-rounded reference
+            torch.testing.assert_close(out, ref.bfloat16().float(), rtol=2 ** -7, atol=1e-3)
+
+
+def test_conv_f32_out_head(lib):
+    """Detect-head form: bf16 inputs, fp32 output, no activation, cout padded to 32."""
+    from aquaculture_amd import engine
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 20, 20, 192, generator=g).bfloat16()
+    w = torch.zeros(32, 192, 1, 1)
+    w[:30] = torch.randn(30, 192, 1, 1, generator=g) * 0.1
+    b = torch.zeros(32)
+    b[:30] = torch.randn(30, generator=g)
+    out = engine.conv2d_nhwc(x.cuda(), w, b, act=False, precision="bf16", out_f32=True).cpu()
+    ref = _ref(x, w, b, 1, 0, False, None, True)
+    assert out.dtype == torch.float32
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
