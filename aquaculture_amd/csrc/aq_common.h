@@ -49,7 +49,7 @@ struct ConvParams {
     const char* zero;    // >= 16 zero bytes
     int in_ld_b, out_ld_b, res_ld_b;   // pixel strides in BYTES
     int B, H, W, Ho, Wo;
-    int cout;            // real cout (multiple of 4)
+    int cout;            // real cout (multiple of 8)
     int k, stride, pad, taps;
     int G;               // 16-byte groups per tap = cin * sizeof(T) / 16
     int kgroups;         // taps * G

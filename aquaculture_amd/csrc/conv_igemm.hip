@@ -175,67 +175,97 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvPara
         __syncthreads();
     }
 
-    // ---------------- epilogue: +bias, SiLU, +residual, store NHWC ----------------
-    // MFMA C/D map (32x32): column (pixel) = lane & 31, row (cout) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // ---------------- epilogue: +bias, SiLU -> LDS transpose -> (+residual) -> coalesced NHWC stores ----------------
+    // MFMA C/D map (32x32): column (pixel) = lane & 31, row (cout) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5):
+    // a lane holds 4-channel slivers of one pixel, so a direct store would touch 32 cache lines per instruction.
+    // Each wave instead transposes one 32-pixel block at a time through its own LDS region (fp32, padded rows)
+    // and then writes whole pixel rows: 8 consecutive channels (16 B of bf16) per lane, lanes along the row.
+    constexpr int CW = TM * 32;                 // couts of this wave
+    constexpr int ROWF = CW * 4 + 16;           // padded fp32 row (bytes): +16 B keeps ds_write_b128 conflict-free
+    constexpr int NCH = CW / 8;                 // 8-channel chunks per pixel row
+    constexpr int ITEMS = 32 * NCH;
+    char* stg = smem + wave * (32 * ROWF);
+    const int cbase = m0 + wm * (BM / WM);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int P = n0 + wn * (BN / WN) + j * 32 + l31;
-        if (P >= p.npix) continue;
-        char* orow = p.out + (long long)P * p.out_ld_b;
-        const char* rrow = p.res ? p.res + (long long)P * p.res_ld_b : nullptr;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int c0 = m0 + wm * (BM / WM) + i * 32 + 8 * g + 4 * h;
-                if (c0 >= p.cout) continue;
-                const f32x4 bv = *(const f32x4*)(p.bias + c0);
-                float v[4];
+                const int cl = i * 32 + 8 * g + 4 * h;        // channel within the wave's CW
+                const f32x4 bv = *(const f32x4*)(p.bias + cbase + cl);
+                f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[i][j][4 * g + e] + bv[e];
-                    if (p.act) v[e] = silu<F32>(v[e]);
+                    float t = acc[i][j][4 * g + e] + bv[e];
+                    if (p.act) t = silu<F32>(t);
+                    v[e] = t;
                 }
-                if (F32) {
-                    if (rrow) {
-                        const f32x4 rv = *(const f32x4*)(rrow + c0 * 4);
+                *(f32x4*)(stg + l31 * ROWF + cl * 4) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int pbase = n0 + wn * (BN / WN) + j * 32;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+        for (int it = 0; it < (ITEMS + 63) / 64; ++it) {
+            const int item = it * 64 + lane;
+            const int pix = item / NCH, ch = item - pix * NCH;
+            const int P = pbase + pix, c0 = cbase + ch * 8;
+            if (item < ITEMS && P < p.npix && c0 < p.cout) {
+                const f32x4 lo = *(const f32x4*)(stg + pix * ROWF + ch * 32);
+                const f32x4 hi = *(const f32x4*)(stg + pix * ROWF + ch * 32 + 16);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                char* orow = p.out + (long long)P * p.out_ld_b;
+                if (F32) {
+                    if (p.res) {
+                        const char* rrow = p.res + (long long)P * p.res_ld_b + c0 * 4;
+                        const f32x4 r0 = *(const f32x4*)rrow, r1 = *(const f32x4*)(rrow + 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
                     }
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(orow + c0 * 4) = o;
+                    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                    *(f32x4*)(orow + c0 * 4) = o0;
+                    *(f32x4*)(orow + c0 * 4 + 16) = o1;
                 } else {
-                    if (rrow) {
-                        const uint2 rv = *(const uint2*)(rrow + c0 * 2);
-                        v[0] += aq_bf2f((bf16_t)(rv.x & 0xffff));
-                        v[1] += aq_bf2f((bf16_t)(rv.x >> 16));
-                        v[2] += aq_bf2f((bf16_t)(rv.y & 0xffff));
-                        v[3] += aq_bf2f((bf16_t)(rv.y >> 16));
+                    if (p.res) {
+                        const uint4 rv = *(const uint4*)(p.res + (long long)P * p.res_ld_b + c0 * 2);
+                        const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] += aq_bf2f((bf16_t)(rw[e] & 0xffff));
+                            v[2 * e + 1] += aq_bf2f((bf16_t)(rw[e] >> 16));
+                        }
                     }
                     if (OUT_F32) {
-                        f32x4 o = {v[0], v[1], v[2], v[3]};
-                        *(f32x4*)(orow + c0 * 4) = o;
+                        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                        *(f32x4*)(orow + c0 * 4) = o0;
+                        *(f32x4*)(orow + c0 * 4 + 16) = o1;
                     } else {
-                        uint2 o;
+                        uint4 o;
                         o.x = (uint32_t)aq_f2bf(v[0]) | ((uint32_t)aq_f2bf(v[1]) << 16);
                         o.y = (uint32_t)aq_f2bf(v[2]) | ((uint32_t)aq_f2bf(v[3]) << 16);
-                        *(uint2*)(orow + c0 * 2) = o;
+                        o.z = (uint32_t)aq_f2bf(v[4]) | ((uint32_t)aq_f2bf(v[5]) << 16);
+                        o.w = (uint32_t)aq_f2bf(v[6]) | ((uint32_t)aq_f2bf(v[7]) << 16);
+                        *(uint4*)(orow + c0 * 2) = o;
                     }
                 }
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
 struct ConvConfig {
-    int bm, bn, threads;
+    int bm, bn, threads, tm;
     void (*bf16)(const ConvParams);
     void (*bf16_f32out)(const ConvParams);
     void (*f32)(const ConvParams);
 };
 
 #define CFG(BM, BN, WM, WN)                                                                    \
-    { BM, BN, WM * WN * 64, conv_igemm_kernel<false, BM, BN, WM, WN, false>,                   \
+    { BM, BN, WM * WN * 64, BM / WM / 32, conv_igemm_kernel<false, BM, BN, WM, WN, false>,                   \
       conv_igemm_kernel<false, BM, BN, WM, WN, true>, conv_igemm_kernel<true, BM, BN, WM, WN, true> }
 
 const ConvConfig kConfigs[] = {
@@ -252,6 +282,13 @@ const ConvConfig kConfigs[] = {
     CFG(64, 128, 1, 4),    // 10: per-wave 64x32, 4 waves
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
+
+// dynamic LDS: two K-chunk buffers, or the per-wave epilogue staging (32 pixel rows of fp32, padded) if larger
+size_t conv_lds_bytes(const ConvConfig& k) {
+    const size_t main_loop = (size_t)2 * (k.bm + k.bn) * 128;
+    const size_t staging = (size_t)(k.threads / 64) * 32 * (k.tm * 32 * 4 + 16);
+    return main_loop > staging ? main_loop : staging;
+}
 bool g_attr_set[kNumConfigs][3];
 
 }  // namespace
@@ -274,7 +311,7 @@ int aq_conv_pick_config(int cout, int npix, int precision) {
         const ConvConfig& k = kConfigs[c];
         const int tm = (cout + k.bm - 1) / k.bm, tn = (npix + k.bn - 1) / k.bn;
         const double waste = (double)(tm * k.bm) / cout;              // padded MFMA rows
-        const int lds = 2 * (k.bm + k.bn) * 128;
+        const int lds = (int)conv_lds_bytes(k);
         const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
         const double slots = 256.0 * wg_per_cu;
         const double tiles = (double)tm * tn;
@@ -296,7 +333,7 @@ int aq_launch_conv(const ConvParams& p_in, int precision, int out_f32, int cfg, 
     p.n_tiles_n = (p.npix + k.bn - 1) / k.bn;
     const int variant = precision == AQ_FP32 ? 2 : (out_f32 ? 1 : 0);
     auto fn = variant == 2 ? k.f32 : (variant == 1 ? k.bf16_f32out : k.bf16);
-    const size_t lds = (size_t)2 * (k.bm + k.bn) * 128;
+    const size_t lds = conv_lds_bytes(k);
     if (!g_attr_set[cfg][variant]) {
         AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         g_attr_set[cfg][variant] = true;

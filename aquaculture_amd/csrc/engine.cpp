@@ -70,6 +70,8 @@ struct aq_engine {
     std::vector<aq_op_desc> ops;
     std::vector<PackedW> packed;        // per op (conv ops only)
     std::vector<int> conv_cfg;          // per op override, -1 = heuristic
+    std::vector<int> tuned_cfg;         // per op result of aq_engine_autotune for (tuned_B, tuned_H, tuned_W)
+    int tuned_B = 0, tuned_H = 0, tuned_W = 0;
     void* zero_page = nullptr;
     // workspace layout of the last sizing / call
     int lay_B = 0, lay_H = 0, lay_W = 0;
@@ -124,7 +126,7 @@ inline char* tptr(aq_engine* e, void* ws, const uint8_t* tiles, int t) {
     return (char*)ws + e->place[t].offset;
 }
 
-int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStream_t stream) {
+int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStream_t stream, int force_cfg = -1) {
     const aq_op_desc& op = e->ops[oi];
     const PackedW& pw = e->packed[oi];
     const int prec = e->desc.precision;
@@ -148,7 +150,8 @@ int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStr
     p.G = pw.G; p.kgroups = pw.kgroups; p.kgroups_pad = pw.kgroups_pad; p.nchunks = pw.kgroups_pad / 8;
     p.npix = B * pd.h * pd.w;
     p.act = op.act;
-    int cfg = e->conv_cfg[oi];
+    int cfg = force_cfg >= 0 ? force_cfg : e->conv_cfg[oi];
+    if (cfg < 0 && e->tuned_B == B && e->tuned_H == e->lay_H && e->tuned_W == e->lay_W) cfg = e->tuned_cfg[oi];
     if (cfg < 0) cfg = aq_conv_pick_config(p.cout, p.npix, prec);
     return aq_launch_conv(p, prec, out_f32, cfg, stream);
 }
@@ -253,7 +256,8 @@ extern "C" int aq_conv2d(const void* in_dev, int in_ld, int in_choff, int cin, v
     const int oeb = (precision == AQ_FP32 || out_f32) ? 4 : 2;
     AQ_REQUIRE((cin * eb) % 16 == 0 && (in_ld * eb) % 16 == 0 && (in_choff * eb) % 16 == 0,
                "conv2d: input channels must be whole 16-byte groups (cin=%d ld=%d off=%d)", cin, in_ld, in_choff);
-    AQ_REQUIRE(cout % 4 == 0 && out_choff % 4 == 0 && out_ld % 4 == 0, "conv2d: cout/out_choff/out_ld must be multiples of 4");
+    AQ_REQUIRE(cout % 8 == 0 && out_choff % 8 == 0 && out_ld % 8 == 0, "conv2d: cout/out_choff/out_ld must be multiples of 8");
+    AQ_REQUIRE(!res_dev || (res_choff % 8 == 0 && res_ld % 8 == 0), "conv2d: residual slice must be 8-channel aligned");
     AQ_REQUIRE(k >= 1 && k * k <= 25 && stride >= 1 && pad >= 0, "conv2d: unsupported k=%d stride=%d pad=%d", k, stride, pad);
     AQ_REQUIRE(precision == AQ_BF16 || precision == AQ_FP32, "conv2d: bad precision %d", precision);
     ConvParams p{};
@@ -288,6 +292,7 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
     e->desc.ops = e->ops.data();
     e->packed.resize(e->ops.size());
     e->conv_cfg.assign(e->ops.size(), -1);
+    e->tuned_cfg.assign(e->ops.size(), -1);
     const int eb = aq_elem_bytes(d->precision);
     auto fail = [&](int rc) { aq_engine_destroy(e); return rc; };
     if (hipMalloc(&e->zero_page, 4096) != hipSuccess || hipMemset(e->zero_page, 0, 4096) != hipSuccess) {
@@ -305,7 +310,7 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
             }
         }
         if (op.kind != AQ_OP_CONV) continue;
-        if (!op.weight || !op.bias || (op.src.channels * eb) % 16 != 0 || op.dst.channels % 4 != 0 || op.k * op.k > 25) {
+        if (!op.weight || !op.bias || (op.src.channels * eb) % 16 != 0 || op.dst.channels % 8 != 0 || op.dst.ch_off % 8 != 0 || op.k * op.k > 25) {
             aq_set_error("engine_create: conv op %zu unsupported (cin=%d cout=%d k=%d)", oi, op.src.channels, op.dst.channels, op.k);
             return fail(AQ_ERR_INVALID);
         }
@@ -380,6 +385,57 @@ extern "C" int aq_engine_set_conv_config(aq_engine* e, int op, int cfg) {
     AQ_REQUIRE(cfg >= -1 && cfg < aq_conv_num_configs(), "set_conv_config: bad config %d", cfg);
     e->conv_cfg[op] = cfg;
     return AQ_OK;
+}
+
+// Times every tile configuration of every conv op on the caller's buffers (after one real forward pass so
+// the activations are real data) and keeps the fastest per op for this (B, H, W).  Not a launch-path call:
+// it synchronises the stream.
+extern "C" int aq_engine_autotune(aq_engine* e, const uint8_t* tiles_dev, int B, int H, int W, void* ws, size_t ws_bytes,
+                                  int reps, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ_REQUIRE(e && tiles_dev && ws && reps > 0, "autotune: bad argument");
+    const size_t npred = 0;
+    (void)npred;
+    int rc = layout(e, B, H, W);
+    if (rc) return rc;
+    if (ws_bytes < e->total_bytes) { aq_set_error("autotune: workspace too small"); return AQ_ERR_WORKSPACE; }
+    std::vector<int> saved = e->tuned_cfg;
+    e->tuned_B = 0;
+    rc = run_plan(e, tiles_dev, B, H, W, ws, ws_bytes, (float*)((char*)ws + e->off_pred), nullptr, nullptr, 0.f, 0.f, 1, stream);
+    if (rc) return rc;
+    hipEvent_t ev0, ev1;
+    AQ_CHECK_HIP(hipEventCreate(&ev0));
+    AQ_CHECK_HIP(hipEventCreate(&ev1));
+    const int ncfg = aq_conv_num_configs();
+    for (size_t oi = 0; oi < e->ops.size() && rc == AQ_OK; ++oi) {
+        if (e->ops[oi].kind != AQ_OP_CONV) continue;
+        float best = 1e30f;
+        int best_cfg = -1;
+        for (int c = 0; c < ncfg && rc == AQ_OK; ++c) {
+            rc = run_conv(e, (int)oi, ws, tiles_dev, B, stream, c);   // warm-up (also sets the LDS attribute)
+            if (rc) break;
+            (void)hipEventRecord(ev0, stream);
+            for (int r = 0; r < reps && rc == AQ_OK; ++r) rc = run_conv(e, (int)oi, ws, tiles_dev, B, stream, c);
+            (void)hipEventRecord(ev1, stream);
+            if (hipEventSynchronize(ev1) != hipSuccess) { aq_set_error("autotune: sync failed"); rc = AQ_ERR_HIP; break; }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev0, ev1);
+            if (ms < best) { best = ms; best_cfg = c; }
+        }
+        saved[oi] = best_cfg;
+    }
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    if (rc) return rc;
+    e->tuned_cfg = saved;
+    e->tuned_B = B; e->tuned_H = H; e->tuned_W = W;
+    return AQ_OK;
+}
+
+extern "C" int aq_engine_get_conv_config(aq_engine* e, int op) {
+    if (!e || op < 0 || op >= (int)e->ops.size()) return -1;
+    if (e->conv_cfg[op] >= 0) return e->conv_cfg[op];
+    return e->tuned_B ? e->tuned_cfg[op] : -1;
 }
 
 extern "C" int aq_engine_profile(aq_engine* e, int enable, int ring) {

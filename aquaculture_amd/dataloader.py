@@ -1,0 +1,153 @@
+"""Image directory -> letterboxed uint8 RGB tiles.
+
+Restates [UPSTREAM utils/dataloaders.py LoadImages, utils/augmentations.py letterbox] as invoked by
+``yolov5/detect.py --source DIR`` (reference README.md:77).  The directory is what the reference's tiler
+writes: ``*.jpeg``, 8-bit, 3-band (reference src/load_data/tile_tifs.py:66-74).
+
+Differences that are deliberate and documented in DESIGN.md:
+  * decode is PIL/libjpeg-turbo (cv2 is not installed here); upstream reads BGR and flips to RGB, we read RGB;
+  * the INTER_LINEAR resize (only taken when the tile is not already 640-fitting) is a numpy restatement of
+    OpenCV's 8-bit fixed-point bilinear kernel -- UNPINNED until a cv2 is available to check it against.
+"""
+from __future__ import annotations
+
+import glob
+import math
+import os
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+from typing import Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+IMG_FORMATS = ("bmp", "dng", "jpeg", "jpg", "mpo", "png", "tif", "tiff", "webp", "pfm")  # [UPSTREAM dataloaders.IMG_FORMATS]
+PAD_VALUE = 114
+_COEF_BITS = 11
+_COEF_SCALE = 1 << _COEF_BITS
+
+
+def list_images(source: str) -> List[str]:
+    """[UPSTREAM LoadImages.__init__]: sorted(glob(dir/*.*)) filtered by extension (a file or glob also works)."""
+    p = str(Path(source).resolve())
+    if "*" in p:
+        files = sorted(glob.glob(p, recursive=True))
+    elif os.path.isdir(p):
+        files = sorted(glob.glob(os.path.join(p, "*.*")))
+    elif os.path.isfile(p):
+        files = [p]
+    else:
+        raise FileNotFoundError(f"{p} does not exist")
+    images = [x for x in files if x.split(".")[-1].lower() in IMG_FORMATS]
+    if not images:
+        raise FileNotFoundError(f"No images found in {p}. Supported formats are: {IMG_FORMATS}")
+    return images
+
+
+def _axis_coeffs(src: int, dst: int):
+    """OpenCV resize INTER_LINEAR 8u coefficient table for one axis: index, (w0, w1) as int16 in 2^11 units."""
+    scale = src / dst
+    d = np.arange(dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = f - s.astype(np.float32)
+    lo = s < 0
+    f[lo], s[lo] = 0.0, 0
+    hi = s >= src - 1
+    f[hi], s[hi] = 0.0, src - 1
+    w1 = np.rint(f * np.float32(_COEF_SCALE)).astype(np.int32)            # saturate_cast<short>(cvRound)
+    w0 = np.rint((np.float32(1.0) - f) * np.float32(_COEF_SCALE)).astype(np.int32)
+    s1 = np.minimum(s + 1, src - 1)
+    return s, s1, w0, w1
+
+
+def resize_linear_u8(img: np.ndarray, new_w: int, new_h: int) -> np.ndarray:
+    """cv2.resize(img, (new_w, new_h), interpolation=cv2.INTER_LINEAR) for uint8 HxWxC (restated, unpinned)."""
+    h, w = img.shape[:2]
+    x0, x1, a0, a1 = _axis_coeffs(w, new_w)
+    y0, y1, b0, b1 = _axis_coeffs(h, new_h)
+    src = img.astype(np.int32)
+    rows = src[:, x0] * a0[None, :, None] + src[:, x1] * a1[None, :, None]        # HResize, scale 2^11
+    r0, r1 = rows[y0], rows[y1]
+    out = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def letterbox_geometry(shape: Tuple[int, int], new_shape=(640, 640), auto=True, scaleup=True, stride=32):
+    """Returns (new_unpad (w, h), (top, bottom, left, right)) exactly as upstream letterbox computes them."""
+    r = min(new_shape[0] / shape[0], new_shape[1] / shape[1])
+    if not scaleup:
+        r = min(r, 1.0)
+    new_unpad = int(round(shape[1] * r)), int(round(shape[0] * r))
+    dw, dh = new_shape[1] - new_unpad[0], new_shape[0] - new_unpad[1]
+    if auto:
+        dw, dh = dw % stride, dh % stride
+    dw /= 2
+    dh /= 2
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    return new_unpad, (top, bottom, left, right)
+
+
+def letterbox(im: np.ndarray, new_shape=(640, 640), auto=True, scaleup=True, stride=32) -> np.ndarray:
+    """Resize + pad to a stride multiple with 114 [UPSTREAM letterbox].  640^2 and 1024^2 tiles need no padding."""
+    shape = im.shape[:2]
+    new_unpad, (top, bottom, left, right) = letterbox_geometry(shape, new_shape, auto, scaleup, stride)
+    if shape[::-1] != new_unpad:
+        im = resize_linear_u8(im, new_unpad[0], new_unpad[1])
+    if top or bottom or left or right:
+        im = np.pad(im, ((top, bottom), (left, right), (0, 0)), mode="constant", constant_values=PAD_VALUE)
+    return np.ascontiguousarray(im)
+
+
+def check_img_size(imgsz, s=32):
+    """[UPSTREAM utils/general.py check_img_size]: round each side up to a multiple of the max stride."""
+    if isinstance(imgsz, int):
+        return max(math.ceil(imgsz / s) * s, 0)
+    return [max(math.ceil(x / s) * s, 0) for x in imgsz]
+
+
+def read_rgb(path: str) -> np.ndarray:
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"))
+
+
+class LoadImages:
+    """Iterates (path, letterboxed uint8 HWC RGB, original (h, w)) in sorted order; ``shard`` = (rank, world)
+    keeps images ``i % world == rank`` (strided tile shard, one process per GPU)."""
+
+    def __init__(self, source: str, img_size=640, stride=32, auto=True, shard: Tuple[int, int] = (0, 1), workers: int = 8):
+        files = list_images(source)
+        self.total = len(files)
+        rank, world = shard
+        self.indices = list(range(rank, len(files), world))
+        self.files = [files[i] for i in self.indices]
+        self.img_size = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
+        self.stride, self.auto = stride, auto
+        self.workers = max(1, workers)
+
+    def __len__(self):
+        return len(self.files)
+
+    def load(self, path: str):
+        im0 = read_rgb(path)
+        return path, letterbox(im0, self.img_size, self.auto, True, self.stride), im0.shape[:2]
+
+    def __iter__(self) -> Iterator[Tuple[str, np.ndarray, Tuple[int, int]]]:
+        if self.workers == 1:
+            for p in self.files:
+                yield self.load(p)
+            return
+        with ThreadPoolExecutor(self.workers) as ex:   # PIL releases the GIL while decoding
+            yield from ex.map(self.load, self.files)
+
+    def batches(self, batch_size: int):
+        """Groups consecutive images of equal letterboxed shape: yields (paths, uint8 [b,H,W,3], [orig shapes])."""
+        paths, ims, shapes = [], [], []
+        for p, im, s0 in self:
+            if ims and (im.shape != ims[0].shape or len(ims) == batch_size):
+                yield paths, np.stack(ims, 0), shapes
+                paths, ims, shapes = [], [], []
+            paths.append(p); ims.append(im); shapes.append(s0)
+        if ims:
+            yield paths, np.stack(ims, 0), shapes

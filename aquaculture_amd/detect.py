@@ -1,0 +1,187 @@
+"""``yolov5/detect.py`` re-implemented on the HIP engine: same flags, same output files.
+
+Reference call (reference README.md:77):
+
+    python3 yolov5/detect.py --weights output/model_weights/multilabel_farms_exp2.pt \\
+        --source data/jpegs --nosave --save-txt --save-conf
+
+Output contract: ``<project>/<name>[N]/labels/<image stem>.txt``, one line per detection
+``cls xc yc w h conf`` (``%g`` each, normalised by the original image size, ascending confidence), no file
+for an image without detections -- consumed unchanged by reference src/process_yolo/geocode_results.py:123-172.
+
+What differs from upstream's loop ([UPSTREAM detect.py run()]): images are decoded by a thread pool and run
+through the engine in batches (``--batch-size``); with ``WORLD_SIZE > 1`` (torchrun) every rank takes the tiles
+``i % world == rank`` and writes its own label files; detections are gathered over RCCL once at the end.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+from pathlib import Path
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import dist as aqdist
+from . import postprocess
+from .checkpoint import load_checkpoint
+from .dataloader import LoadImages, check_img_size
+
+UNSUPPORTED = ("view_img", "save_crop", "augment", "visualize", "update", "dnn")
+
+
+def increment_path(path, exist_ok=False, sep="", mkdir=False) -> Path:
+    """[UPSTREAM utils/general.py increment_path]: runs/detect/exp -> exp2, exp3, ..."""
+    path = Path(path)
+    if path.exists() and not exist_ok:
+        for n in range(2, 9999):
+            p = f"{path}{sep}{n}"
+            if not os.path.exists(p):
+                break
+        path = Path(p)
+    if mkdir:
+        path.mkdir(parents=True, exist_ok=True)
+    return path
+
+
+def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
+    """Upstream's flag set plus --batch-size / --precision / --workers."""
+    root = Path.cwd()
+    p = argparse.ArgumentParser()
+    p.add_argument("--weights", nargs="+", type=str, default="yolov5s.pt", help="model path")
+    p.add_argument("--source", type=str, default="data/images", help="file/dir/glob")
+    p.add_argument("--data", type=str, default="data/coco128.yaml", help="(unused: class names come from the checkpoint)")
+    p.add_argument("--imgsz", "--img", "--img-size", nargs="+", type=int, default=[640], help="inference size h,w")
+    p.add_argument("--conf-thres", type=float, default=0.25, help="confidence threshold")
+    p.add_argument("--iou-thres", type=float, default=0.45, help="NMS IoU threshold")
+    p.add_argument("--max-det", type=int, default=1000, help="maximum detections per image")
+    p.add_argument("--device", default="", help="GPU ordinal (default: LOCAL_RANK or 0)")
+    p.add_argument("--view-img", action="store_true")
+    p.add_argument("--save-txt", action="store_true", help="save results to *.txt")
+    p.add_argument("--save-conf", action="store_true", help="save confidences in --save-txt labels")
+    p.add_argument("--save-crop", action="store_true")
+    p.add_argument("--nosave", action="store_true", help="do not save images/videos")
+    p.add_argument("--classes", nargs="+", type=int, help="filter by class: --classes 0, or --classes 0 2 3")
+    p.add_argument("--agnostic-nms", action="store_true")
+    p.add_argument("--augment", action="store_true")
+    p.add_argument("--visualize", action="store_true")
+    p.add_argument("--update", action="store_true")
+    p.add_argument("--project", default=str(root / "runs/detect"), help="save results to project/name")
+    p.add_argument("--name", default="exp", help="save results to project/name")
+    p.add_argument("--exist-ok", action="store_true", help="existing project/name ok, do not increment")
+    p.add_argument("--line-thickness", default=3, type=int)
+    p.add_argument("--hide-labels", default=False, action="store_true")
+    p.add_argument("--hide-conf", default=False, action="store_true")
+    p.add_argument("--half", action="store_true", help="reduced precision (bf16 on MI355X; upstream: fp16)")
+    p.add_argument("--dnn", action="store_true")
+    p.add_argument("--vid-stride", type=int, default=1)
+    p.add_argument("--batch-size", type=int, default=64, help="tiles per engine call")
+    p.add_argument("--precision", choices=("fp32", "bf16"), default=None, help="default fp32 (detect.py without --half)")
+    p.add_argument("--workers", type=int, default=8, help="jpeg decode threads")
+    opt = p.parse_args(argv)
+    opt.imgsz *= 2 if len(opt.imgsz) == 1 else 1
+    return opt
+
+
+def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_det=1000, device="",
+        save_txt=False, save_conf=False, nosave=False, classes=None, agnostic_nms=False,
+        project="runs/detect", name="exp", exist_ok=False, half=False, batch_size=64, precision=None,
+        workers=8, log=print, **unsupported):
+    from .engine import Engine   # raises if the HIP library or the GPU is missing: there is no fallback
+
+    for k in UNSUPPORTED:
+        if unsupported.get(k):
+            raise NotImplementedError(f"--{k.replace('_', '-')} is not part of the tile-sweep path (reference README.md:77)")
+    if classes is not None or agnostic_nms:
+        raise NotImplementedError("--classes / --agnostic-nms are not used by the reference invocation and not implemented")
+    if not nosave:
+        log("note: annotated images are never written (the reference runs with --nosave)")
+    weights = weights[0] if isinstance(weights, (list, tuple)) else weights
+    precision = precision or ("bf16" if half else "fp32")
+
+    rank, world, local = aqdist.init()
+    dev = int(device) if str(device).strip().isdigit() else local
+    torch.cuda.set_device(dev)
+
+    # directories: rank 0 picks the run directory, everyone uses it
+    if rank == 0:
+        save_dir = increment_path(Path(project) / name, exist_ok=exist_ok)
+        (save_dir / "labels" if save_txt else save_dir).mkdir(parents=True, exist_ok=True)
+    if world > 1:
+        box = [str(save_dir) if rank == 0 else None]
+        torch.distributed.broadcast_object_list(box, src=0)
+        save_dir = Path(box[0])
+    labels_dir = str(save_dir / "labels")
+
+    ck = load_checkpoint(weights)
+    eng = Engine(ck, precision, dev)
+    imgsz = check_img_size(list(imgsz), s=int(max(ck.stride)))
+    dataset = LoadImages(source, img_size=imgsz, stride=int(max(ck.stride)), auto=True, shard=(rank, world), workers=workers)
+
+    copy_stream = torch.cuda.Stream()
+    seen, n_labels, n_dets = 0, 0, 0
+    t_pre = t_inf = t_post = 0.0
+    gathered: List[torch.Tensor] = []
+    t_start = time.perf_counter()
+    shape_str = ""
+    for paths, batch, shapes0 in dataset.batches(batch_size):
+        t0 = time.perf_counter()
+        host = torch.from_numpy(batch).pin_memory()
+        with torch.cuda.stream(copy_stream):
+            tiles = host.to(dev, non_blocking=True)
+        torch.cuda.current_stream().wait_stream(copy_stream)
+        t1 = time.perf_counter()
+        dets, counts = eng.infer(tiles, conf_thres, iou_thres, max_det)
+        counts_h = counts.cpu().numpy()
+        dets_h = dets[:, : int(counts_h.max(initial=0))].cpu().numpy() if counts_h.size else dets.cpu().numpy()
+        t2 = time.perf_counter()
+        H, W = batch.shape[1:3]
+        shape_str = f"(1, 3, {H}, {W})"
+        for b, p in enumerate(paths):
+            seen += 1
+            det = dets_h[b, : counts_h[b]]
+            n_dets += det.shape[0]
+            rows = postprocess.detections_to_rows(det, (H, W), shapes0[b])
+            if save_txt and postprocess.write_label_file(labels_dir, Path(p).stem, rows, save_conf):
+                n_labels += 1
+            s = f"image {dataset.indices[seen - 1] + 1}/{dataset.total} {p}: {H}x{W} "
+            s += postprocess.class_summary(det[:, 5], ck.names) if det.shape[0] else "(no detections), "
+            log(f"{s}{(t2 - t1) * 1e3 / len(paths):.1f}ms")
+            if world > 1 and det.shape[0]:
+                idx = torch.full((det.shape[0],), dataset.indices[seen - 1], dtype=torch.float32)
+                gathered.append(aqdist.pack_rows(idx, torch.from_numpy(det)))
+        t3 = time.perf_counter()
+        t_pre += t1 - t0
+        t_inf += t2 - t1
+        t_post += t3 - t2
+    elapsed = time.perf_counter() - t_start
+
+    if world > 1:   # the one collective of the path: final detection gather over RCCL/xGMI
+        rows = torch.cat(gathered, 0) if gathered else torch.zeros((0, aqdist.ROW))
+        rows = aqdist.gather_rows(rows.to(dev))
+        seen_all, labels_all, dets_all, elapsed = aqdist.reduce_counters(seen, n_labels, n_dets, elapsed, dev)
+        assert rows.shape[0] == dets_all, "gathered detection rows do not add up"
+    else:
+        seen_all, labels_all, dets_all = seen, n_labels, n_dets
+    if rank == 0:
+        per = lambda t: t * 1e3 / max(seen, 1)
+        log(f"Speed: {per(t_pre):.1f}ms pre-process, {per(t_inf):.1f}ms inference+NMS, {per(t_post):.1f}ms post-process "
+            f"per image at shape {shape_str}")
+        log(f"{seen_all} images, {dets_all} detections, {seen_all / max(elapsed, 1e-9):.1f} images/s on {world} GPU(s) [{precision}]")
+        if save_txt:
+            log(f"Results saved to {save_dir}\n{labels_all} labels saved to {save_dir / 'labels'}")
+    eng.close()
+    return save_dir
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    opt = parse_opt(argv)
+    run(**vars(opt))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -71,7 +71,7 @@ def synthetic_tile(i: int, size: int = 640) -> np.ndarray:
                 ring, inside = (np.abs(d - s) <= 1.0), d < s - 1
             img[inside] = img[inside] * 0.8 - 6.0
             img[ring] = (200.0, 205.0, 210.0)
-    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
 
 
 def synthetic_batch(indices: Iterable[int], size: int = 640) -> np.ndarray:

@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 640-px tiles/s (whole node), YOLOv5m bf16, MI355X -- BASELINE.json `metric`.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+One *step* = one pass of the whole hot path (preprocess -> backbone/neck/head convs -> decode -> NMS) over one
+batch of 64 synthetic 640x640 ocean tiles that already reside in HBM (BASELINE.json configs[1]); each rank runs
+its own batches (tile-sharded, weak scaling) and the only collective is the final detection gather.
+Rank 0 prints ONE JSON line with the metric, a `roofline` object for the dominant kernel (the implicit-GEMM conv
+on the 3x3 layers, MFMA-bound, timed live with HIP events on the launch stream) and a `cpu_baseline` object
+(the CPU oracle -- a PyTorch-CPU restatement of detect.py, NOT the reference's own detect.py, which is absent from
+the reference tree -- timed on this host's cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--batch", type=int, default=64)
+    p.add_argument("--size", type=int, default=640)
+    p.add_argument("--variant", default="yolov5m")
+    p.add_argument("--precision", default="bf16", choices=("bf16", "fp32"))
+    p.add_argument("--pool", type=int, default=2, help="distinct synthetic batches kept in HBM and cycled")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle sample budget")
+    p.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristic instead of timing configs")
+    p.add_argument("--no-profile", action="store_true", help="skip per-op HIP events (roofline becomes null)")
+    p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"),
+                   help="optional PMC-derived HBM bytes per launch for the dominant kernel")
+    return p.parse_args()
+
+
+def host_threads() -> int:
+    """CPU threads we may use: the affinity mask, capped at the GPU box's per-GPU share of 16."""
+    if os.environ.get("AQ_CPU_THREADS"):
+        return int(os.environ["AQ_CPU_THREADS"])
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def make_tiles(rank: int, batch: int, pool: int, size: int) -> np.ndarray:
+    from concurrent.futures import ThreadPoolExecutor
+    from aquaculture_amd import tiles
+    idx = [rank * 100003 + i for i in range(batch * pool)]   # disjoint synthetic tile ids per rank
+    with ThreadPoolExecutor(host_threads()) as ex:
+        arr = list(ex.map(lambda i: tiles.synthetic_tile(i, size), idx))
+    return np.stack(arr, 0).reshape(pool, batch, size, size, 3)
+
+
+def cpu_baseline(ck, size: int, budget_s: float) -> dict:
+    """The oracle (kind 'port') on this host's cores: B=1, fp32, all threads, 2 warm-up tiles, then tiles until
+    the time budget is used."""
+    from aquaculture_amd import tiles
+    from oracle import yolov5_oracle as O
+    torch.set_num_threads(host_threads())
+    m = O.model_from_checkpoint(ck)
+    for i in range(2):
+        O.detect_tiles(m, tiles.synthetic_batch([i], size))
+    n, t0, per = 0, time.perf_counter(), []
+    while n < 64 and (time.perf_counter() - t0) < budget_s:
+        x = tiles.synthetic_batch([n], size)
+        t1 = time.perf_counter()
+        O.detect_tiles(m, x)
+        per.append(time.perf_counter() - t1)
+        n += 1
+    return {"value": round(n / sum(per), 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} synthetic {size}x{size} tiles, batch 1, fp32 PyTorch-CPU restatement of detect.py (oracle/), "
+                      f"median {1e3 * float(np.median(per)):.0f} ms/tile, {torch.get_num_threads()} threads of os.cpu_count()={os.cpu_count()}"}
+
+
+def main() -> int:
+    a = parse()
+    from aquaculture_amd import checkpoint, dist as aqdist, spec
+    from aquaculture_amd.engine import Engine
+
+    rank, world, local = aqdist.init("nccl" if int(os.environ.get("WORLD_SIZE", 1)) > 1 else None)
+    if world != a.gpus:
+        print(f"bench: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    ck = checkpoint.synthetic_checkpoint(a.variant, 5)
+    eng = Engine(ck, a.precision, local)
+    B, K, W = a.batch, a.steps, a.warmup
+    tiles_dev = torch.from_numpy(make_tiles(rank, B, a.pool, a.size)).to(dev)
+    max_det = 1000
+    dets = torch.empty((K, B, max_det, 6), dtype=torch.float32, device=dev)
+    counts = torch.zeros((K, B), dtype=torch.int32, device=dev)
+
+    def step(k: int, slot: int):
+        eng.infer(tiles_dev[k % a.pool], 0.25, 0.45, max_det, out=(dets[slot], counts[slot]))
+
+    def gather_all():
+        # final detection gather: the path's one collective (RCCL over xGMI when world > 1)
+        keep = torch.arange(max_det, device=dev).view(1, 1, -1) < counts.view(K, B, 1)
+        rows = dets[keep]                                                   # [n, 6]
+        tile_id = (torch.arange(K * B, device=dev).view(K, B, 1) * world + rank).expand(K, B, max_det)[keep]
+        return aqdist.gather_rows(aqdist.pack_rows(tile_id, rows))
+
+    cfgs = eng.autotune(tiles_dev[0]) if not a.no_autotune else None
+    for k in range(W):
+        step(k, 0)
+    gather_all()          # untimed: loads torch's indexing kernels / opens the RCCL channels once
+    counts.zero_()
+    torch.cuda.synchronize()
+    if not a.no_profile:
+        eng.profile(True, ring=max(K, 1))
+    aqdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        step(k, k)
+    rows = gather_all()
+    torch.cuda.synchronize()
+    aqdist.barrier()
+    elapsed = time.perf_counter() - t0
+    n_dets_total = int(rows.shape[0])
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    if rank != 0:
+        return 0
+
+    tiles_total = world * K * B
+    value = tiles_total / elapsed
+    plan = eng.plan
+    fl = plan.flops(a.size, a.size)
+    roof = None
+    ops_ms = None
+    if not a.no_profile:
+        ms, calls = eng.op_times_ms()
+        ops_ms = ms
+        idx3 = [i for i, o in enumerate(plan.ops) if o.kind == spec.OP_CONV and o.meta.get("class") == "conv3x3"]
+        idxc = [i for i, o in enumerate(plan.ops) if o.kind == spec.OP_CONV]
+        t3 = float(ms[idx3].sum()) * 1e-3       # seconds per step in the 3x3 conv launches
+        tc = float(ms[idxc].sum()) * 1e-3
+        peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+        ach = fl["conv3x3"] * B / t3 / 1e12
+        traffic = None
+        try:
+            with open(a.traffic_json) as f:
+                traffic = json.load(f).get("bytes_per_launch")
+        except (OSError, ValueError):
+            pass
+        roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": traffic,
+                "kernel": "conv_igemm_kernel (implicit-GEMM conv) on the 28 3x3 layers",
+                "launches_per_step": len(idx3), "avg_launch_ms": round(1e3 * t3 / len(idx3), 4),
+                "flops_per_step": fl["conv3x3"] * B, "steps_timed": calls,
+                "all_conv_tflops": round((fl["total"]) * B / tc / 1e12, 1),
+                "step_ms_by_kind": {"conv3x3": round(1e3 * t3, 3), "conv_other": round(1e3 * (tc - t3), 3),
+                                    "rest": round(float(ms.sum()) - 1e3 * tc, 3)}}
+    out = {
+        "metric": "640px tiles/sec (whole node) YOLOv5m bf16" if (a.size == 640 and a.variant == "yolov5m" and a.precision == "bf16")
+                  else f"{a.size}px tiles/sec (whole node) {a.variant} {a.precision}",
+        "value": round(value, 1), "unit": "tiles/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+        "config": {"workload": f"{a.variant} {a.precision}, 1xMI355X per rank, batch={B}, synthetic {a.size}x{a.size} ocean tiles "
+                               f"resident in HBM ({a.pool} distinct batches cycled), seeded random-init weights nc=5 "
+                               f"(BASELINE.json configs[1])",
+                   "batch_per_gpu": B, "tile_px": a.size, "parallelism": f"tile-sharded dp{world}",
+                   "detections_gathered": n_dets_total},
+        "roofline": roof,
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        eng.close()
+        out["cpu_baseline"] = cpu_baseline(ck, a.size, a.cpu_seconds)
+    print(json.dumps(out), flush=True)
+    if ops_ms is not None and os.environ.get("AQ_BENCH_OPS"):
+        for i, o in enumerate(plan.ops):
+            print(f"# op {i:3d} cfg {cfgs[i] if cfgs else -1:2d} {o.name:24s} {ops_ms[i]:8.4f} ms  {o.flops_per_tile * B / max(ops_ms[i], 1e-9) / 1e9:9.1f} TFLOP/s",
+                  file=sys.stderr)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -117,6 +117,11 @@ int aq_engine_op_times(aq_engine* e, float* ms_out, int n_ops, int* calls_record
 int aq_engine_num_ops(aq_engine* e);
 /* Tuning hook: force the tile configuration of one conv op (-1 = built-in heuristic). */
 int aq_engine_set_conv_config(aq_engine* e, int op, int cfg);
+/* Tuning: time every tile configuration of every conv op on real activations of a (B,H,W) batch and keep the
+ * fastest per op for that geometry (cudnn.benchmark-style).  Synchronises the stream; call once before timing. */
+int aq_engine_autotune(aq_engine* e, const uint8_t* tiles_dev, int B, int H, int W,
+                       void* workspace_dev, size_t workspace_bytes, int reps, void* stream);
+int aq_engine_get_conv_config(aq_engine* e, int op);
 int aq_conv_num_configs(void);
 int aq_conv_config_tiles(int cfg, int* bm, int* bn);
 

@@ -1,0 +1,146 @@
+"""End-to-end parity of the HIP engine (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+fp32 engine  vs fp32 oracle           : the parity gate named by BASELINE.json's north_star
+                                        (boxes/confidences within 1e-4, identical post-NMS box counts).
+bf16 engine  vs bf16-emulating oracle : same rounding points (bf16 storage, fp32 accumulate), so only
+                                        summation order differs; tolerance documents what bf16 costs.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiles_small():
+    from aquaculture_amd import tiles
+    return tiles.synthetic_batch([0, 19], 128)
+
+
+@pytest.fixture(scope="module")
+def tiles_640():
+    from aquaculture_amd import tiles
+    return tiles.synthetic_batch([0, 1, 2], 640)
+
+
+def _engine(ck, precision):
+    from aquaculture_amd import engine
+    return engine.Engine(ck, precision)
+
+
+def test_intermediate_tensors_fp32(lib, synth_ck, tiles_small):
+    """Per-module outputs at 128x128 (backbone, neck, raw heads) against the oracle's taps."""
+    from oracle import yolov5_oracle as O
+    eng = _engine(synth_ck, "fp32")
+    m = O.model_from_checkpoint(synth_ck)
+    m.taps = {}
+    pred_ref = m.forward(O.preprocess(tiles_small))
+    B = tiles_small.shape[0]
+    pred = eng.forward_raw(torch.from_numpy(tiles_small).cuda())
+    torch.cuda.synchronize()
+    names = {"out0": "model.0", "out1": "model.1", "out2": "model.2", "out3": "model.3", "out5": "model.5",
+             "out7": "model.7", "out8": "model.8", "out9": "model.9", "out13": "model.13", "out17": "model.17",
+             "out20": "model.20", "out23": "model.23"}
+    for tname, key in names.items():
+        got = eng.tensor_by_name(tname, B).float().cpu().permute(0, 3, 1, 2)
+        ref = m.taps[key]
+        scale = ref.abs().max().item()
+        err = (got - ref).abs().max().item()
+        assert err <= 2e-5 * max(scale, 1.0), f"{key}: max err {err} (scale {scale})"
+    for lvl in range(3):
+        got = eng.tensor_by_name(f"head{lvl}", B).float().cpu()[..., :3 * (synth_ck.nc + 5)].permute(0, 3, 1, 2)
+        ref = m.taps[f"model.24.m.{lvl}"]
+        assert (got - ref).abs().max().item() <= 1e-3, f"head {lvl}"
+    torch.testing.assert_close(pred.cpu(), pred_ref, rtol=1e-4, atol=1e-3)
+
+
+def test_forward_raw_fp32_640(lib, synth_ck, tiles_640):
+    from oracle import yolov5_oracle as O
+    eng = _engine(synth_ck, "fp32")
+    m = O.model_from_checkpoint(synth_ck)
+    ref = m.forward(O.preprocess(tiles_640))
+    pred = eng.forward_raw(torch.from_numpy(tiles_640).cuda()).cpu()
+    assert pred.shape == ref.shape == (3, 25200, 10)
+    # confidences (sigmoid outputs) within 1e-4 absolute; boxes within 1e-4 of the image size (0.064 px)
+    assert (pred[..., 4:] - ref[..., 4:]).abs().max().item() <= 1e-4
+    assert (pred[..., :4] - ref[..., :4]).abs().max().item() <= 640 * 1e-4
+
+
+def _match(dets, counts, ref_list, box_tol, conf_tol):
+    """Same number of boxes per tile, and a one-to-one pairing (same class) within tolerance.  Rows are compared
+    as a set, not by position: two confidences that differ by 1e-7 may legitimately sort in either order."""
+    for b, ref in enumerate(ref_list):
+        n = int(counts[b])
+        assert n == ref.shape[0], f"tile {b}: {n} boxes vs oracle {ref.shape[0]}"
+        got = dets[b, :n]
+        assert np.all(np.diff(got[:, 4]) <= 0), f"tile {b}: confidences not descending"
+        used = np.zeros(n, bool)
+        for r in ref:
+            d = np.abs(got[:, :4] - r[:4]).max(1) / box_tol + np.abs(got[:, 4] - r[4]) / conf_tol
+            d[used | (got[:, 5] != r[5])] = np.inf
+            j = int(np.argmin(d))
+            assert np.abs(got[j, :4] - r[:4]).max() <= box_tol and abs(got[j, 4] - r[4]) <= conf_tol, \
+                f"tile {b}: oracle box {r} has no engine match (closest {got[j]})"
+            used[j] = True
+
+
+def test_infer_fp32_matches_oracle_detections(lib, synth_ck, tiles_640):
+    """The north-star gate: identical post-NMS box counts, boxes/conf within 1e-4 (boxes normalised by 640)."""
+    from oracle import yolov5_oracle as O
+    eng = _engine(synth_ck, "fp32")
+    m = O.model_from_checkpoint(synth_ck)
+    ref = O.detect_tiles(m, tiles_640)
+    dets, counts = eng.infer(torch.from_numpy(tiles_640).cuda())
+    _match(dets.cpu().numpy(), counts.cpu().numpy(), ref, box_tol=640 * 1e-4, conf_tol=1e-4)
+    assert sum(r.shape[0] for r in ref) > 100   # the case actually exercises NMS
+
+
+def test_nms_kernel_bitexact_on_oracle_pred(lib, synth_ck, tiles_640):
+    """S2 alone: feed the ORACLE's pred to the HIP NMS; output must equal the oracle's NMS bit for bit."""
+    from aquaculture_amd import engine
+    from oracle import yolov5_oracle as O
+    m = O.model_from_checkpoint(synth_ck)
+    pred = m.forward(O.preprocess(tiles_640))
+    ref = O.non_max_suppression(pred.numpy())
+    dets, counts = engine.nms(pred.cuda().contiguous(), synth_ck.nc)
+    dets, counts = dets.cpu().numpy(), counts.cpu().numpy()
+    for b, r in enumerate(ref):
+        assert counts[b] == r.shape[0]
+        assert np.array_equal(dets[b, :counts[b]], r)
+
+
+def test_infer_bf16_close_to_emulated_oracle(lib, synth_ck, tiles_640):
+    """bf16 engine vs an oracle that rounds weights/activations to bf16 at the same points.
+
+    Measured on MI355X (round 1): |d conf| mean 6.8e-3, p99.9 4.9e-2, max 8.8e-2; |d box| mean 0.68 px;
+    post-NMS counts 312/363/348 vs 313/357/346.  The seeded synthetic checkpoint amplifies tiny spatial
+    feature variations ~60x in its calibrated head, so single-ulp bf16 rounding flips (summation order)
+    show up at this level; the fp32 mode is the 1e-4 parity gate, this test bounds what bf16 costs."""
+    from oracle import yolov5_oracle as O
+    eng = _engine(synth_ck, "bf16")
+    m = O.model_from_checkpoint(synth_ck, O.q_bf16)
+    ref = m.forward(O.preprocess(tiles_640))
+    t = torch.from_numpy(tiles_640).cuda()
+    pred = eng.forward_raw(t).cpu()
+    d_conf = (pred[..., 4:] - ref[..., 4:]).abs().flatten()
+    assert d_conf.mean().item() <= 2e-2
+    assert d_conf.kthvalue(int(0.999 * d_conf.numel()))[0].item() <= 0.15
+    assert (pred[..., :4] - ref[..., :4]).abs().mean().item() <= 2.0
+    ref_counts = [r.shape[0] for r in O.non_max_suppression(ref.numpy())]
+    _, counts = eng.infer(t)
+    for got, want in zip(counts.cpu().tolist(), ref_counts):
+        assert abs(got - want) <= max(3, 0.05 * want)
+
+
+def test_infer_deterministic(lib, synth_ck, tiles_640):
+    """Atomics are used for candidate compaction; results must not depend on their order."""
+    eng = _engine(synth_ck, "bf16")
+    t = torch.from_numpy(tiles_640).cuda()
+    d0, c0 = eng.infer(t)
+    d0, c0 = d0.clone(), c0.clone()
+    for _ in range(3):
+        d1, c1 = eng.infer(t)
+        assert torch.equal(c0, c1)
+        for b in range(t.shape[0]):
+            assert torch.equal(d0[b, :c0[b]], d1[b, :c1[b]])
