@@ -58,6 +58,8 @@ struct ConvParams {
     int npix;            // B * Ho * Wo
     int act;
     int n_tiles_m, n_tiles_n;
+    float inv_hw, inv_wo;        // reciprocals for division-free pixel decode (filled by aq_launch_conv)
+    unsigned magic_G, magic_k, magic_ntm;   // floor(2^32 / d) + 1
 };
 
 int aq_launch_conv(const ConvParams& p, int precision, int out_f32, int cfg, hipStream_t stream);

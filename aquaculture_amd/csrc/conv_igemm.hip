@@ -31,12 +31,40 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
 template <bool F32>
 __device__ __forceinline__ float silu(float v) {
     // [UPSTREAM nn.SiLU]: v * sigmoid(v) = v / (1 + exp(-v))
-    if (F32) return v / (1.0f + expf(-v));
-    return v / (1.0f + __expf(-v));
+    if (F32) return v / (1.0f + expf(-v));                       // parity mode: IEEE divide, accurate exp
+    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));         // bf16 mode: v_exp + v_rcp (error << bf16 ulp)
+}
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two fp32 -> packed bf16 (round-to-nearest-even) in one v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    uint32_t u;
+    __builtin_memcpy(&u, &r, 4);
+    return u;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    // s_waitcnt vmcnt(N): all but the wave's N youngest vector-memory operations are done (loads, LDS-DMA and
+    // stores count together, in issue order).
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// workgroups per CU the LDS footprint allows (<= 4), as waves per SIMD for __launch_bounds__: keeps the register
+// allocator from trading occupancy away on the small, memory-bound tile shapes.
+constexpr int conv_min_waves(int bm, int bn, int nw) {
+    const int lds = 2 * (bm + bn) * 128;
+    int wgs = (160 * 1024) / lds;
+    wgs = wgs < 1 ? 1 : (wgs > 4 ? 4 : wgs);
+    const int w = (nw / 4) * wgs;
+    return w > 8 ? 8 : w;
 }
 
 template <bool F32, int BM, int BN, int WM, int WN, bool OUT_F32>
-__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN)) void conv_igemm_kernel(const ConvParams p) {
     constexpr int NW = WM * WN;
     constexpr int ROWB = 128;                 // LDS bytes per row = one K chunk
     constexpr int NIW = BM / 8, NIX = BN / 8; // 1-KiB LDS-DMA instructions per chunk (weights, activations)
@@ -46,29 +74,48 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvPara
     static_assert(NW % 2 == 0, "swizzle phase assumes an even wave count");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int BUF = (BM + BN) * ROWB;
+    // epilogue staging: one 32-pixel x 32-cout fp32 block per wave at a time, rows padded by 16 B
+    constexpr int SROW = 32 * 4 + 16;
+    constexpr int STG = 32 * SROW;
+    static_assert(NW * STG <= BUF, "epilogue staging must fit in one pipeline buffer");
+    constexpr bool OUT4 = F32 || OUT_F32;                    // 4-byte outputs: two 16-B stores per item
+    constexpr int NSTORE = TM * TN * 2 * (OUT4 ? 2 : 1);     // store instructions a wave issues per tile
+    static_assert(NSTORE <= 63, "vmcnt immediate");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // XCD-aware, bijective block -> tile map: blocks that share an XCD (same blockIdx % 8) get a contiguous
-    // run of tiles, so neighbouring pixel tiles (shared 3x3 halo rows) and the weight panel hit one L2.
-    int wg;
+    // Persistent workgroups: block w handles tiles w, w + G, w + 2G, ...  The XCD-aware, bijective remap gives the
+    // blocks that share an XCD (same blockIdx % 8) consecutive w, so at any moment one L2 serves neighbouring pixel
+    // tiles (shared 3x3 halo rows) and one weight panel.
+    const int G = gridDim.x;
+    int tile;
     {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int bid = blockIdx.x;
+        const int q = G >> 3, r = G & 7, xcd = bid & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tile_m = wg % p.n_tiles_m, tile_n = wg / p.n_tiles_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int ntiles = p.n_tiles_m * p.n_tiles_n;
+    if (tile >= ntiles) return;
 
-    // ---------------- loader state ----------------
+    // ---------------- loader state (for the tile being staged) ----------------
     const int lrow = lane >> 3, lslot = lane & 7;
     const int gs = lslot ^ (((wave & 1) << 2) | (lrow >> 1));   // source group of this lane's LDS slot
     long long xbase[JX];
     unsigned xmask[JX];
-    {
-        const int hw = p.Ho * p.Wo;
+    const char* wsrc;
+    const long long wstep = (long long)8 * NW * p.kgroups_pad * 16;   // bytes between this lane's weight rows
+    const int hw = p.Ho * p.Wo;
+
+    auto decode_tile = [&](int t, int& m0, int& n0) {
+        const int tile_n = p.n_tiles_m == 1 ? t : (int)__umulhi((unsigned)t, p.magic_ntm);   // t / n_tiles_m
+        const int tile_m = t - tile_n * p.n_tiles_m;
+        m0 = tile_m * BM;
+        n0 = tile_n * BN;
+        wsrc = p.w + ((long long)(m0 + 8 * wave + lrow) * p.kgroups_pad + gs) * 16;
+        // pixel -> (b, y, x) without integer division: npix < 2^24 (checked on the host) so P is exact in fp32 and
+        // a reciprocal multiply is off by at most one, which the remainder test repairs.
 #pragma unroll
         for (int j = 0; j < JX; ++j) {
             const int r = 8 * (wave + NW * j) + lrow;
@@ -76,22 +123,24 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvPara
             unsigned mask = 0;
             long long base = 0;
             if (P < p.npix) {
-                const int b = P / hw, rem = P - b * hw;
-                const int y = rem / p.Wo, x = rem - y * p.Wo;
+                int b = (int)((float)P * p.inv_hw);
+                int rem = P - b * hw;
+                if (rem < 0) { --b; rem += hw; } else if (rem >= hw) { ++b; rem -= hw; }
+                int y = (int)((float)rem * p.inv_wo);
+                int x = rem - y * p.Wo;
+                if (x < 0) { --y; x += p.Wo; } else if (x >= p.Wo) { ++y; x -= p.Wo; }
                 const int iy0 = y * p.stride - p.pad, ix0 = x * p.stride - p.pad;
                 base = ((long long)(b * p.H + iy0) * p.W + ix0) * p.in_ld_b;
-                for (int t = 0; t < p.taps; ++t) {
-                    const int ky = t / p.k, kx = t - ky * p.k;
-                    const int iy = iy0 + ky, ix = ix0 + kx;
-                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
-                }
+                // tap mask = (valid rows) x (valid columns), k bits each
+                unsigned colbits = 0;
+                for (int kx = 0; kx < p.k; ++kx) colbits |= (unsigned)((unsigned)(ix0 + kx) < (unsigned)p.W) << kx;
+                for (int ky = 0; ky < p.k; ++ky)
+                    if ((unsigned)(iy0 + ky) < (unsigned)p.H) mask |= colbits << (ky * p.k);
             }
             xbase[j] = base;
             xmask[j] = mask;
         }
-    }
-    const char* wsrc = p.w + ((long long)(m0 + 8 * wave + lrow) * p.kgroups_pad + gs) * 16;
-    const long long wstep = (long long)8 * NW * p.kgroups_pad * 16;   // bytes between this lane's weight rows
+    };
 
     auto stage = [&](int chunk, char* buf) {
         // weights: rows [0, BM)
@@ -103,9 +152,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvPara
         }
         // activations: rows [BM, BM+BN)
         const int kg = chunk * 8 + gs;
-        const int tap = kg / p.G;
+        const int tap = p.G == 1 ? kg : (int)__umulhi((unsigned)kg, p.magic_G);   // kg / G (exact: kg, G < 2^15)
         const int cg = kg - tap * p.G;
-        const int ky = tap / p.k, kx = tap - ky * p.k;
+        const int ky = p.k == 1 ? tap : (int)__umulhi((unsigned)tap, p.magic_k);  // tap / k
+        const int kx = tap - ky * p.k;
         const long long tapoff = (long long)(ky * p.W + kx) * p.in_ld_b + cg * 16;
         const bool kvalid = kg < p.kgroups;
 #pragma unroll
@@ -123,12 +173,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvPara
     const int a_off = (wm * (BM / WM) + l31) * ROWB;
     const int b_off = BM * ROWB + (wn * (BN / WN) + l31) * ROWB;
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     auto compute = [&](const char* buf) {
 #pragma unroll
@@ -162,98 +206,126 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvPara
         }
     };
 
-    // ---------------- main loop: 2 LDS buffers, chunk c+1 in flight under chunk c's MFMAs ----------------
-    stage(0, smem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int c = 0; c < p.nchunks; ++c) {
-        char* cur = smem + (c & 1) * BUF;
-        char* nxt = smem + ((c & 1) ^ 1) * BUF;
-        if (c + 1 < p.nchunks) stage(c + 1, nxt);
-        compute(cur);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-
-    // ---------------- epilogue: +bias, SiLU -> LDS transpose -> (+residual) -> coalesced NHWC stores ----------------
+    // ---------------- epilogue: +bias, SiLU -> LDS transpose -> (+residual) -> coalesced NHWC stores -------------
     // MFMA C/D map (32x32): column (pixel) = lane & 31, row (cout) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5):
     // a lane holds 4-channel slivers of one pixel, so a direct store would touch 32 cache lines per instruction.
-    // Each wave instead transposes one 32-pixel block at a time through its own LDS region (fp32, padded rows)
-    // and then writes whole pixel rows: 8 consecutive channels (16 B of bf16) per lane, lanes along the row.
-    constexpr int CW = TM * 32;                 // couts of this wave
-    constexpr int ROWF = CW * 4 + 16;           // padded fp32 row (bytes): +16 B keeps ds_write_b128 conflict-free
-    constexpr int NCH = CW / 8;                 // 8-channel chunks per pixel row
-    constexpr int ITEMS = 32 * NCH;
-    char* stg = smem + wave * (32 * ROWF);
-    const int cbase = m0 + wm * (BM / WM);
+    // Each wave transposes one 32-cout x 32-pixel MFMA block at a time through its own LDS region (fp32, padded
+    // rows) and writes 8 consecutive channels (16 B of bf16) per lane, 4 lanes per pixel.
+    auto epilogue = [&](char* region, int m0, int n0) {
+        char* stg = region + wave * STG;
+        const int cwave = m0 + wm * (BM / WM);
+        const int pix = lane >> 2, ch = lane & 3;            // item = lane (+64): pixel, 8-channel chunk
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
+        for (int j = 0; j < TN; ++j) {
+            const int pbase = n0 + wn * (BN / WN) + j * 32;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
+                const int cblk = cwave + i * 32;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int cl = i * 32 + 8 * g + 4 * h;        // channel within the wave's CW
-                const f32x4 bv = *(const f32x4*)(p.bias + cbase + cl);
-                f32x4 v;
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = 8 * g + 4 * h;
+                    const f32x4 bv = *(const f32x4*)(p.bias + cblk + cl);
+                    f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[i][j][4 * g + e] + bv[e];
-                    if (p.act) t = silu<F32>(t);
-                    v[e] = t;
-                }
-                *(f32x4*)(stg + l31 * ROWF + cl * 4) = v;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        const int pbase = n0 + wn * (BN / WN) + j * 32;
-#pragma unroll
-        for (int it = 0; it < (ITEMS + 63) / 64; ++it) {
-            const int item = it * 64 + lane;
-            const int pix = item / NCH, ch = item - pix * NCH;
-            const int P = pbase + pix, c0 = cbase + ch * 8;
-            if (item < ITEMS && P < p.npix && c0 < p.cout) {
-                const f32x4 lo = *(const f32x4*)(stg + pix * ROWF + ch * 32);
-                const f32x4 hi = *(const f32x4*)(stg + pix * ROWF + ch * 32 + 16);
-                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                char* orow = p.out + (long long)P * p.out_ld_b;
-                if (F32) {
-                    if (p.res) {
-                        const char* rrow = p.res + (long long)P * p.res_ld_b + c0 * 4;
-                        const f32x4 r0 = *(const f32x4*)rrow, r1 = *(const f32x4*)(rrow + 16);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[i][j][4 * g + e] + bv[e];
+                        if (p.act) t = silu<F32>(t);
+                        v[e] = t;
                     }
-                    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                    *(f32x4*)(orow + c0 * 4) = o0;
-                    *(f32x4*)(orow + c0 * 4 + 16) = o1;
-                } else {
-                    if (p.res) {
-                        const uint4 rv = *(const uint4*)(p.res + (long long)P * p.res_ld_b + c0 * 2);
-                        const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+                    *(f32x4*)(stg + l31 * SROW + cl * 4) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[2 * e] += aq_bf2f((bf16_t)(rw[e] & 0xffff));
-                            v[2 * e + 1] += aq_bf2f((bf16_t)(rw[e] >> 16));
+                for (int it = 0; it < 2; ++it) {
+                    const int px = pix + 16 * it;
+                    const int P = pbase + px, c0 = cblk + ch * 8;
+                    const f32x4 lo = *(const f32x4*)(stg + px * SROW + ch * 32);
+                    const f32x4 hi = *(const f32x4*)(stg + px * SROW + ch * 32 + 16);
+                    if (P < p.npix && c0 < p.cout) {
+                        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        char* orow = p.out + (long long)P * p.out_ld_b;
+                        if (F32) {
+                            if (p.res) {
+                                const char* rrow = p.res + (long long)P * p.res_ld_b + c0 * 4;
+                                const f32x4 r0 = *(const f32x4*)rrow, r1 = *(const f32x4*)(rrow + 16);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                            }
+                        } else if (p.res) {
+                            const uint4 rv = *(const uint4*)(p.res + (long long)P * p.res_ld_b + c0 * 2);
+                            const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[2 * e] += __uint_as_float(rw[e] << 16);
+                                v[2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u);
+                            }
+                        }
+                        if (OUT4) {
+                            f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                            *(f32x4*)(orow + c0 * 4) = o0;
+                            *(f32x4*)(orow + c0 * 4 + 16) = o1;
+                        } else {
+                            uint4 o;
+                            o.x = pack_bf16x2(v[0], v[1]);
+                            o.y = pack_bf16x2(v[2], v[3]);
+                            o.z = pack_bf16x2(v[4], v[5]);
+                            o.w = pack_bf16x2(v[6], v[7]);
+                            *(uint4*)(orow + c0 * 2) = o;
                         }
                     }
-                    if (OUT_F32) {
-                        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                        *(f32x4*)(orow + c0 * 4) = o0;
-                        *(f32x4*)(orow + c0 * 4 + 16) = o1;
-                    } else {
-                        uint4 o;
-                        o.x = (uint32_t)aq_f2bf(v[0]) | ((uint32_t)aq_f2bf(v[1]) << 16);
-                        o.y = (uint32_t)aq_f2bf(v[2]) | ((uint32_t)aq_f2bf(v[3]) << 16);
-                        o.z = (uint32_t)aq_f2bf(v[4]) | ((uint32_t)aq_f2bf(v[5]) << 16);
-                        o.w = (uint32_t)aq_f2bf(v[6]) | ((uint32_t)aq_f2bf(v[7]) << 16);
-                        *(uint4*)(orow + c0 * 2) = o;
-                    }
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
             }
         }
+    };
+
+    // ---------------- flattened (tile, chunk) pipeline over two LDS buffers ----------------
+    // While chunk s feeds the MFMAs, chunk s+1 streams in by LDS-DMA; at a tile's last chunk the NEXT tile's
+    // first chunk is put in flight, so it lands during this tile's epilogue (stores are not waited for: the
+    // counted vmcnt leaves the epilogue's NSTORE youngest operations outstanding).
+    int m0, n0;
+    decode_tile(tile, m0, n0);
+    stage(0, smem);
+    wait_vmcnt<0>();
+    __syncthreads();
+    int step = 0;
+    while (true) {
+        const int m0_cur = m0, n0_cur = n0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        const int next_tile = tile + G;
+        char* cur = smem;
+        for (int c = 0; c < p.nchunks; ++c, ++step) {
+            cur = smem + (step & 1) * BUF;
+            char* nxt = smem + ((step & 1) ^ 1) * BUF;
+            const bool last = (c + 1 == p.nchunks);
+            if (!last) {
+                stage(c + 1, nxt);
+            } else if (next_tile < ntiles) {
+                decode_tile(next_tile, m0, n0);
+                stage(0, nxt);
+            }
+            compute(cur);
+            if (!last) {
+                wait_vmcnt<0>();
+                __syncthreads();
+            }
+        }
+        // every wave is done reading `cur` -> it becomes the epilogue staging area (raw barrier: no vmcnt drain)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_barrier();
+        epilogue(cur, m0_cur, n0_cur);
+        tile = next_tile;
+        if (tile >= ntiles) break;
+        wait_vmcnt<NSTORE>();                 // the next tile's first chunk has landed (this wave's part)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();         // ... and everyone's part; staging reads are finished too
     }
 }
 
@@ -283,13 +355,11 @@ const ConvConfig kConfigs[] = {
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
-// dynamic LDS: two K-chunk buffers, or the per-wave epilogue staging (32 pixel rows of fp32, padded) if larger
-size_t conv_lds_bytes(const ConvConfig& k) {
-    const size_t main_loop = (size_t)2 * (k.bm + k.bn) * 128;
-    const size_t staging = (size_t)(k.threads / 64) * 32 * (k.tm * 32 * 4 + 16);
-    return main_loop > staging ? main_loop : staging;
-}
+// dynamic LDS: two K-chunk buffers (the epilogue staging lives inside the idle one)
+size_t conv_lds_bytes(const ConvConfig& k) { return (size_t)2 * (k.bm + k.bn) * 128; }
 bool g_attr_set[kNumConfigs][3];
+int g_blocks_per_cu[kNumConfigs][3];
+int g_num_cus = 256;
 
 }  // namespace
 
@@ -329,6 +399,14 @@ int aq_launch_conv(const ConvParams& p_in, int precision, int out_f32, int cfg, 
     if (cfg < 0 || cfg >= kNumConfigs) { aq_set_error("conv: bad config %d", cfg); return AQ_ERR_INVALID; }
     const ConvConfig& k = kConfigs[cfg];
     ConvParams p = p_in;
+    if (p.npix >= (1 << 24) || p.kgroups_pad >= (1 << 15) || p.G <= 0 || p.G >= (1 << 15) || p.k <= 0) {
+        aq_set_error("conv: shape outside the fast-index range (npix=%d kgroups=%d)", p.npix, p.kgroups_pad);
+        return AQ_ERR_INVALID;
+    }
+    p.inv_hw = 1.0f / (float)(p.Ho * p.Wo);
+    p.inv_wo = 1.0f / (float)p.Wo;
+    p.magic_G = (unsigned)(0x100000000ull / (unsigned)p.G) + 1u;   // floor(n * magic / 2^32) == n / G for n < 2^15
+    p.magic_k = (unsigned)(0x100000000ull / (unsigned)p.k) + 1u;
     p.n_tiles_m = (p.cout + k.bm - 1) / k.bm;
     p.n_tiles_n = (p.npix + k.bn - 1) / k.bn;
     const int variant = precision == AQ_FP32 ? 2 : (out_f32 ? 1 : 0);
@@ -338,8 +416,22 @@ int aq_launch_conv(const ConvParams& p_in, int precision, int out_f32, int cfg, 
         AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         g_attr_set[cfg][variant] = true;
     }
-    const long long grid = (long long)p.n_tiles_m * p.n_tiles_n;
-    if (grid <= 0 || grid > 0x7fffffffLL) { aq_set_error("conv: bad grid %lld", grid); return AQ_ERR_INVALID; }
+    const long long ntiles = (long long)p.n_tiles_m * p.n_tiles_n;
+    if (ntiles <= 0 || ntiles > 0x7fffffffLL) { aq_set_error("conv: bad tile count %lld", ntiles); return AQ_ERR_INVALID; }
+    p.magic_ntm = (unsigned)(0x100000000ull / (unsigned)p.n_tiles_m) + 1u;
+    if (ntiles * p.n_tiles_m >= (1LL << 31)) { aq_set_error("conv: too many tiles"); return AQ_ERR_INVALID; }
+    // persistent grid: as many workgroups as stay resident (occupancy query once per kernel), capped by the tile count
+    if (g_blocks_per_cu[cfg][variant] == 0) {
+        int nb = 0;
+        AQ_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, k.threads, lds));
+        g_blocks_per_cu[cfg][variant] = nb > 0 ? nb : 1;
+        int dev = 0, cus = 256;
+        AQ_CHECK_HIP(hipGetDevice(&dev));
+        AQ_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        g_num_cus = cus;
+    }
+    long long grid = (long long)g_num_cus * g_blocks_per_cu[cfg][variant];
+    if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(k.threads), lds, stream, p);
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;

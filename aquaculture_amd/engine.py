@@ -255,12 +255,31 @@ class Engine:
     def set_conv_config(self, op: int, cfg: int) -> None:
         _check(self.lib.aq_engine_set_conv_config(self.handle, op, cfg))
 
-    def autotune(self, tiles: torch.Tensor, reps: int = 3) -> List[int]:
-        """Pick the fastest tile configuration per conv op for this batch geometry (synchronises)."""
+    def autotune(self, tiles: torch.Tensor, reps: int = 3, cache: Optional[str] = None) -> List[int]:
+        """Pick the fastest tile configuration per conv op for this batch geometry (synchronises).
+        ``cache``: optional JSON file; a stored table for the same model/precision/geometry is applied
+        instead of re-timing (used to keep tuning launches out of rocprof traces)."""
+        import json
         B, H, W = self._check_tiles(tiles)
+        key = f"{self.ck.variant}:nc{self.ck.nc}:p{self.precision}:{B}x{H}x{W}:n{self.lib.aq_conv_num_configs()}"
+        table = {}
+        if cache and os.path.exists(cache):
+            with open(cache) as f:
+                table = json.load(f)
+            if key in table and len(table[key]) == len(self.plan.ops):
+                for i, c in enumerate(table[key]):
+                    if self.plan.ops[i].kind == _spec.OP_CONV:
+                        self.set_conv_config(i, c)
+                return list(table[key])
         ws = self.workspace(B, H, W)
         _check(self.lib.aq_engine_autotune(self.handle, tiles.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(), reps, _stream_ptr()))
-        return [self.lib.aq_engine_get_conv_config(self.handle, i) for i in range(len(self.plan.ops))]
+        cfgs = [self.lib.aq_engine_get_conv_config(self.handle, i) for i in range(len(self.plan.ops))]
+        if cache:
+            table[key] = cfgs
+            os.makedirs(os.path.dirname(os.path.abspath(cache)), exist_ok=True)
+            with open(cache, "w") as f:
+                json.dump(table, f)
+        return cfgs
 
     def profile(self, enable: bool, ring: int = 32) -> None:
         _check(self.lib.aq_engine_profile(self.handle, int(enable), ring))

@@ -121,7 +121,7 @@ def main() -> int:
         tile_id = (torch.arange(K * B, device=dev).view(K, B, 1) * world + rank).expand(K, B, max_det)[keep]
         return aqdist.gather_rows(aqdist.pack_rows(tile_id, rows))
 
-    cfgs = eng.autotune(tiles_dev[0]) if not a.no_autotune else None
+    cfgs = eng.autotune(tiles_dev[0], cache=os.environ.get("AQ_TUNE_CACHE")) if not a.no_autotune else None
     for k in range(W):
         step(k, 0)
     gather_all()          # untimed: loads torch's indexing kernels / opens the RCCL channels once
