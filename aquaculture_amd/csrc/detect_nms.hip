@@ -25,60 +25,78 @@ struct DecodeParams {
     float anchor[3][8][2]; // pixels
     float* pred;           // [B][N][no] or null
     float conf_thres;
-    int32_t* cand;         // [B][cap] or null
+    int32_t* cand;         // [B][cap] candidate indices or null
+    float* cand_rows;      // [B][cap][no] decoded rows of the candidates (same order as cand) or null
     int32_t* cand_count;   // [B]
     int cap;
 };
 
 __device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+__device__ __forceinline__ void decode_row(const DecodeParams& p, const float* src, int lvl, int a, int x, int y,
+                                           float obj, float* dst) {
+    // xy = (xy * 2 + grid) * stride, grid = index - 0.5 ; wh = (wh * 2) ** 2 * anchor_grid
+    const float s0 = sigmoidf_ref(src[0]), s1 = sigmoidf_ref(src[1]);
+    const float s2 = sigmoidf_ref(src[2]), s3 = sigmoidf_ref(src[3]);
+    const float gx = (float)x - 0.5f, gy = (float)y - 0.5f;
+    dst[0] = (s0 * 2.0f + gx) * p.stride[lvl];
+    dst[1] = (s1 * 2.0f + gy) * p.stride[lvl];
+    const float tw = s2 * 2.0f, th = s3 * 2.0f;
+    dst[2] = (tw * tw) * p.anchor[lvl][a][0];
+    dst[3] = (th * th) * p.anchor[lvl][a][1];
+    dst[4] = obj;
+    for (int c = 0; c < p.nc; ++c) dst[5 + c] = sigmoidf_ref(src[5 + c]);
+}
+
+// One lane per (pixel, anchor), anchors of a pixel on adjacent lanes (they share the pixel's 128-byte head row).
+// Objectness is evaluated for every candidate; the other 9 sigmoids only where a row is actually written:
+// every row when the full pred tensor is requested (S1 alone), else only rows with obj > conf_thres, which go
+// to the compact candidate list that NMS reads.
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
     const int N = p.off[3];
-    const long long total = (long long)p.B * N;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(i / N), n = (int)(i - (long long)b * N);
-        const int lvl = n >= p.off[2] ? 2 : (n >= p.off[1] ? 1 : 0);
-        const int m = n - p.off[lvl];
+    const int b = blockIdx.y;
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < N; w += gridDim.x * blockDim.x) {
+        int m = w;                                         // position in the pixel-major walk of this image
+        const int na = p.na;
+        const int lvl = m >= p.off[2] ? 2 : (m >= p.off[1] ? 1 : 0);
+        m -= p.off[lvl];
         const int ny = p.ny[lvl], nx = p.nx[lvl];
-        const int a = m / (ny * nx), rem = m - a * ny * nx;
-        const int y = rem / nx, x = rem - y * nx;
-        const float* src = p.head[lvl] + (((long long)b * ny + y) * nx + x) * p.head_ld + a * p.no;
-        float* dst = p.pred ? p.pred + i * p.no : nullptr;
-        const float s0 = sigmoidf_ref(src[0]), s1 = sigmoidf_ref(src[1]);
-        const float s2 = sigmoidf_ref(src[2]), s3 = sigmoidf_ref(src[3]);
+        const int pix = (int)((unsigned)m / (unsigned)na), a = m - pix * na;
+        const int y = (int)((unsigned)pix / (unsigned)nx), x = pix - y * nx;
+        const int n = p.off[lvl] + a * ny * nx + pix;      // upstream candidate index: a * ny * nx + y * nx + x
+        const float* src = p.head[lvl] + ((long long)(b * ny + y) * nx + x) * p.head_ld + a * p.no;
         const float obj = sigmoidf_ref(src[4]);
-        if (dst) {
-            // xy = (xy * 2 + grid) * stride, grid = index - 0.5 ; wh = (wh * 2) ** 2 * anchor_grid
-            const float gx = (float)x - 0.5f, gy = (float)y - 0.5f;
-            dst[0] = (s0 * 2.0f + gx) * p.stride[lvl];
-            dst[1] = (s1 * 2.0f + gy) * p.stride[lvl];
-            const float tw = s2 * 2.0f, th = s3 * 2.0f;
-            dst[2] = (tw * tw) * p.anchor[lvl][a][0];
-            dst[3] = (th * th) * p.anchor[lvl][a][1];
-            dst[4] = obj;
-            for (int c = 0; c < p.nc; ++c) dst[5 + c] = sigmoidf_ref(src[5 + c]);
-        }
+        if (p.pred) decode_row(p, src, lvl, a, x, y, obj, p.pred + ((long long)b * N + n) * p.no);
         if (p.cand && obj > p.conf_thres) {
             const int pos = atomicAdd(p.cand_count + b, 1);
-            if (pos < p.cap) p.cand[(long long)b * p.cap + pos] = n;
+            if (pos < p.cap) {
+                p.cand[(long long)b * p.cap + pos] = n;
+                if (p.cand_rows) decode_row(p, src, lvl, a, x, y, obj, p.cand_rows + ((long long)b * p.cap + pos) * p.no);
+            }
         }
     }
 }
 
 struct NmsParams {
-    const float* pred;       // [B][N][no]
+    const float* rows;       // decoded rows: full pred [B][N][no] (rows_per_tile = N) or compact [B][cap][no]
+    int rows_per_tile;
     int B, N, nc, no;
     float conf_thres, iou_thres;
     int max_det;
-    const int32_t* cand;     // [B][cap] or null (then every index is examined)
+    const int32_t* cand;     // [B][cap] candidate index of each compact row, or null (row t IS candidate t)
     const int32_t* cand_count;
     int cap;
     unsigned long long* keys;   // [B][npow2]
-    float4* sbox;               // [B][N]
+    float4* sbox;               // [B][N]        (slow path)
+    unsigned long long* mask;   // [B][kFast][kFast/64] suppression bit matrix (fast path)
     int npow2;
     aq_det* dets;               // [B][max_det]
     int32_t* counts;            // [B]
 };
+
+constexpr int kFast = 2048;              // candidates handled by the bit-matrix path
+constexpr int kFastWords = kFast / 64;
+constexpr int kIdxBits = 17;             // candidate index / row slot < 2^17 (1280x1280 tiles: 100,800)
 
 // conf = obj * cls_conf, best class = first maximum; box = xywh2xyxy (x -/+ w/2)
 __device__ __forceinline__ bool candidate_row(const float* row, int nc, float thr, float4& box, float& conf, int& cls) {
@@ -97,6 +115,14 @@ __device__ __forceinline__ bool candidate_row(const float* row, int nc, float th
     return true;
 }
 
+// key = conf bits (30: 0 <= conf <= 1) | inverted candidate index (17) | row slot (17).  Descending key order is
+// descending confidence with ties broken by ascending candidate index (the slot never decides: indices are unique).
+__device__ __forceinline__ unsigned long long make_key(float conf, int idx, int slot) {
+    return ((unsigned long long)__float_as_uint(conf) << (2 * kIdxBits)) |
+           ((unsigned long long)(((1u << kIdxBits) - 1u) - (unsigned)idx) << kIdxBits) | (unsigned long long)slot;
+}
+__device__ __forceinline__ int key_slot(unsigned long long k) { return (int)(k & ((1u << kIdxBits) - 1u)); }
+
 __device__ __forceinline__ void bitonic_desc(unsigned long long* k, int n, int tid, int nthreads) {
     for (int size = 2; size <= n; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -112,26 +138,43 @@ __device__ __forceinline__ void bitonic_desc(unsigned long long* k, int n, int t
     }
 }
 
+// torchvision nms_kernel_impl's test, fp32, evaluated in its order: inter / (area_i + area_j - inter) > thr
+__device__ __forceinline__ bool iou_gt(const float4 bi, float iarea, const float4 bj, float thr) {
+    const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+    const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+    const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+    const float inter = w * h;
+    const float jarea = (bj.z - bj.x) * (bj.w - bj.y);
+    const float ovr = inter / (iarea + jarea - inter);
+    return ovr > thr;
+}
+
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
     __shared__ int s_n;
-    __shared__ unsigned long long s_keys[kSortLds];
-    __shared__ unsigned char s_supp[kMaxNms + 16];
+    // one LDS block, two uses: fast path = unsorted keys [kFast] + sorted offset boxes [kFast];
+    //                          slow path = keys for the in-LDS bitonic sort [kSortLds] + suppression flags
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kSortLds * 8 + kMaxNms + 16];
+    __shared__ int s_kept;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float* pred = p.pred + (long long)b * p.N * p.no;
+    const float* rows = p.rows + (long long)b * p.rows_per_tile * p.no;
     unsigned long long* keys = p.keys + (long long)b * p.npow2;
-    float4* sbox = p.sbox + (long long)b * p.N;
 
     if (tid == 0) s_n = 0;
     __syncthreads();
-    // A: threshold twice (obj, then obj*cls), key = (conf bits, ~index): descending key order is
-    //    descending confidence, ties by ascending candidate index.
+    // A: threshold twice (obj, then obj*cls) and build the sort keys
     const int n0 = p.cand ? min(p.cand_count[b], p.cap) : p.N;
     for (int t = tid; t < n0; t += kNmsThreads) {
         const int idx = p.cand ? p.cand[(long long)b * p.cap + t] : t;
         float4 box; float conf; int cls;
-        if (candidate_row(pred + (long long)idx * p.no, p.nc, p.conf_thres, box, conf, cls)) {
+        if (candidate_row(rows + (long long)t * p.no, p.nc, p.conf_thres, box, conf, cls)) {
             const int pos = atomicAdd(&s_n, 1);
-            keys[pos] = ((unsigned long long)__float_as_uint(conf) << 32) | (unsigned long long)(0xffffffffu - (unsigned)idx);
+            keys[pos] = make_key(conf, idx, t);
         }
     }
     __syncthreads();
@@ -140,7 +183,89 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
         if (tid == 0) p.counts[b] = 0;
         return;
     }
-    // B: sort
+
+    auto emit = [&](int slot, int k) {   // one output row [x1, y1, x2, y2, conf, cls], boxes WITHOUT the class offset
+        float4 box; float conf; int cls;
+        candidate_row(rows + (long long)slot * p.no, p.nc, p.conf_thres, box, conf, cls);
+        aq_det d; d.x1 = box.x; d.y1 = box.y; d.x2 = box.z; d.y2 = box.w; d.conf = conf; d.cls = (float)cls;
+        p.dets[(long long)b * p.max_det + k] = d;
+    };
+
+    if (n <= kFast) {
+        // ---------------- fast path ----------------
+        unsigned long long* kin = (unsigned long long*)s_raw;
+        float4* sb = (float4*)(s_raw + kFast * 8);
+        int* sslot = (int*)(s_raw + kFast * 8 + kFast * 16);          // row slot of the r-th most confident box
+        unsigned short* skept = (unsigned short*)(s_raw + kFast * 8 + kFast * 16 + kFast * 4);   // kept ranks
+        for (int t = tid; t < n; t += kNmsThreads) kin[t] = keys[t];
+        __syncthreads();
+        // B: rank sort (keys are unique): rank = number of larger keys; all lanes read the same kin[u] (broadcast)
+        for (int t = tid; t < n; t += kNmsThreads) {
+            const unsigned long long k = kin[t];
+            int r = 0;
+            for (int u = 0; u < n; ++u) r += (kin[u] > k) ? 1 : 0;
+            sslot[r] = key_slot(k);
+            // C: sorted boxes + class offset (boxes + cls * max_wh, fp32)
+            float4 box; float conf; int cls;
+            candidate_row(rows + (long long)key_slot(k) * p.no, p.nc, p.conf_thres, box, conf, cls);
+            const float c = (float)cls * kMaxWH;
+            box.x = box.x + c; box.y = box.y + c; box.z = box.z + c; box.w = box.w + c;
+            sb[r] = box;
+        }
+        __syncthreads();
+        // D1: suppression bit matrix, upper triangle: bit j of mask[i][w] = IoU(i, 64w + j) > thr, 64w + j > i
+        const int nw = (n + 63) >> 6;
+        unsigned long long* mask = p.mask + (long long)b * kFast * kFastWords;
+        for (int item = tid; item < n * nw; item += kNmsThreads) {
+            const int i = item / nw, w = item - i * nw;
+            unsigned long long bits = 0ull;
+            if (w >= (i >> 6)) {
+                const float4 bi = sb[i];
+                const float iarea = (bi.z - bi.x) * (bi.w - bi.y);
+                const int j0 = w << 6;
+                const int jbeg = max(j0, i + 1), jend = min(j0 + 64, n);
+                for (int j = jbeg; j < jend; ++j)
+                    if (iou_gt(bi, iarea, sb[j], p.iou_thres)) bits |= 1ull << (j - j0);
+            }
+            mask[(long long)i * nw + w] = bits;
+        }
+        __syncthreads();
+        // D2: greedy scan by one wave; lane w keeps word w of the removed set; mask rows are fetched 8 at a time
+        if (tid < 64) {
+            unsigned long long removed = 0ull;
+            int kept = 0;
+            bool done = false;
+            for (int i0 = 0; i0 < n && !done; i0 += 8) {
+                unsigned long long row[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    row[r] = (i0 + r < n && tid < nw) ? mask[(long long)(i0 + r) * nw + tid] : 0ull;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int i = i0 + r;
+                    if (i < n && !done) {
+                        const unsigned long long cur = readlane64(removed, i >> 6);
+                        if (!((cur >> (i & 63)) & 1ull)) {
+                            if (tid == 0) skept[kept] = (unsigned short)i;
+                            ++kept;
+                            removed |= row[r];
+                            if (kept >= p.max_det) done = true;
+                        }
+                    }
+                }
+            }
+            if (tid == 0) { p.counts[b] = kept; s_kept = kept; }
+        }
+        __syncthreads();
+        // E: all threads write the kept rows (descending confidence = ascending rank)
+        for (int k = tid; k < s_kept; k += kNmsThreads) emit(sslot[skept[k]], k);
+        return;
+    }
+
+    // ---------------- slow path (n > kFast): bitonic sort + barrier-per-kept greedy loop ----------------
+    unsigned long long* s_keys = (unsigned long long*)s_raw;
+    unsigned char* s_supp = s_raw + kSortLds * 8;
+    float4* sbox = p.sbox + (long long)b * p.N;
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
     for (int t = n + tid; t < np2; t += kNmsThreads) keys[t] = 0ull;
@@ -155,42 +280,26 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
         bitonic_desc(keys, np2, tid, kNmsThreads);
     }
     n = min(n, kMaxNms);
-    // C: sorted boxes + class offset (boxes + cls * max_wh, fp32)
     for (int t = tid; t < n; t += kNmsThreads) {
-        const int idx = (int)(0xffffffffu - (unsigned)(keys[t] & 0xffffffffull));
         float4 box; float conf; int cls;
-        candidate_row(pred + (long long)idx * p.no, p.nc, p.conf_thres, box, conf, cls);
+        candidate_row(rows + (long long)key_slot(keys[t]) * p.no, p.nc, p.conf_thres, box, conf, cls);
         const float c = (float)cls * kMaxWH;
         box.x = box.x + c; box.y = box.y + c; box.z = box.z + c; box.w = box.w + c;
         sbox[t] = box;
         s_supp[t] = 0;
     }
     __syncthreads();
-    // D: greedy pass (torchvision nms_kernel_impl): i kept unless suppressed; suppress j > i with IoU > thr
     int kept = 0;
     for (int i = 0; i < n; ++i) {
         if (s_supp[i]) continue;   // uniform: flags only change between barriers
-        if (tid == 0) {
-            const int idx = (int)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
-            float4 box; float conf; int cls;
-            candidate_row(pred + (long long)idx * p.no, p.nc, p.conf_thres, box, conf, cls);
-            aq_det d; d.x1 = box.x; d.y1 = box.y; d.x2 = box.z; d.y2 = box.w; d.conf = conf; d.cls = (float)cls;
-            p.dets[(long long)b * p.max_det + kept] = d;
-        }
+        if (tid == 0) emit(key_slot(keys[i]), kept);
         ++kept;
         if (kept >= p.max_det) break;
         const float4 bi = sbox[i];
         const float iarea = (bi.z - bi.x) * (bi.w - bi.y);
         for (int j = i + 1 + tid; j < n; j += kNmsThreads) {
             if (s_supp[j]) continue;
-            const float4 bj = sbox[j];
-            const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
-            const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-            const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
-            const float inter = w * h;
-            const float jarea = (bj.z - bj.x) * (bj.w - bj.y);
-            const float ovr = inter / (iarea + jarea - inter);
-            if (ovr > p.iou_thres) s_supp[j] = 1;
+            if (iou_gt(bi, iarea, sbox[j], p.iou_thres)) s_supp[j] = 1;
         }
         __syncthreads();
     }
@@ -204,11 +313,12 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" int aq_detect_decode(const float* const head_dev[3], int head_ld, int B, int H, int W, int nc, int na,
                                 const float* anchors_px, const float* stride, float* pred_dev, float conf_thres,
-                                int32_t* cand_dev, int32_t* cand_count_dev, int cand_cap, void* stream) {
+                                int32_t* cand_dev, float* cand_rows_dev, int32_t* cand_count_dev, int cand_cap, void* stream) {
     AQ_REQUIRE(head_dev && head_dev[0] && head_dev[1] && head_dev[2], "decode: null head pointer");
     AQ_REQUIRE(na >= 1 && na <= 8 && nc >= 1 && head_ld >= na * (nc + 5), "decode: bad na=%d nc=%d head_ld=%d", na, nc, head_ld);
     AQ_REQUIRE(pred_dev || cand_dev, "decode: nothing to write");
     AQ_REQUIRE(!cand_dev || (cand_count_dev && cand_cap > 0), "decode: candidate list needs a counter and a capacity");
+    AQ_REQUIRE(!cand_rows_dev || cand_dev, "decode: candidate rows need the candidate index list");
     DecodeParams p;
     p.head_ld = head_ld; p.B = B; p.nc = nc; p.na = na; p.no = nc + 5;
     int off = 0;
@@ -223,34 +333,41 @@ extern "C" int aq_detect_decode(const float* const head_dev[3], int head_ld, int
         for (int a = 0; a < na; ++a) { p.anchor[l][a][0] = anchors_px[(l * na + a) * 2]; p.anchor[l][a][1] = anchors_px[(l * na + a) * 2 + 1]; }
     }
     p.off[3] = off;
-    p.pred = pred_dev; p.conf_thres = conf_thres; p.cand = cand_dev; p.cand_count = cand_count_dev; p.cap = cand_cap;
+    p.pred = pred_dev; p.conf_thres = conf_thres; p.cand = cand_dev; p.cand_rows = cand_rows_dev;
+    p.cand_count = cand_count_dev; p.cap = cand_cap;
     if (cand_dev) AQ_CHECK_HIP(hipMemsetAsync(cand_count_dev, 0, sizeof(int32_t) * B, (hipStream_t)stream));
-    const long long total = (long long)B * off;
-    long long g = (total + 255) / 256;
-    if (g > 256 * 16) g = 256 * 16;
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p);
+    AQ_REQUIRE(B <= 65535, "decode: batch too large for the grid");
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((off + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, p);
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;
 }
 
 extern "C" size_t aq_nms_scratch_bytes(int B, int N) {
     if (B <= 0 || N <= 0) return 0;
-    return align_up((size_t)B * next_pow2(N) * sizeof(unsigned long long), 256) + align_up((size_t)B * N * sizeof(float4), 256);
+    return align_up((size_t)B * next_pow2(N) * sizeof(unsigned long long), 256) + align_up((size_t)B * N * sizeof(float4), 256) +
+           align_up((size_t)B * kFast * kFastWords * sizeof(unsigned long long), 256);
 }
 
-extern "C" int aq_nms(const float* pred_dev, int B, int N, int nc, float conf_thres, float iou_thres, int max_det,
-                      const int32_t* cand_dev, const int32_t* cand_count_dev, int cand_cap,
+extern "C" int aq_nms(const float* rows_dev, int rows_per_tile, int B, int N, int nc, float conf_thres, float iou_thres,
+                      int max_det, const int32_t* cand_dev, const int32_t* cand_count_dev, int cand_cap,
                       void* scratch_dev, aq_det* dets_dev, int32_t* counts_dev, void* stream) {
-    AQ_REQUIRE(pred_dev && scratch_dev && dets_dev && counts_dev, "nms: null pointer");
+    AQ_REQUIRE(rows_dev && scratch_dev && dets_dev && counts_dev, "nms: null pointer");
     AQ_REQUIRE(B > 0 && N > 0 && nc >= 1 && max_det > 0, "nms: bad shape B=%d N=%d nc=%d max_det=%d", B, N, nc, max_det);
-    AQ_REQUIRE(!cand_dev || (cand_count_dev && cand_cap > 0), "nms: candidate list needs a counter and a capacity");
+    AQ_REQUIRE(N < (1 << kIdxBits), "nms: at most %d candidates per tile are supported (got %d)", (1 << kIdxBits) - 1, N);
+    AQ_REQUIRE(!cand_dev || (cand_count_dev && cand_cap > 0 && cand_cap <= N && rows_per_tile == cand_cap),
+               "nms: a compact candidate list needs a counter, 0 < cap <= N and rows_per_tile == cap");
+    AQ_REQUIRE(cand_dev || rows_per_tile == N, "nms: without a candidate list the rows are the full pred (rows_per_tile == N)");
     NmsParams p;
-    p.pred = pred_dev; p.B = B; p.N = N; p.nc = nc; p.no = nc + 5;
+    p.rows = rows_dev; p.rows_per_tile = rows_per_tile; p.B = B; p.N = N; p.nc = nc; p.no = nc + 5;
     p.conf_thres = conf_thres; p.iou_thres = iou_thres; p.max_det = max_det;
     p.cand = cand_dev; p.cand_count = cand_count_dev; p.cap = cand_cap;
     p.npow2 = next_pow2(N);
-    p.keys = (unsigned long long*)scratch_dev;
-    p.sbox = (float4*)((char*)scratch_dev + align_up((size_t)B * p.npow2 * sizeof(unsigned long long), 256));
+    char* s = (char*)scratch_dev;
+    p.keys = (unsigned long long*)s;
+    s += align_up((size_t)B * p.npow2 * sizeof(unsigned long long), 256);
+    p.sbox = (float4*)s;
+    s += align_up((size_t)B * N * sizeof(float4), 256);
+    p.mask = (unsigned long long*)s;
     p.dets = dets_dev; p.counts = counts_dev;
     hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(kNmsThreads), 0, (hipStream_t)stream, p);
     AQ_CHECK_HIP(hipGetLastError());

@@ -76,7 +76,7 @@ struct aq_engine {
     // workspace layout of the last sizing / call
     int lay_B = 0, lay_H = 0, lay_W = 0;
     std::vector<TensorPlace> place;
-    size_t off_pred = 0, off_cand = 0, off_cand_count = 0, off_nms = 0, total_bytes = 0;
+    size_t off_pred = 0, off_cand = 0, off_cand_rows = 0, off_cand_count = 0, off_nms = 0, total_bytes = 0;
     int N = 0;
     void* last_ws = nullptr;
     const uint8_t* last_tiles = nullptr;
@@ -114,6 +114,7 @@ int layout(aq_engine* e, int B, int H, int W) {
     e->N = N;
     e->off_pred = off; off += align_up((size_t)B * N * (e->desc.nc + 5) * sizeof(float), kAlign);
     e->off_cand = off; off += align_up((size_t)B * N * sizeof(int32_t), kAlign);
+    e->off_cand_rows = off; off += align_up((size_t)B * N * (e->desc.nc + 5) * sizeof(float), kAlign);
     e->off_cand_count = off; off += align_up((size_t)B * sizeof(int32_t), kAlign);
     e->off_nms = off; off += align_up(aq_nms_scratch_bytes(B, N), kAlign);
     e->total_bytes = off;
@@ -173,6 +174,7 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
     float* pred = pred_out ? pred_out : (float*)((char*)ws + e->off_pred);
     int32_t* cand = (int32_t*)((char*)ws + e->off_cand);
     int32_t* cand_count = (int32_t*)((char*)ws + e->off_cand_count);
+    float* cand_rows = (float*)((char*)ws + e->off_cand_rows);
     for (int oi = 0; oi < n_ops; ++oi) {
         const aq_op_desc& op = e->ops[oi];
         if (ev) AQ_CHECK_HIP(hipEventRecord(ev[oi], stream));
@@ -207,13 +209,13 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
                 }
             const bool want_nms = dets != nullptr;
             rc = aq_detect_decode(heads, e->tensors[e->desc.head_tensor[0]].channels, B, H, W, e->desc.nc, e->desc.na,
-                                  anchors, e->desc.stride, pred, conf, want_nms ? cand : nullptr,
-                                  want_nms ? cand_count : nullptr, e->N, stream);
+                                  anchors, e->desc.stride, want_nms ? nullptr : pred, conf, want_nms ? cand : nullptr,
+                                  want_nms ? cand_rows : nullptr, want_nms ? cand_count : nullptr, e->N, stream);
             break;
         }
         case AQ_OP_NMS:
             if (dets)
-                rc = aq_nms(pred, B, e->N, e->desc.nc, conf, iou, max_det, cand, cand_count, e->N,
+                rc = aq_nms(cand_rows, e->N, B, e->N, e->desc.nc, conf, iou, max_det, cand, cand_count, e->N,
                             (char*)ws + e->off_nms, dets, counts, stream);
             break;
         default:

@@ -12,11 +12,11 @@ template <bool F32>
 __global__ __launch_bounds__(256) void preprocess_s2d_kernel(const uint8_t* __restrict__ in, char* __restrict__ out,
                                                             int B, int H, int W) {
     const int H2 = H >> 1, W2 = W >> 1;
-    const long long n = (long long)B * H2 * W2;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int X = (int)(i % W2);
-        const long long t = i / W2;
-        const int Y = (int)(t % H2), b = (int)(t / H2);
+    const unsigned n = (unsigned)B * H2 * W2;   // < 2^31 (checked on the host): 32-bit index math, no 64-bit division
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned t = i / (unsigned)W2;
+        const int X = (int)(i - t * W2);
+        const int b = (int)(t / (unsigned)H2), Y = (int)(t - (unsigned)b * H2);
         float v[16];
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
@@ -26,11 +26,11 @@ __global__ __launch_bounds__(256) void preprocess_s2d_kernel(const uint8_t* __re
         }
         v[12] = v[13] = v[14] = v[15] = 0.0f;
         if (F32) {
-            f32x4* o = (f32x4*)(out + i * 64);
+            f32x4* o = (f32x4*)(out + (size_t)i * 64);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { f32x4 x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; o[q] = x; }
         } else {
-            uint4* o = (uint4*)(out + i * 32);
+            uint4* o = (uint4*)(out + (size_t)i * 32);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 uint4 x;
@@ -57,13 +57,13 @@ __device__ __forceinline__ uint32_t max_bf16x2(uint32_t a, uint32_t b) {
 template <bool F32>
 __global__ __launch_bounds__(256) void maxpool5_kernel(const char* __restrict__ in, char* __restrict__ out,
                                                       int ld_b, int groups, int B, int H, int W) {
-    const long long n = (long long)B * H * W * groups;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % groups);
-        long long t = i / groups;
-        const int x = (int)(t % W); t /= W;
-        const int y = (int)(t % H);
-        const int b = (int)(t / H);
+    const unsigned n = (unsigned)B * H * W * groups;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        unsigned t = i / (unsigned)groups;
+        const int g = (int)(i - t * groups);
+        unsigned t2 = t / (unsigned)W;
+        const int x = (int)(t - t2 * W);
+        const int b = (int)(t2 / (unsigned)H), y = (int)(t2 - (unsigned)b * H);
         const int y0 = max(y - 2, 0), y1 = min(y + 2, H - 1), x0 = max(x - 2, 0), x1 = min(x + 2, W - 1);
         uint4 m = *(const uint4*)(in + (((long long)b * H + y) * W + x) * ld_b + g * 16);
         for (int yy = y0; yy <= y1; ++yy)
@@ -88,13 +88,13 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const char* __restrict_
                                                         char* __restrict__ out, int out_ld_b,
                                                         int groups, int B, int H, int W) {
     const int Ho = 2 * H, Wo = 2 * W;
-    const long long n = (long long)B * Ho * Wo * groups;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % groups);
-        long long t = i / groups;
-        const int x = (int)(t % Wo); t /= Wo;
-        const int y = (int)(t % Ho);
-        const int b = (int)(t / Ho);
+    const unsigned n = (unsigned)B * Ho * Wo * groups;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        unsigned t = i / (unsigned)groups;
+        const int g = (int)(i - t * groups);
+        unsigned t2 = t / (unsigned)Wo;
+        const int x = (int)(t - t2 * Wo);
+        const int b = (int)(t2 / (unsigned)Ho), y = (int)(t2 - (unsigned)b * Ho);
         const uint4 v = *(const uint4*)(in + (((long long)b * H + (y >> 1)) * W + (x >> 1)) * in_ld_b + g * 16);
         *(uint4*)(out + (((long long)b * Ho + y) * Wo + x) * out_ld_b + g * 16) = v;
     }
@@ -112,6 +112,7 @@ extern "C" int aq_preprocess_s2d(const uint8_t* tiles_dev, void* out_dev, int B,
     AQ_REQUIRE(tiles_dev && out_dev, "preprocess: null pointer");
     AQ_REQUIRE(B > 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0), "preprocess: bad shape B=%d H=%d W=%d", B, H, W);
     const long long n = (long long)B * (H / 2) * (W / 2);
+    AQ_REQUIRE(n < (1LL << 31), "preprocess: batch too large");
     if (precision == AQ_FP32)
         hipLaunchKernelGGL(preprocess_s2d_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, tiles_dev, (char*)out_dev, B, H, W);
     else
@@ -127,6 +128,7 @@ extern "C" int aq_sppf_pool(void* buf_dev, int ld, int ch_off, int c, int B, int
     AQ_REQUIRE(ch_off + 4 * c <= ld, "sppf_pool: slices [x|y1|y2|y3] exceed the buffer width");
     const int groups = c * eb / 16;
     const long long n = (long long)B * H * W * groups;
+    AQ_REQUIRE(n < (1LL << 31), "sppf_pool: batch too large");
     char* base = (char*)buf_dev + (long long)ch_off * eb;
     for (int s = 0; s < 3; ++s) {   // y1 = m(x), y2 = m(y1), y3 = m(y2)  [UPSTREAM SPPF.forward]
         const char* in = base + (long long)s * c * eb;
@@ -148,6 +150,7 @@ extern "C" int aq_upsample2x(const void* in_dev, int in_ld, int in_choff, void* 
                (in_ld * eb) % 16 == 0 && (out_ld * eb) % 16 == 0, "upsample2x: channels must be 16-byte groups");
     const int groups = c * eb / 16;
     const long long n = (long long)B * 4 * H * W * groups;
+    AQ_REQUIRE(n < (1LL << 31), "upsample2x: batch too large");
     hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const char*)in_dev + (long long)in_choff * eb, in_ld * eb,
                        (char*)out_dev + (long long)out_choff * eb, out_ld * eb, groups, B, H, W);

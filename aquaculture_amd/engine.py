@@ -102,10 +102,10 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_sppf_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.aq_upsample2x.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.aq_detect_decode.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32),
-                                     vp, f32, vp, vp, i32, vp]
+                                     vp, f32, vp, vp, vp, i32, vp]
     lib.aq_nms_scratch_bytes.argtypes = [i32, i32]
     lib.aq_nms_scratch_bytes.restype = sz
-    lib.aq_nms.argtypes = [vp, i32, i32, i32, f32, f32, i32, vp, vp, i32, vp, vp, vp, vp]
+    lib.aq_nms.argtypes = [vp, i32, i32, i32, i32, f32, f32, i32, vp, vp, i32, vp, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -307,7 +307,7 @@ def nms(pred: torch.Tensor, nc: int, conf_thres=0.25, iou_thres=0.45, max_det=10
     scratch = torch.empty(lib.aq_nms_scratch_bytes(B, N), dtype=torch.uint8, device=pred.device)
     dets = torch.empty((B, max_det, 6), dtype=torch.float32, device=pred.device)
     counts = torch.empty((B,), dtype=torch.int32, device=pred.device)
-    _check(lib.aq_nms(pred.data_ptr(), B, N, nc, conf_thres, iou_thres, max_det, None, None, 0,
+    _check(lib.aq_nms(pred.data_ptr(), N, B, N, nc, conf_thres, iou_thres, max_det, None, None, 0,
                       scratch.data_ptr(), dets.data_ptr(), counts.data_ptr(), _stream_ptr()))
     return dets, counts
 

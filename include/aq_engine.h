@@ -148,18 +148,21 @@ int aq_sppf_pool(void* buf_dev, int ld, int ch_off, int c, int B, int H, int W, 
 int aq_upsample2x(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff,
                   int c, int B, int H, int W, int precision, void* stream);
 /* Detect.forward inference branch on raw fp32 head maps [B][ny][nx][head_ld] (channel = a*no + o):
- * writes pred [B][N][no] when pred_dev != NULL; when cand_dev != NULL also compacts candidates with
- * obj > conf_thres into cand_dev[B][cand_cap] (index into N) and cand_count_dev[B]. */
+ * writes pred [B][N][no] when pred_dev != NULL; when cand_dev != NULL also compacts the candidates with
+ * obj > conf_thres: their candidate indices into cand_dev[B][cand_cap], their decoded rows into
+ * cand_rows_dev[B][cand_cap][no] (optional) and their number into cand_count_dev[B]. */
 int aq_detect_decode(const float* const head_dev[3], int head_ld, int B, int H, int W, int nc, int na,
                      const float* anchors_px /* [3][na][2] host */, const float* stride /* [3] host */,
-                     float* pred_dev, float conf_thres, int32_t* cand_dev, int32_t* cand_count_dev,
-                     int cand_cap, void* stream);
+                     float* pred_dev, float conf_thres, int32_t* cand_dev, float* cand_rows_dev,
+                     int32_t* cand_count_dev, int cand_cap, void* stream);
 /* S2: non_max_suppression(pred, conf, iou, classes=None, agnostic=False, multi_label=False, max_det).
+ * rows_dev is either the full pred [B][N][no] (rows_per_tile = N, cand_dev = NULL) or the compact rows
+ * aq_detect_decode wrote (rows_per_tile = cand_cap, with cand_dev / cand_count_dev).
  * scratch_dev: aq_nms_scratch_bytes(B, N).  Deterministic: ties in confidence by ascending candidate index;
- * no wall-clock time limit. */
+ * no wall-clock time limit.  N < 131072. */
 size_t aq_nms_scratch_bytes(int B, int N);
-int aq_nms(const float* pred_dev, int B, int N, int nc, float conf_thres, float iou_thres, int max_det,
-           const int32_t* cand_dev, const int32_t* cand_count_dev, int cand_cap,
+int aq_nms(const float* rows_dev, int rows_per_tile, int B, int N, int nc, float conf_thres, float iou_thres,
+           int max_det, const int32_t* cand_dev, const int32_t* cand_count_dev, int cand_cap,
            void* scratch_dev, aq_det* dets_dev, int32_t* counts_dev, void* stream);
 
 #ifdef __cplusplus
