@@ -58,6 +58,7 @@ struct ConvParams {
     int npix;            // B * Ho * Wo
     int act;
     int n_tiles_m, n_tiles_n;
+    int bias_n;          // bias entries staged into LDS (filled by aq_launch_conv)
     float inv_hw, inv_wo;        // reciprocals for division-free pixel decode (filled by aq_launch_conv)
     unsigned magic_G, magic_k, magic_ntm;   // floor(2^32 / d) + 1
 };

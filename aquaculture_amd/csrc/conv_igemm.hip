@@ -20,6 +20,7 @@
 // fp32 parity mode uses the same byte geometry (a 16-byte group = 4 floats) on v_mfma_f32_32x32x2_f32,
 // which is bit-for-bit an fmaf chain (exact fp32 products, fp32 accumulate).
 #include "aq_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -55,17 +56,18 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // workgroups per CU the LDS footprint allows (<= 4), as waves per SIMD for __launch_bounds__: keeps the register
 // allocator from trading occupancy away on the small, memory-bound tile shapes.
-constexpr int conv_min_waves(int bm, int bn, int nw) {
-    const int lds = 2 * (bm + bn) * 128;
+constexpr int conv_min_waves(int bm, int bn, int nw, int nstage) {
+    const int lds = nstage * (bm + bn) * 128;
     int wgs = (160 * 1024) / lds;
     wgs = wgs < 1 ? 1 : (wgs > 4 ? 4 : wgs);
     const int w = (nw / 4) * wgs;
     return w > 8 ? 8 : w;
 }
 
-template <bool F32, int BM, int BN, int WM, int WN, bool OUT_F32>
-__global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN)) void conv_igemm_kernel(const ConvParams p) {
+template <bool F32, int BM, int BN, int WM, int WN, bool OUT_F32, int NSTAGE, bool BIAS_LDS>
+__global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAGE)) void conv_igemm_kernel(const ConvParams p) {
     constexpr int NW = WM * WN;
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "pipeline depth");
     constexpr int ROWB = 128;                 // LDS bytes per row = one K chunk
     constexpr int NIW = BM / 8, NIX = BN / 8; // 1-KiB LDS-DMA instructions per chunk (weights, activations)
     constexpr int JW = (NIW + NW - 1) / NW, JX = NIX / NW;
@@ -80,7 +82,9 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN)) void
     static_assert(NW * STG <= BUF, "epilogue staging must fit in one pipeline buffer");
     constexpr bool OUT4 = F32 || OUT_F32;                    // 4-byte outputs: two 16-B stores per item
     constexpr int NSTORE = TM * TN * 2 * (OUT4 ? 2 : 1);     // store instructions a wave issues per tile
-    static_assert(NSTORE <= 63, "vmcnt immediate");
+    constexpr int LSTAGE = JW + JX;                          // LDS-DMA instructions a wave issues per stage
+    static_assert(NSTAGE == 2 || NIW % NW == 0, "counted vmcnt needs the same load count in every wave");
+    static_assert(NSTORE + LSTAGE <= 63, "vmcnt immediate");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -98,6 +102,16 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN)) void
     }
     const int ntiles = p.n_tiles_m * p.n_tiles_n;
     if (tile >= ntiles) return;
+
+    // bias vector -> LDS once (behind the pipeline buffers): the epilogue then issues no global loads of its own,
+    // so nothing in it makes the compiler drain the in-flight LDS-DMA prefetches (vmcnt is in-order).
+    // (BIAS_LDS = false for the one shape whose two resident workgroups use all 160 KiB already.)
+    const float* sbias = p.bias;
+    if constexpr (BIAS_LDS) {
+        float* sb = (float*)(smem + NSTAGE * BUF);
+        for (int i = tid; i < p.bias_n; i += NW * 64) sb[i] = p.bias[i];
+        sbias = sb;
+    }
 
     // ---------------- loader state (for the tile being staged) ----------------
     const int lrow = lane >> 3, lslot = lane & 7;
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN)) void
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int cl = 8 * g + 4 * h;
-                    const f32x4 bv = *(const f32x4*)(p.bias + cblk + cl);
+                    const f32x4 bv = *(const f32x4*)(sbias + cblk + cl);
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -281,85 +295,107 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN)) void
         }
     };
 
-    // ---------------- flattened (tile, chunk) pipeline over two LDS buffers ----------------
-    // While chunk s feeds the MFMAs, chunk s+1 streams in by LDS-DMA; at a tile's last chunk the NEXT tile's
-    // first chunk is put in flight, so it lands during this tile's epilogue (stores are not waited for: the
-    // counted vmcnt leaves the epilogue's NSTORE youngest operations outstanding).
-    int m0, n0;
-    decode_tile(tile, m0, n0);
-    stage(0, smem);
-    wait_vmcnt<0>();
-    __syncthreads();
+    // ---------------- flattened (tile, chunk) pipeline over NSTAGE LDS buffers ----------------
+    // Step s = (tile, chunk) in this workgroup's order.  While step s feeds the MFMAs, steps s+1 .. s+NSTAGE-1 stream
+    // in by LDS-DMA (a staging cursor runs NSTAGE-1 steps ahead, straight across tile boundaries), so a tile's
+    // epilogue overlaps the next tile's first chunks.  Waits are counted: vmcnt leaves the younger stage (and the
+    // epilogue's NSTORE stores) outstanding, never draining the queue inside the loop.
+    int st_tile = tile, st_chunk = 0, st_step = 0;   // staging cursor
+    int sm0, sn0;
+    auto stage_next = [&]() {
+        if (st_tile >= ntiles) return;
+        if (st_chunk == 0) decode_tile(st_tile, sm0, sn0);
+        stage(st_chunk, smem + (st_step % NSTAGE) * BUF);
+        ++st_step;
+        if (++st_chunk == p.nchunks) { st_chunk = 0; st_tile += G; }
+    };
+    // wait until step `need` has landed in this wave's view: at most (st_step - need - 1) younger stages (+ extra
+    // younger non-stage operations) may stay in flight
+    auto wait_step = [&](int need, auto extra_tag) {
+        constexpr int EXTRA = decltype(extra_tag)::value;
+        const int ahead = st_step - need - 1;
+        if (NSTAGE == 3 && ahead >= 1) wait_vmcnt<LSTAGE + EXTRA>();
+        else wait_vmcnt<EXTRA>();
+    };
+    using Tag0 = std::integral_constant<int, 0>;
+    using TagS = std::integral_constant<int, NSTORE>;
+
+#pragma unroll
+    for (int d = 0; d < NSTAGE - 1; ++d) stage_next();
+    wait_step(0, Tag0{});
+    __builtin_amdgcn_s_barrier();
     int step = 0;
-    while (true) {
-        const int m0_cur = m0, n0_cur = n0;
+    for (; tile < ntiles; tile += G) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-        const int next_tile = tile + G;
         char* cur = smem;
         for (int c = 0; c < p.nchunks; ++c, ++step) {
-            cur = smem + (step & 1) * BUF;
-            char* nxt = smem + ((step & 1) ^ 1) * BUF;
-            const bool last = (c + 1 == p.nchunks);
-            if (!last) {
-                stage(c + 1, nxt);
-            } else if (next_tile < ntiles) {
-                decode_tile(next_tile, m0, n0);
-                stage(0, nxt);
-            }
+            cur = smem + (step % NSTAGE) * BUF;
+            stage_next();                                  // step + NSTAGE - 1 (its buffer was freed by the last barrier)
             compute(cur);
-            if (!last) {
-                wait_vmcnt<0>();
-                __syncthreads();
+            if (c + 1 < p.nchunks) {
+                wait_step(step + 1, Tag0{});
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
             }
         }
         // every wave is done reading `cur` -> it becomes the epilogue staging area (raw barrier: no vmcnt drain)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        epilogue(cur, m0_cur, n0_cur);
-        tile = next_tile;
-        if (tile >= ntiles) break;
-        wait_vmcnt<NSTORE>();                 // the next tile's first chunk has landed (this wave's part)
+        const int tile_n = p.n_tiles_m == 1 ? tile : (int)__umulhi((unsigned)tile, p.magic_ntm);
+        epilogue(cur, (tile - tile_n * p.n_tiles_m) * BM, tile_n * BN);
+        if (tile + G >= ntiles) break;
+        wait_step(step, TagS{});                           // the next tile's first chunk has landed (this wave's part)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();         // ... and everyone's part; staging reads are finished too
+        __builtin_amdgcn_s_barrier();                      // ... and everyone's part; staging reads are finished too
     }
 }
 
 struct ConvConfig {
-    int bm, bn, threads, tm;
+    int bm, bn, threads, tm, nstage, bias_lds;
     void (*bf16)(const ConvParams);
     void (*bf16_f32out)(const ConvParams);
     void (*f32)(const ConvParams);
 };
 
-#define CFG(BM, BN, WM, WN)                                                                    \
-    { BM, BN, WM * WN * 64, BM / WM / 32, conv_igemm_kernel<false, BM, BN, WM, WN, false>,                   \
-      conv_igemm_kernel<false, BM, BN, WM, WN, true>, conv_igemm_kernel<true, BM, BN, WM, WN, true> }
+#define CFG(BM, BN, WM, WN, NS, BL)                                                                    \
+    { BM, BN, WM * WN * 64, BM / WM / 32, NS, BL, conv_igemm_kernel<false, BM, BN, WM, WN, false, NS, BL>, \
+      conv_igemm_kernel<false, BM, BN, WM, WN, true, NS, BL>, conv_igemm_kernel<true, BM, BN, WM, WN, true, NS, BL> }
 
 const ConvConfig kConfigs[] = {
-    CFG(256, 256, 2, 4),   // 0: per-wave 128x64
-    CFG(192, 256, 2, 4),   // 1: per-wave  96x64
-    CFG(128, 256, 2, 4),   // 2: per-wave  64x64
-    CFG(96, 512, 1, 8),    // 3: per-wave  96x64
-    CFG(64, 512, 1, 8),    // 4: per-wave  64x64
-    CFG(32, 512, 1, 8),    // 5: per-wave  32x64  (detect heads, cout padded to 32)
-    CFG(192, 128, 2, 4),   // 6: per-wave  96x32  (small-M layers: more tiles)
-    CFG(128, 128, 2, 2),   // 7: per-wave  64x64, 4 waves
-    CFG(64, 256, 1, 4),    // 8: per-wave  64x64, 4 waves
-    CFG(96, 256, 1, 4),    // 9: per-wave  96x64, 4 waves
-    CFG(64, 128, 1, 4),    // 10: per-wave 64x32, 4 waves
+    CFG(256, 256, 2, 4, 2, true),   // 0: per-wave 128x64
+    CFG(192, 256, 2, 4, 2, true),   // 1: per-wave  96x64
+    CFG(128, 256, 2, 4, 2, true),   // 2: per-wave  64x64
+    CFG(96, 512, 1, 8, 2, true),    // 3: per-wave  96x64
+    CFG(64, 512, 1, 8, 2, true),    // 4: per-wave  64x64
+    CFG(32, 512, 1, 8, 2, true),    // 5: per-wave  32x64  (detect heads, cout padded to 32)
+    CFG(192, 128, 2, 4, 2, false),   // 6: per-wave  96x32  (small-M layers: more tiles)
+    CFG(128, 128, 2, 2, 2, true),   // 7: per-wave  64x64, 4 waves
+    CFG(64, 256, 1, 4, 2, true),    // 8: per-wave  64x64, 4 waves
+    CFG(96, 256, 1, 4, 2, true),    // 9: per-wave  96x64, 4 waves
+    CFG(64, 128, 1, 4, 2, true),    // 10: per-wave 64x32, 4 waves
+    // 3-stage pipelines (two K chunks in flight)
+    CFG(192, 128, 2, 4, 3, true),   // 11
+    CFG(128, 256, 2, 4, 3, true),   // 12
+    CFG(128, 128, 2, 2, 3, true),   // 13
+    CFG(64, 256, 1, 4, 3, true),    // 14
+    CFG(96, 256, 1, 4, 3, true),    // 15
+    CFG(64, 128, 1, 4, 3, true),    // 16
+    CFG(256, 128, 4, 2, 3, true),   // 17: per-wave 64x64
+    CFG(192, 192, 2, 2, 3, true),   // 18: per-wave 96x96, 4 waves
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
-// dynamic LDS: two K-chunk buffers (the epilogue staging lives inside the idle one)
-size_t conv_lds_bytes(const ConvConfig& k) { return (size_t)2 * (k.bm + k.bn) * 128; }
+// dynamic LDS: NSTAGE K-chunk buffers (the epilogue staging lives inside the just-consumed one)
+size_t conv_lds_bytes(const ConvConfig& k, int bias_n) { return (size_t)k.nstage * (k.bm + k.bn) * 128 + (k.bias_lds ? (size_t)bias_n * 4 : 0); }
 bool g_attr_set[kNumConfigs][3];
-int g_blocks_per_cu[kNumConfigs][3];
-int g_num_cus = 256;
+struct OccEntry { size_t lds; int blocks; };
+OccEntry g_occ[kNumConfigs][3][8];   // resident blocks per CU by dynamic-LDS size (a handful of sizes per kernel)
+int g_num_cus = 0;
 
 }  // namespace
 
@@ -381,7 +417,8 @@ int aq_conv_pick_config(int cout, int npix, int precision) {
         const ConvConfig& k = kConfigs[c];
         const int tm = (cout + k.bm - 1) / k.bm, tn = (npix + k.bn - 1) / k.bn;
         const double waste = (double)(tm * k.bm) / cout;              // padded MFMA rows
-        const int lds = (int)conv_lds_bytes(k);
+        const int lds = (int)conv_lds_bytes(k, tm * k.bm);
+        if (lds > 160 * 1024) continue;
         const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
         const double slots = 256.0 * wg_per_cu;
         const double tiles = (double)tm * tn;
@@ -411,9 +448,11 @@ int aq_launch_conv(const ConvParams& p_in, int precision, int out_f32, int cfg, 
     p.n_tiles_n = (p.npix + k.bn - 1) / k.bn;
     const int variant = precision == AQ_FP32 ? 2 : (out_f32 ? 1 : 0);
     auto fn = variant == 2 ? k.f32 : (variant == 1 ? k.bf16_f32out : k.bf16);
-    const size_t lds = conv_lds_bytes(k);
+    p.bias_n = ((p.cout + k.bm - 1) / k.bm) * k.bm;   // every tile row has a bias slot (bias buffer is zero padded)
+    const size_t lds = conv_lds_bytes(k, p.bias_n);
+    if (lds > 160 * 1024) { aq_set_error("conv: config %d needs %zu B of LDS", cfg, lds); return AQ_ERR_INVALID; }
     if (!g_attr_set[cfg][variant]) {
-        AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         g_attr_set[cfg][variant] = true;
     }
     const long long ntiles = (long long)p.n_tiles_m * p.n_tiles_n;
@@ -421,16 +460,24 @@ int aq_launch_conv(const ConvParams& p_in, int precision, int out_f32, int cfg, 
     p.magic_ntm = (unsigned)(0x100000000ull / (unsigned)p.n_tiles_m) + 1u;
     if (ntiles * p.n_tiles_m >= (1LL << 31)) { aq_set_error("conv: too many tiles"); return AQ_ERR_INVALID; }
     // persistent grid: as many workgroups as stay resident (occupancy query once per kernel), capped by the tile count
-    if (g_blocks_per_cu[cfg][variant] == 0) {
-        int nb = 0;
-        AQ_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, k.threads, lds));
-        g_blocks_per_cu[cfg][variant] = nb > 0 ? nb : 1;
+    if (g_num_cus == 0) {
         int dev = 0, cus = 256;
         AQ_CHECK_HIP(hipGetDevice(&dev));
         AQ_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         g_num_cus = cus;
     }
-    long long grid = (long long)g_num_cus * g_blocks_per_cu[cfg][variant];
+    int blocks = 0;
+    OccEntry* occ = g_occ[cfg][variant];
+    for (int i = 0; i < 8; ++i) {
+        if (occ[i].blocks && occ[i].lds == lds) { blocks = occ[i].blocks; break; }
+        if (!occ[i].blocks || i == 7) {
+            int nb = 0;
+            AQ_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, k.threads, lds));
+            occ[i].lds = lds; occ[i].blocks = blocks = nb > 0 ? nb : 1;
+            break;
+        }
+    }
+    long long grid = (long long)g_num_cus * blocks;
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(k.threads), lds, stream, p);
     AQ_CHECK_HIP(hipGetLastError());

@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Per-op hardware counters for the bench workload (runs ON the GPU box).
+
+Runs `bench.py` under `rocprofv3 --pmc` once per counter group (counters in their own passes, with
+kernel-trace only -- never with sys/hip/hsa tracing), maps every kernel dispatch of the timed steps back to its
+plan op by position (each engine step launches a fixed kernel sequence starting with preprocess_s2d_kernel) and
+writes a per-op table.  FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for
+gfx950 wide coalesced reads; WRITE_SIZE is taken as is; both are in KiB in rocprofv3's output.
+
+    python tools/profile_pmc.py --out gpurun_out/pmc_r01 [--batch 64] [--groups sq1 sq2 fetch write]
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GROUPS = {
+    "sq1": "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE",
+    "sq2": "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM",
+    "fetch": "FETCH_SIZE",
+    "write": "WRITE_SIZE",
+    "l2": "TCC_HIT_sum TCC_MISS_sum",
+}
+
+
+def run_pass(name, counters, out, batch, steps):
+    d = os.path.join(out, name)
+    os.makedirs(d, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp", AQ_TUNE_CACHE=os.path.join(out, "tune_cache.json"))
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters.split(), "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "1", "--batch", str(batch),
+           "--no-cpu-baseline", "--no-profile"]
+    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
+    with open(os.path.join(d, "log.txt"), "w") as f:
+        f.write(r.stdout[-4000:] + "\n---\n" + r.stderr[-4000:])
+    if r.returncode != 0:
+        print(f"pass {name} failed rc={r.returncode}: {r.stderr[-600:]}", file=sys.stderr)
+        return None
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    return files[0] if files else None
+
+
+def parse(path):
+    """-> list of dispatches in order: {name, counters{}, dur_ns}"""
+    by_id = {}
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            did = int(row["Dispatch_Id"])
+            d = by_id.setdefault(did, {"name": row["Kernel_Name"], "c": {}, "vgpr": row.get("VGPR_Count"), "lds": row.get("LDS_Block_Size"),
+                                       "grid": row.get("Grid_Size"), "wg": row.get("Workgroup_Size"),
+                                       "dur": int(row.get("End_Timestamp", 0) or 0) - int(row.get("Start_Timestamp", 0) or 0)})
+            d["c"][row["Counter_Name"]] = d["c"].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+    return [by_id[k] for k in sorted(by_id)]
+
+
+def steps_of(disp, kernels_per_step):
+    starts = [i for i, d in enumerate(disp) if "preprocess_s2d_kernel" in d["name"]]
+    return [disp[s:s + kernels_per_step] for s in starts if s + kernels_per_step <= len(disp)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc"))
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--groups", nargs="+", default=["sq1", "sq2", "fetch", "write"])
+    a = ap.parse_args()
+    a.out = os.path.abspath(a.out)
+    os.makedirs(a.out, exist_ok=True)
+    # tuned configs first (outside any profiler), so the profiled runs launch no tuning kernels
+    env = dict(os.environ, AQ_TUNE_CACHE=os.path.join(a.out, "tune_cache.json"))
+    subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", str(a.batch),
+                    "--no-cpu-baseline"], env=env, capture_output=True, text=True, check=True)
+    sys.path.insert(0, ROOT)
+    from aquaculture_amd import spec
+    plan = spec.build_plan("yolov5m", 5)
+    fl = plan.flops(640, 640)
+    # kernel sequence of one step: one per op, the SPPF pool op launches 3 kernels
+    seq = []
+    for i, o in enumerate(plan.ops):
+        seq += [i] * (3 if o.kind == spec.OP_SPPF_POOL else 1)
+    merged = defaultdict(lambda: defaultdict(float))
+    meta = {}
+    for g in a.groups:
+        path = run_pass(g, GROUPS[g], a.out, a.batch, a.steps)
+        if not path:
+            continue
+        st = steps_of(parse(path), len(seq))
+        st = st[1:] if len(st) > 1 else st          # drop the warm-up step when there is another
+        for step in st:
+            for pos, d in enumerate(step):
+                op = seq[pos]
+                for k, v in d["c"].items():
+                    merged[op][k] += v / len(st)
+                merged[op]["dur_ns_" + g] += d["dur"] / len(st)
+                meta[op] = (d["name"], d["vgpr"], d["lds"], d["grid"], d["wg"])
+    rows = []
+    for i, o in enumerate(plan.ops):
+        c = merged.get(i, {})
+        rows.append({"op": i, "name": o.name, "kernel": meta.get(i, ("",))[0][:80], "vgpr": meta.get(i, ("", "", "", "", ""))[1],
+                     "lds": meta.get(i, ("", "", "", "", ""))[2], "grid": meta.get(i, ("", "", "", "", ""))[3],
+                     "flops": o.flops_per_tile * a.batch, **{k: v for k, v in c.items()}})
+    with open(os.path.join(a.out, "per_op.json"), "w") as f:
+        json.dump({"batch": a.batch, "rows": rows}, f)
+    # compact text table
+    def g(r, k):
+        return r.get(k, 0.0)
+    lines = ["op name                     us     TF/s  mfma%  valu%  lds%  wait%  waitinst% | VALU/MFMA inst  ldsconf% | rdMB  wrMB"]
+    for r in rows:
+        dur = g(r, "dur_ns_sq1") or g(r, "dur_ns_sq2") or g(r, "dur_ns_fetch")
+        if not dur:
+            continue
+        wc = g(r, "SQ_WAVE_CYCLES") or 1.0
+        busy = g(r, "SQ_BUSY_CYCLES") or 1.0
+        mf = g(r, "SQ_INSTS_MFMA") or 0.0
+        line = "%3d %-22s %7.1f %7.1f %6.1f %6.1f %5.1f %6.1f %9.1f | %7.1f %8.0f %7.1f | %6.1f %6.1f" % (
+            r["op"], r["name"][:22], dur / 1e3, r["flops"] / max(dur, 1) / 1e3,
+            100 * g(r, "SQ_VALU_MFMA_BUSY_CYCLES") / (busy * 4 if busy else 1),
+            100 * g(r, "SQ_ACTIVE_INST_VALU") / wc, 100 * g(r, "SQ_ACTIVE_INST_LDS") / wc, 100 * g(r, "SQ_WAIT_ANY") / wc,
+            100 * g(r, "SQ_WAIT_INST_ANY") / wc,
+            g(r, "SQ_INSTS_VALU") / mf if mf else 0.0, mf,
+            100 * g(r, "SQ_LDS_BANK_CONFLICT") / max(g(r, "SQ_LDS_IDX_ACTIVE"), 1.0),
+            2 * g(r, "FETCH_SIZE") / 1024, g(r, "WRITE_SIZE") / 1024)
+        lines.append(line)
+    txt = "\n".join(lines)
+    with open(os.path.join(a.out, "per_op.txt"), "w") as f:
+        f.write(txt + "\n")
+    print(txt)
+
+
+if __name__ == "__main__":
+    main()
