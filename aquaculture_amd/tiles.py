@@ -57,7 +57,8 @@ def synthetic_tile(i: int, size: int = 640) -> np.ndarray:
         n = int(rng.integers(1, 13))
         circ = rng.random() < 0.5
         pitch = int(rng.integers(44, 72))
-        x0, y0 = int(rng.integers(40, size // 2)), int(rng.integers(40, size // 2))
+        lo = min(40, size // 4)   # small test tiles: keep the draw valid (640-px tiles are unchanged)
+        x0, y0 = int(rng.integers(lo, size // 2)), int(rng.integers(lo, size // 2))
         yy, xx = np.mgrid[0:size, 0:size]
         for k in range(n):
             cx, cy = x0 + (k % 4) * pitch, y0 + (k // 4) * pitch

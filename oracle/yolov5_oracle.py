@@ -215,7 +215,8 @@ def greedy_nms(boxes: np.ndarray, iou_thres: float) -> List[int]:
         w = np.maximum(zero, xx2 - xx1)
         h = np.maximum(zero, yy2 - yy1)
         inter = w * h
-        ovr = inter / (areas[i] + areas[i + 1:] - inter)
+        with np.errstate(invalid="ignore", divide="ignore"):   # 0/0 for zero-area boxes -> NaN -> "not > thr", as in C
+            ovr = inter / (areas[i] + areas[i + 1:] - inter)
         suppressed[i + 1:] |= ovr > thr
     return keep
 

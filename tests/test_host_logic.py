@@ -1,0 +1,138 @@
+"""Host side of the path: label writer (byte-identical to the oracle's), letterbox, tile names, CLI, C ABI surface."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from aquaculture_amd import dataloader, detect, postprocess, tiles
+from oracle import yolov5_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _random_dets(rng, n, size):
+    d = np.zeros((n, 6), np.float32)
+    xy = rng.uniform(-20, size + 20, (n, 2))
+    wh = rng.uniform(1, 120, (n, 2))
+    d[:, 0:2] = xy - wh / 2
+    d[:, 2:4] = xy + wh / 2
+    d[:, 4] = np.sort(rng.uniform(0.25, 1.0, n))[::-1]
+    d[:, 5] = rng.integers(0, 5, n)
+    return d
+
+
+@pytest.mark.parametrize("img1,img0", [((640, 640), (640, 640)), ((640, 640), (1024, 1024)), ((480, 640), (500, 700)), ((640, 384), (1000, 600))])
+def test_label_text_is_byte_identical_to_oracle(img1, img0):
+    rng = np.random.default_rng(hash((img1, img0)) % 2 ** 31)
+    det = _random_dets(rng, 300, max(img1))
+    want = O.label_lines(det, img1, img0)
+    got = postprocess.format_rows(postprocess.detections_to_rows(det, img1, img0)).splitlines()
+    assert got == want
+    assert postprocess.detections_to_rows(np.zeros((0, 6), np.float32), img1, img0).shape == (0, 6)
+
+
+def test_label_file_contract_for_the_reference_consumer(tmp_path):
+    """reference src/process_yolo/geocode_results.py:140-172: np.loadtxt rows cls xc yc w h conf; ndim == 1 for one line;
+    no file when there are no detections (it only downloads images that have a label file, :46-55)."""
+    det = _random_dets(np.random.default_rng(1), 5, 640)
+    stem = tiles.tile_name(7).replace(".jpeg", "")
+    assert postprocess.write_label_file(str(tmp_path), stem, postprocess.detections_to_rows(det, (640, 640), (1024, 1024)))
+    arr = np.loadtxt(tmp_path / (stem + ".txt"))
+    assert arr.shape == (5, 6) and set(arr[:, 0]) <= {0, 1, 2, 3, 4} and np.all(np.diff(arr[:, 5]) >= 0)
+    assert int(1024 * (arr[0, 1] - arr[0, 3] / 2)) >= 0
+    assert not postprocess.write_label_file(str(tmp_path), "empty", np.zeros((0, 6), np.float32))
+    assert not (tmp_path / "empty.txt").exists()
+    one = postprocess.detections_to_rows(det[:1], (640, 640), (640, 640))
+    postprocess.write_label_file(str(tmp_path), "one", one)
+    assert np.loadtxt(tmp_path / "one.txt").ndim == 1
+    postprocess.write_label_file(str(tmp_path), "one", one)      # upstream opens in append mode
+    assert np.loadtxt(tmp_path / "one.txt").shape == (2, 6)
+
+
+def test_tile_name_codec_follows_reference_data():
+    """reference src/utils.py:372-389; all names in reference output/cf_images.csv have exactly four '_' fields."""
+    for i, year in ((0, 2015), (37, 2004), (123456, 2021)):
+        n = tiles.tile_name(i, year)
+        assert n.endswith(".jpeg") and len(n[:-5].split("_")) == 4
+        spec = tiles.parse_tile_name(n)
+        assert spec["year"] == str(year) and int(spec["x_offset"]) % 1024 == 0 and int(spec["y_offset"]) % 1024 == 0
+        assert int(os.path.basename(n).split("_")[0][-4:]) == year          # geocode_results.py:143
+    assert tiles.tile_name(5, 2021).startswith("ORTHOIMAGERY.ORTHOPHOTOS.ORTHO-EXPRESS.2021_")
+    with pytest.raises(ValueError):
+        tiles.parse_tile_name("a_b_c.jpeg")
+    a, b = tiles.synthetic_tile(3), tiles.synthetic_tile(3)
+    assert a.dtype == np.uint8 and a.shape == (640, 640, 3) and a.flags["C_CONTIGUOUS"] and np.array_equal(a, b)
+    assert not np.array_equal(a, tiles.synthetic_tile(4))
+
+
+def test_letterbox_geometry_and_resize():
+    assert dataloader.letterbox_geometry((640, 640)) == ((640, 640), (0, 0, 0, 0))
+    assert dataloader.letterbox_geometry((1024, 1024)) == ((640, 640), (0, 0, 0, 0))     # real tiles: scale 0.625, no pad
+    (nw, nh), pads = dataloader.letterbox_geometry((500, 700))
+    assert (nw, nh) == (640, 457) and pads == (11, 12, 0, 0) and (nh + 23) % 32 == 0
+    im = np.full((1024, 1024, 3), 77, np.uint8)
+    out = dataloader.letterbox(im)
+    assert out.shape == (640, 640, 3) and np.all(out == 77)                              # constants survive fixed-point bilinear
+    ramp = np.tile(np.arange(1024, dtype=np.float32)[None, :, None] / 4, (1024, 1, 3)).astype(np.uint8)
+    r = dataloader.resize_linear_u8(ramp, 640, 640).astype(np.int32)
+    assert np.all(np.diff(r[0, :, 0]) >= 0) and abs(int(r[0, 320, 0]) - int(ramp[0, 512, 0])) <= 1
+    out = dataloader.letterbox(np.zeros((500, 700, 3), np.uint8))
+    assert out.shape == (480, 640, 3) and np.all(out[:11] == 114) and np.all(out[-12:] == 114) and np.all(out[11:-12] == 0)
+    assert dataloader.check_img_size([640, 650]) == [640, 672]
+
+
+def test_load_images_sorted_sharded_and_batched(tmp_path):
+    paths = tiles.write_synthetic_jpegs(str(tmp_path), range(7), size=64)
+    (tmp_path / "notes.txt").write_text("not an image")
+    files = dataloader.list_images(str(tmp_path))
+    assert files == sorted(paths)
+    ds0 = dataloader.LoadImages(str(tmp_path), 64, shard=(0, 2), workers=2)
+    ds1 = dataloader.LoadImages(str(tmp_path), 64, shard=(1, 2), workers=1)
+    assert sorted(ds0.indices + ds1.indices) == list(range(7)) and len(ds0) == 4 and ds0.total == 7
+    batches = list(ds0.batches(3))
+    assert [b[1].shape for b in batches] == [(3, 64, 64, 3), (1, 64, 64, 3)] and batches[0][1].dtype == np.uint8
+    assert batches[0][2][0] == (64, 64)
+    with pytest.raises(FileNotFoundError):
+        dataloader.list_images(str(tmp_path / "missing"))
+
+
+def test_cli_flags_and_paths(tmp_path):
+    opt = detect.parse_opt(["--weights", "w.pt", "--source", "data/jpegs", "--nosave", "--save-txt", "--save-conf"])   # reference README.md:77
+    assert opt.imgsz == [640, 640] and opt.conf_thres == 0.25 and opt.iou_thres == 0.45 and opt.max_det == 1000
+    assert opt.save_txt and opt.save_conf and opt.nosave and not opt.half and opt.name == "exp"
+    assert detect.parse_opt(["--img", "1280"]).imgsz == [1280, 1280]
+    p = detect.increment_path(tmp_path / "exp")
+    assert p.name == "exp"
+    p.mkdir()
+    assert detect.increment_path(tmp_path / "exp").name == "exp2"
+    (tmp_path / "exp2").mkdir()
+    assert detect.increment_path(tmp_path / "exp").name == "exp3"
+    assert detect.increment_path(tmp_path / "exp", exist_ok=True).name == "exp"
+
+
+def test_library_exports_every_declared_symbol(lib):
+    """-m 'not gpu': the C-ABI library loads and exports every function include/aq_engine.h declares."""
+    from aquaculture_amd import engine
+    hdr = open(os.path.join(ROOT, "include", "aq_engine.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(aq_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 24
+    assert declared == set(engine.EXPORTS), declared ^ set(engine.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.aq_version() >= 1 and lib.aq_conv_num_configs() >= 10
+
+
+def test_no_cpu_fallback(synth_ck):
+    """The product path must fail loudly without a GPU; it never routes through the oracle or PyTorch eager."""
+    import torch
+    from aquaculture_amd import engine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        engine.Engine(synth_ck, "bf16")
+    with pytest.raises(RuntimeError):
+        engine.nms(torch.zeros(1, 10, 10), 5)
+    src = "".join(open(os.path.join(ROOT, "aquaculture_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "aquaculture_amd")) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src

@@ -1,0 +1,143 @@
+"""The oracle against the committed golden vectors, and the two independent restatements against each other
+(torch.nn.functional oracle vs the plain-C loops of oracle/ref_kernels.c)."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from aquaculture_amd import checkpoint, tiles
+from oracle import yolov5_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def cref():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_build", "libref_kernels.so"))
+    fp = C.POINTER(C.c_float)
+    lib.ref_conv2d_nhwc.argtypes = [fp, fp, fp, fp] + [C.c_int] * 9
+    lib.ref_maxpool5_nhwc.argtypes = [fp, fp] + [C.c_int] * 4
+    lib.ref_detect_decode.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, fp]
+    lib.ref_nms.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, fp]
+    lib.ref_format_label.argtypes = [fp, C.c_char_p, C.c_int]
+    return lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+@pytest.fixture(scope="module")
+def model(synth_ck):
+    return O.model_from_checkpoint(synth_ck)
+
+
+def test_g2_per_module_outputs_64(model):
+    g = np.load(os.path.join(GOLD, "g2_modules_64.npz"))
+    model.taps = {}
+    pred = model.forward(O.preprocess(tiles.synthetic_batch([0], 64)))
+    for k, v in model.taps.items():
+        np.testing.assert_allclose(v.numpy(), g[k.replace(".", "_")], rtol=1e-4, atol=1e-5, err_msg=k)
+    np.testing.assert_allclose(pred.numpy(), g["pred"], rtol=1e-4, atol=1e-4)
+    assert pred.shape == (1, 3 * (8 * 8 + 4 * 4 + 2 * 2), 10)
+    model.taps = None
+
+
+def test_g3_detections_and_label_text_640(model):
+    g = np.load(os.path.join(GOLD, "g3_detections_640.npz"))
+    with open(os.path.join(GOLD, "g3_labels_640.json")) as f:
+        labels = json.load(f)
+    idx = [0, 5, 11]                      # a subset keeps the CPU suite fast; the GPU suite checks all 16
+    dets = O.detect_tiles(model, tiles.synthetic_batch(idx, 640))
+    for i, d in zip(idx, dets):
+        ref = g[f"det_{i}"]
+        assert d.shape == ref.shape
+        np.testing.assert_allclose(d, ref, rtol=0, atol=2e-3)
+        lines = O.label_lines(d, (640, 640), (640, 640))
+        want = labels[tiles.tile_name(i)].split("\n")
+        assert len(lines) == len(want)
+        same = sum(a == b for a, b in zip(lines, want))
+        assert same >= 0.98 * len(want)   # thread-count dependent fp32 summation may flip a 6th digit of a confidence
+
+
+def test_g4_nms_cases():
+    g = np.load(os.path.join(GOLD, "g4_nms_cases.npz"))
+    names = sorted({k.split("__")[0] for k in g.files})
+    assert len(names) >= 7
+    for n in names:
+        ct, it, md = g[n + "__args"]
+        out = O.non_max_suppression(g[n + "__pred"], float(ct), float(it), int(md))[0]
+        assert np.array_equal(out, g[n + "__out"]), n
+    assert g["none_pass__out"].shape[0] == 0 and g["max_det_100__out"].shape[0] == 100
+    assert g["iou_exactly_half_thr050__out"].shape[0] == 2 and g["iou_exactly_half_thr045__out"].shape[0] == 1
+
+
+def test_g5_g6_label_formatting_and_box_rescale():
+    with open(os.path.join(GOLD, "g1_g5_g6.json")) as f:
+        g = json.load(f)
+    for c in g["g5"]:
+        v = np.array([c["value_f32_bits"]], np.uint32).view(np.float32)[0]
+        assert "%g" % float(v) == c["text"]
+    for c in g["g6"]:
+        assert O.label_lines(np.array(c["det"], np.float32), tuple(c["img1"]), tuple(c["img0"])) == c["lines"]
+
+
+def test_c_conv_matches_torch_conv(cref):
+    """Independent restatements agree: F.conv2d+SiLU (oracle primitive) vs plain C loops."""
+    g = torch.Generator().manual_seed(3)
+    for (B, H, W, cin, cout, k, s) in [(1, 9, 7, 16, 24, 3, 1), (2, 8, 8, 12, 8, 3, 2), (1, 6, 5, 32, 16, 1, 1)]:
+        x = torch.randn(B, H, W, cin, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) * 0.2
+        b = torch.randn(cout, generator=g) * 0.1
+        ref = torch.nn.functional.silu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, b, s, k // 2)).permute(0, 2, 3, 1).contiguous()
+        xn, wn, bn = x.numpy().copy(), np.ascontiguousarray(w.permute(0, 2, 3, 1).numpy()), b.numpy().copy()
+        out = np.zeros(tuple(ref.shape), np.float32)
+        cref.ref_conv2d_nhwc(_fp(xn), _fp(wn), _fp(bn), _fp(out), B, H, W, cin, cout, k, s, k // 2, 1)
+        np.testing.assert_allclose(out, ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_c_decode_and_nms_match_python_oracle(cref, model, synth_ck):
+    x = tiles.synthetic_batch([19], 128)
+    model.taps = {}
+    pred = model.forward(O.preprocess(x)).numpy()
+    ag = synth_ck.anchor_grid_px().numpy().astype(np.float32)
+    rows = []
+    for lvl, s in enumerate((8, 16, 32)):
+        head = np.ascontiguousarray(model.taps[f"model.24.m.{lvl}"].permute(0, 2, 3, 1).numpy())
+        ny, nx = head.shape[1:3]
+        out = np.zeros((1, 3 * ny * nx, 10), np.float32)
+        a = np.ascontiguousarray(ag[lvl])
+        cref.ref_detect_decode(_fp(head), _fp(out), 1, ny, nx, 3, 10, float(s), _fp(a))
+        rows.append(out)
+    model.taps = None
+    cpred = np.concatenate(rows, 1)
+    np.testing.assert_allclose(cpred, pred, rtol=1e-5, atol=1e-4)
+    ref = O.non_max_suppression(pred)[0]
+    out = np.zeros((1000, 6), np.float32)
+    p0 = np.ascontiguousarray(pred[0])
+    n = cref.ref_nms(_fp(p0), p0.shape[0], 5, 0.25, 0.45, 1000, _fp(out))
+    assert n == ref.shape[0] and np.array_equal(out[:n], ref)
+
+
+def test_c_printf_g_equals_python_percent_g(cref):
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([rng.uniform(0, 1, 200), 10.0 ** rng.uniform(-7, 7, 200), [0, 1, 0.5, 1e-5, 123456, 1234567]]).astype(np.float32)
+    buf = C.create_string_buffer(256)
+    for i in range(0, len(vals) - 6, 6):
+        row = np.ascontiguousarray(vals[i:i + 6])
+        cref.ref_format_label(_fp(row), buf, 256)
+        assert buf.value.decode() == ("%g " * 6).rstrip() % tuple(float(v) for v in row)
+
+
+def test_oracle_bf16_model_differs_only_by_rounding(synth_ck):
+    x = O.preprocess(tiles.synthetic_batch([0], 64))
+    a = O.model_from_checkpoint(synth_ck).forward(x)
+    b = O.model_from_checkpoint(synth_ck, O.q_bf16).forward(x)
+    d = (a[..., 4:] - b[..., 4:]).abs()
+    assert 0 < d.max() < 0.2 and d.mean() < 0.02

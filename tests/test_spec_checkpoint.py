@@ -1,0 +1,112 @@
+"""Host logic: architecture plan, checkpoint import without upstream code, BN folding, weight packing."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from aquaculture_amd import checkpoint, spec
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_flops_and_params_match_published_architecture():
+    """yolov5m nc=80 = 21.2 M params / 49.0 GFLOPs upstream; yolov5x = 86.7 M / 205.7."""
+    m = spec.build_plan("yolov5m", 80).flops(640, 640)
+    assert abs(m["total"] / 1e9 - 48.87) < 0.05
+    shapes = checkpoint.expected_state_shapes("yolov5m", 80)
+    params = sum(int(np.prod(s)) for k, s in shapes.items() if "running" not in k and not k.endswith("anchors"))
+    assert abs(params / 1e6 - 21.19) < 0.02
+    x = spec.build_plan("yolov5x", 80).flops(640, 640)
+    assert abs(x["total"] / 1e9 - 205.45) < 0.5
+    m5 = spec.build_plan("yolov5m", 5).flops(640, 640)
+    assert abs(m5["total"] / 1e9 - 47.905) < 0.01 and abs(m5["conv3x3"] / 1e9 - 33.974) < 0.01
+    assert spec.num_candidates(640, 640) == 25200
+
+
+def test_plan_is_well_formed():
+    p = spec.build_plan("yolov5m", 5)
+    written = {p.input_tensor: [(0, 3)]}
+    for op in p.ops:
+        if op.kind in (spec.OP_DECODE, spec.OP_NMS):
+            continue
+        for s in (op.src, op.res):
+            if s is None:
+                continue
+            assert 0 <= s.ch_off and s.ch_off + s.channels <= p.tensors[s.tensor].channels
+            covered = np.zeros(p.tensors[s.tensor].channels, bool)
+            for a, b in written.get(s.tensor, []):
+                covered[a:b] = True
+            assert covered[s.ch_off:s.ch_off + s.channels].all(), f"{op.name} reads channels nobody wrote"
+        d = op.dst
+        if op.kind == spec.OP_SPPF_POOL:
+            written.setdefault(d.tensor, []).append((d.ch_off, d.ch_off + d.channels))
+        else:
+            assert d.ch_off + d.channels <= p.tensors[d.tensor].channels
+            written.setdefault(d.tensor, []).append((d.ch_off, d.ch_off + d.channels))
+    assert len(p.conv_ops()) == 74 and sum(len(o.weight_keys) for o in p.conv_ops()) == 82   # 79 Conv + 3 Detect convs
+
+
+def test_synthetic_checkpoint_roundtrip_through_upstream_format(tmp_path):
+    """The .pt is a pickled module tree with models.yolo/models.common class paths; we load it with stand-ins."""
+    path = str(tmp_path / "syn.pt")
+    checkpoint.write_synthetic_checkpoint(path, "yolov5m", 5)
+    import pickle
+    raw = open(path, "rb").read()
+    assert b"models.yolo" in raw and b"DetectionModel" in raw and b"models.common" in raw
+    ck = checkpoint.load_checkpoint(path)
+    ref = checkpoint.synthetic_checkpoint("yolov5m", 5)
+    assert ck.variant == "yolov5m" and ck.nc == 5 and ck.na == 3 and ck.stride == (8.0, 16.0, 32.0) and ck.bn_eps == 1e-3
+    assert ck.names[0] == "circle_farm" and len(ck.names) == 5
+    assert set(k for k in ck.state if "num_batches" not in k) == set(ref.state)
+    for k, v in ref.state.items():
+        assert torch.equal(ck.state[k], v), k
+    assert all(v.dtype == torch.float32 for k, v in ck.state.items() if v.is_floating_point())
+
+
+def test_checkpoint_validation_rejects_wrong_architecture():
+    ck = checkpoint.synthetic_checkpoint("yolov5m", 5)
+    del ck.state["model.6.m.2.cv1.conv.weight"]
+    with pytest.raises(ValueError):
+        checkpoint.validate_against_plan(ck)
+
+
+def test_fuse_conv_bn_equals_conv_then_bn():
+    ck = checkpoint.synthetic_checkpoint("yolov5m", 5)
+    key = "model.3"
+    w, b = checkpoint.fuse_conv_bn(ck.state, key, ck.bn_eps)
+    x = torch.randn(1, w.shape[1], 9, 9)
+    y = F.conv2d(x, ck.state[f"{key}.conv.weight"], None, 1, 1)
+    y = F.batch_norm(y, ck.state[f"{key}.bn.running_mean"], ck.state[f"{key}.bn.running_var"],
+                     ck.state[f"{key}.bn.weight"], ck.state[f"{key}.bn.bias"], False, 0.0, ck.bn_eps)
+    torch.testing.assert_close(F.conv2d(x, w, b, 1, 1), y, rtol=1e-4, atol=1e-5)
+
+
+def test_stem_space_to_depth_rewrite_is_exact_convolution():
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(8, 3, 6, 6, generator=g)
+    x = torch.randn(2, 3, 32, 48, generator=g)
+    ref = F.conv2d(x, w, None, stride=2, padding=2)
+    B, C, H, W = x.shape
+    s2d = x.view(B, C, H // 2, 2, W // 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(B, 12, H // 2, W // 2)   # ch = (dy*2+dx)*3+c
+    s2d = torch.cat([s2d, torch.zeros(B, 4, H // 2, W // 2)], 1)
+    got = F.conv2d(s2d, checkpoint.stem_to_s2d(w), None, stride=1, padding=1)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_packed_weights_match_committed_digest():
+    with open(os.path.join(GOLD, "g1_g5_g6.json")) as f:
+        g1 = json.load(f)["g1"]
+    import hashlib
+    ck = checkpoint.synthetic_checkpoint("yolov5m", 5)
+    plan = spec.build_plan("yolov5m", 5)
+    packed = checkpoint.pack_plan_weights(ck, plan)
+    h = hashlib.sha256()
+    for pw in packed:
+        h.update(pw.weight.tobytes())
+        h.update(pw.bias.tobytes())
+    assert h.hexdigest() == g1["packed_sha256"], "synthetic checkpoint or packing changed: regenerate the golden fixtures"
+    for pw, op in zip(packed, plan.conv_ops()):
+        assert pw.weight.shape == (op.dst.channels, op.k, op.k, op.src.channels) and pw.weight.flags["C_CONTIGUOUS"]
