@@ -45,6 +45,21 @@ def run_pass(name, counters, out, batch, steps):
     return files[0] if files else None
 
 
+def run_stats(out, batch):
+    """`rocprofv3 --kernel-trace --stats` of the default bench command; returns (bench json, 3x3 avg launch us)."""
+    d = os.path.join(out, "stats")
+    os.makedirs(d, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp", AQ_TUNE_CACHE=os.path.join(out, "tune_cache.json"))
+    cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "bench", "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--batch", str(batch), "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
+    with open(os.path.join(d, "bench_stdout.json"), "w") as f:
+        f.write(r.stdout)
+    if r.returncode != 0:
+        print("stats pass failed:", r.stderr[-500:], file=sys.stderr)
+    return d
+
+
 def parse(path):
     """-> list of dispatches in order: {name, counters{}, dur_ns}"""
     by_id = {}
@@ -68,7 +83,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc"))
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--groups", nargs="+", default=["sq1", "sq2", "fetch", "write"])
+    ap.add_argument("--groups", nargs="+", default=["stats", "sq1", "sq2", "fetch", "write"])
     a = ap.parse_args()
     a.out = os.path.abspath(a.out)
     os.makedirs(a.out, exist_ok=True)
@@ -83,7 +98,26 @@ def main():
     # kernel sequence of one step: one per op, the SPPF pool op launches 3 kernels
     seq = []
     for i, o in enumerate(plan.ops):
-        seq += [i] * (3 if o.kind == spec.OP_SPPF_POOL else 1)
+        seq += [i] * (3 if o.kind == spec.OP_SPPF_POOL else (2 if o.kind == spec.OP_DECODE else 1))   # decode = memset + kernel
+    if "stats" in a.groups:
+        a.groups = [g for g in a.groups if g != "stats"]
+        sd = run_stats(a.out, a.batch)
+        tr = glob.glob(os.path.join(sd, "**", "*kernel_trace.csv"), recursive=True)
+        if tr:
+            disp = []
+            with open(tr[0]) as f:
+                for row in csv.DictReader(f):
+                    disp.append({"name": row["Kernel_Name"], "dur": int(row["End_Timestamp"]) - int(row["Start_Timestamp"]), "start": int(row["Start_Timestamp"])})
+            disp.sort(key=lambda d: d["start"])
+            st = steps_of(disp, len(seq))[-20:]          # the 20 timed steps (warm-up and autotune-free)
+            idx3 = [i for i, o in enumerate(plan.ops) if o.kind == spec.OP_CONV and o.meta.get("class") == "conv3x3"]
+            durs = [d["dur"] for step in st for pos, d in enumerate(step) if seq[pos] in idx3]
+            summ = {"steps": len(st), "conv3x3_launches": len(durs), "conv3x3_avg_launch_us": sum(durs) / max(len(durs), 1) / 1e3,
+                    "conv3x3_ms_per_step": sum(durs) / max(len(st), 1) / 1e6,
+                    "all_kernels_ms_per_step": sum(d["dur"] for step in st for d in step) / max(len(st), 1) / 1e6}
+            with open(os.path.join(a.out, "stats_summary.json"), "w") as f:
+                json.dump(summ, f, indent=1)
+            print("kernel-trace summary:", json.dumps(summ))
     merged = defaultdict(lambda: defaultdict(float))
     meta = {}
     for g in a.groups:
@@ -107,6 +141,16 @@ def main():
                      "flops": o.flops_per_tile * a.batch, **{k: v for k, v in c.items()}})
     with open(os.path.join(a.out, "per_op.json"), "w") as f:
         json.dump({"batch": a.batch, "rows": rows}, f)
+    # HBM traffic per launch of the dominant kernel (the 3x3 conv launches), gfx950 correction applied
+    r3 = [r for r, o in zip(rows, plan.ops) if o.kind == spec.OP_CONV and o.meta.get("class") == "conv3x3" and "FETCH_SIZE" in r and "WRITE_SIZE" in r]
+    if r3:
+        rd = sum(2 * r["FETCH_SIZE"] * 1024 for r in r3) / len(r3)
+        wr = sum(r["WRITE_SIZE"] * 1024 for r in r3) / len(r3)
+        with open(os.path.join(a.out, "hbm_traffic.json"), "w") as f:
+            json.dump({"kernel": "conv_igemm_kernel on the 28 3x3 layers", "batch": a.batch, "launches_averaged": len(r3),
+                       "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr,
+                       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 counts 128-B "
+                                 "requests at 64 B, MI355X_MICROARCH.md HBM section), KiB -> bytes; mean over the 28 launches of one step"}, f, indent=1)
     # compact text table
     def g(r, k):
         return r.get(k, 0.0)
