@@ -103,7 +103,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     precision = precision or ("bf16" if half else "fp32")
 
     rank, world, local = aqdist.init()
-    dev = int(device) if str(device).strip().isdigit() else local
+    dev = int(device) if str(device).strip().isdigit() else local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev)
 
     # directories: rank 0 picks the run directory, everyone uses it

@@ -25,7 +25,7 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, world, local = env_rank_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("AQ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -49,6 +49,8 @@ def gather_rows(rows: torch.Tensor) -> torch.Tensor:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return rows
     world = dist.get_world_size()
+    if dist.get_backend() == "gloo":
+        rows = rows.cpu()          # rehearsal backend: host tensors
     n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
@@ -67,6 +69,8 @@ def reduce_counters(tiles: int, labels: int, dets: int, elapsed_s: float, device
     """C3: sums of (tiles, label files, detections) and the max of elapsed seconds over ranks."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return tiles, labels, dets, elapsed_s
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
     s = torch.tensor([tiles, labels, dets], dtype=torch.int64, device=device)
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)

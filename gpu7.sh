@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 500 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -5
+timeout -k 10 800 python -m pytest tests/test_gpu_cli.py -x -q -m gpu 2>&1 | tail -15

@@ -1,0 +1,83 @@
+"""End to end through the preserved entry point: jpeg directory + upstream-format checkpoint -> label files
+(reference README.md:77 invocation; output consumed by reference src/process_yolo/geocode_results.py:123-172)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TILES = [0, 1, 2, 3, 19, 20, 21, 22, 23, 24]
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    from aquaculture_amd import checkpoint, tiles
+    d = tmp_path_factory.mktemp("cli")
+    tiles.write_synthetic_jpegs(str(d / "jpegs"), TILES, size=640)
+    checkpoint.write_synthetic_checkpoint(str(d / "multilabel_farms_synth.pt"), "yolov5m", 5)
+    return d
+
+
+def _run(workdir, name, extra=(), launcher=(), env=None):
+    cmd = [sys.executable, *launcher, os.path.join(ROOT, "yolov5", "detect.py"), "--weights", str(workdir / "multilabel_farms_synth.pt"),
+           "--source", str(workdir / "jpegs"), "--nosave", "--save-txt", "--save-conf", "--project", str(workdir / "runs"), "--name", name,
+           "--batch-size", "4", *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout, workdir / "runs" / name / "labels"
+
+
+def test_cli_writes_labels_the_consumer_can_parse(workdir, lib):
+    from aquaculture_amd import checkpoint, dataloader, tiles
+    from oracle import yolov5_oracle as O
+    out, labels = _run(workdir, "exp")
+    assert "labels saved to" in out and "Speed:" in out
+    files = sorted(os.listdir(labels))
+    stems = {tiles.tile_name(i)[:-5] for i in TILES}
+    assert files and {f[:-4] for f in files} <= stems
+    # oracle on the same decoded jpegs (fp32 is the CLI default = detect.py without --half)
+    model = O.model_from_checkpoint(checkpoint.load_checkpoint(str(workdir / "multilabel_farms_synth.pt")))
+    same = total = 0
+    for i in TILES:
+        stem = tiles.tile_name(i)[:-5]
+        im = dataloader.read_rgb(str(workdir / "jpegs" / (stem + ".jpeg")))
+        want = O.label_lines(O.detect_tiles(model, im[None])[0], (640, 640), (640, 640))
+        path = labels / (stem + ".txt")
+        if not want:
+            assert not path.exists()          # no detections => no file
+            continue
+        arr = np.loadtxt(path)
+        arr = arr[None] if arr.ndim == 1 else arr
+        assert arr.shape == (len(want), 6) and set(arr[:, 0]) <= {0, 1, 2, 3, 4}
+        assert np.all(np.diff(arr[:, 5]) >= -1e-6) and arr[:, 1:5].min() >= 0 and arr[:, 1:5].max() <= 1
+        got = open(path).read().splitlines()
+        pool = {}
+        for l in got:
+            f = l.split()
+            pool.setdefault(" ".join(f[:5]), []).append(float(f[5]))
+        for l in want:
+            f = l.split()
+            hit = [c for c in pool.get(" ".join(f[:5]), []) if abs(c - float(f[5])) <= 1e-4]
+            same += bool(hit)
+            total += 1
+    assert total > 500 and same >= 0.995 * total
+
+
+def test_cli_two_ranks_write_the_same_label_set(workdir, lib):
+    """torchrun with 2 ranks (both on the one GPU, gloo as the rehearsal backend): strided shard + final gather;
+    the union of the ranks' label files equals the single-process run byte for byte (tiles are independent)."""
+    _, ref = _run(workdir, "exp_ref", extra=("--half",))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out, lab = _run(workdir, "exp_ddp", extra=("--half",), env={"AQ_DIST_BACKEND": "gloo"},
+                    launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(port)))
+    assert "on 2 GPU(s)" in out
+    assert sorted(os.listdir(ref)) == sorted(os.listdir(lab))
+    for f in os.listdir(ref):
+        assert open(ref / f).read() == open(lab / f).read(), f
