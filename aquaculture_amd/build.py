@@ -20,6 +20,7 @@ ARCH = "gfx950"
 SOURCES = [
     # (file, extra flags)
     ("conv_igemm.hip", []),
+    ("conv_halo.hip", []),
     ("pointwise.hip", []),
     ("detect_nms.hip", ["-ffp-contract=off"]),   # bit-level parity with the oracle's fp32 op order
     ("engine.cpp", ["-x", "hip"]),

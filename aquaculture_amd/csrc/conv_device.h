@@ -1,0 +1,120 @@
+// Device helpers shared by the convolution kernels (gfx950).
+#pragma once
+#include "aq_common.h"
+
+namespace aqdev {
+
+__device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
+    // LDS-DMA: 16 B per lane from a PER-LANE global address to wave-uniform LDS base + lane * 16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <bool F32>
+__device__ __forceinline__ float silu(float v) {
+    // [UPSTREAM nn.SiLU]: v * sigmoid(v) = v / (1 + exp(-v))
+    if (F32) return v / (1.0f + expf(-v));                       // parity mode: IEEE divide, accurate exp
+    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));         // bf16 mode: v_exp + v_rcp (error << bf16 ulp)
+}
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {   // one v_cvt_pk_bf16_f32 (RNE)
+    f32x2_t v = {lo, hi};
+    bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    uint32_t u;
+    __builtin_memcpy(&u, &r, 4);
+    return u;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    // all but the wave's N youngest vector-memory operations are done (loads, LDS-DMA, stores: in issue order)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int kStgRow = 32 * 4 + 16;          // padded fp32 row of the 32x32 epilogue staging block
+constexpr int kStgBytes = 32 * kStgRow;       // per wave
+
+// Epilogue of one wave: acc[TM][TN] (32x32 MFMA C/D blocks; column = pixel = lane & 31,
+// row = cout = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) -> +bias, SiLU -> LDS transpose (one block at a time,
+// in the wave's own staging region) -> (+residual) -> 16-byte coalesced NHWC stores, 8 channels per lane.
+template <bool F32, bool OUT4, int TM, int TN>
+__device__ __forceinline__ void epilogue_store(const ConvParams& p, f32x16 (&acc)[TM][TN], char* stg, const float* sbias,
+                                               int cwave /*first cout of this wave*/, int pwave /*first pixel of this wave*/,
+                                               int lane) {
+    const int h = lane >> 5, l31 = lane & 31;
+    const int pix = lane >> 2, ch = lane & 3;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int pbase = pwave + j * 32;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int cblk = cwave + i * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = 8 * g + 4 * h;
+                const f32x4 bv = *(const f32x4*)(sbias + cblk + cl);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[i][j][4 * g + e] + bv[e];
+                    if (p.act) t = silu<F32>(t);
+                    v[e] = t;
+                }
+                *(f32x4*)(stg + l31 * kStgRow + cl * 4) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int px = pix + 16 * it;
+                const int P = pbase + px, c0 = cblk + ch * 8;
+                const f32x4 lo = *(const f32x4*)(stg + px * kStgRow + ch * 32);
+                const f32x4 hi = *(const f32x4*)(stg + px * kStgRow + ch * 32 + 16);
+                if (P < p.npix && c0 < p.cout) {
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    char* orow = p.out + (long long)P * p.out_ld_b;
+                    if (F32) {
+                        if (p.res) {
+                            const char* rrow = p.res + (long long)P * p.res_ld_b + c0 * 4;
+                            const f32x4 r0 = *(const f32x4*)rrow, r1 = *(const f32x4*)(rrow + 16);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                        }
+                    } else if (p.res) {
+                        const uint4 rv = *(const uint4*)(p.res + (long long)P * p.res_ld_b + c0 * 2);
+                        const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] += __uint_as_float(rw[e] << 16);
+                            v[2 * e + 1] += __uint_as_float(rw[e] & 0xffff0000u);
+                        }
+                    }
+                    if (OUT4) {
+                        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                        *(f32x4*)(orow + c0 * 4) = o0;
+                        *(f32x4*)(orow + c0 * 4 + 16) = o1;
+                    } else {
+                        uint4 o;
+                        o.x = pack_bf16x2(v[0], v[1]);
+                        o.y = pack_bf16x2(v[2], v[3]);
+                        o.z = pack_bf16x2(v[4], v[5]);
+                        o.w = pack_bf16x2(v[6], v[7]);
+                        *(uint4*)(orow + c0 * 2) = o;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// XCD-aware bijective block -> first-tile map of a persistent grid of G blocks (blocks sharing an XCD get consecutive ids)
+__device__ __forceinline__ int first_tile(int G, int bid) {
+    const int q = G >> 3, r = G & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+}  // namespace aqdev

@@ -399,10 +399,12 @@ int g_num_cus = 0;
 
 }  // namespace
 
-extern "C" int aq_conv_num_configs(void) { return kNumConfigs; }
+// one index space for tuning: [0, kNumConfigs) = implicit-GEMM tiles, then the halo-reuse 3x3 kernel's tiles
+extern "C" int aq_conv_num_configs(void) { return kNumConfigs + aq_conv_halo_num_configs(); }
 
 extern "C" int aq_conv_config_tiles(int cfg, int* bm, int* bn) {
-    if (cfg < 0 || cfg >= kNumConfigs) return AQ_ERR_INVALID;
+    if (cfg >= kNumConfigs) return aq_conv_halo_tiles(cfg - kNumConfigs, bm, bn);
+    if (cfg < 0) return AQ_ERR_INVALID;
     *bm = kConfigs[cfg].bm;
     *bn = kConfigs[cfg].bn;
     return AQ_OK;
@@ -433,7 +435,8 @@ int aq_conv_pick_config(int cout, int npix, int precision) {
 }
 
 int aq_launch_conv(const ConvParams& p_in, int precision, int out_f32, int cfg, hipStream_t stream) {
-    if (cfg < 0 || cfg >= kNumConfigs) { aq_set_error("conv: bad config %d", cfg); return AQ_ERR_INVALID; }
+    if (cfg >= kNumConfigs) return aq_launch_conv_halo(p_in, precision, out_f32, cfg - kNumConfigs, stream);
+    if (cfg < 0) { aq_set_error("conv: bad config %d", cfg); return AQ_ERR_INVALID; }
     const ConvConfig& k = kConfigs[cfg];
     ConvParams p = p_in;
     if (p.npix >= (1 << 24) || p.kgroups_pad >= (1 << 15) || p.G <= 0 || p.G >= (1 << 15) || p.k <= 0) {

@@ -415,6 +415,7 @@ extern "C" int aq_engine_autotune(aq_engine* e, const uint8_t* tiles_dev, int B,
         int best_cfg = -1;
         for (int c = 0; c < ncfg && rc == AQ_OK; ++c) {
             rc = run_conv(e, (int)oi, ws, tiles_dev, B, stream, c);   // warm-up (also sets the LDS attribute)
+            if (rc == AQ_ERR_INVALID) { rc = AQ_OK; continue; }       // this tile shape does not apply to this layer
             if (rc) break;
             (void)hipEventRecord(ev0, stream);
             for (int r = 0; r < reps && rc == AQ_OK; ++r) rc = run_conv(e, (int)oi, ws, tiles_dev, B, stream, c);

@@ -96,7 +96,9 @@ def main() -> int:
     from aquaculture_amd import checkpoint, dist as aqdist, spec
     from aquaculture_amd.engine import Engine
 
-    rank, world, local = aqdist.init("nccl" if int(os.environ.get("WORLD_SIZE", 1)) > 1 else None)
+    # one rank per GPU over RCCL ("nccl"); AQ_DIST_BACKEND=gloo is the single-GPU rehearsal of the N > 1 code path
+    rank, world, local = aqdist.init((os.environ.get("AQ_DIST_BACKEND") or "nccl") if int(os.environ.get("WORLD_SIZE", 1)) > 1 else None)
+    local = local % max(torch.cuda.device_count(), 1)
     if world != a.gpus:
         print(f"bench: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         return 2
@@ -140,7 +142,7 @@ def main() -> int:
     elapsed = time.perf_counter() - t0
     n_dets_total = int(rows.shape[0])
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t[0])
 
