@@ -21,7 +21,7 @@ using namespace aqdev;
 namespace {
 
 template <bool F32, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void conv3x3_halo_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) void conv3x3_halo_kernel(const ConvParams p) {
     constexpr int NW = WM * WN;
     constexpr int ROWB = 128;
     constexpr int NIW = BM / 8, JW = NIW / NW;
@@ -61,8 +61,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void conv3x3_halo_kern
         m0 = (t - tn * p.n_tiles_m) * BM;
         n0 = tn * BN;
     };
+    auto w_src = [&](int m0s, int tap, int cc) -> const char* {
+        return p.w + ((long long)(m0s + 8 * wave + lrow) * p.kgroups_pad + (tap * p.G + 8 * cc + gsw)) * 16;
+    };
     auto stage_w = [&](int m0s, int tap, int cc, char* wb) {
-        const char* src = p.w + ((long long)(m0s + 8 * wave + lrow) * p.kgroups_pad + (tap * p.G + 8 * cc + gsw)) * 16;
+        const char* src = w_src(m0s, tap, cc);
 #pragma unroll
         for (int j = 0; j < JW; ++j) glds16(src + j * wstep, wb + (wave + NW * j) * 1024);
     };
@@ -122,8 +125,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void conv3x3_halo_kern
         }
     };
 
-    auto compute = [&](const char* wb, const char* xb, int tap, int cc) {
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    // next-step DMA is issued in slices between the k-steps' MFMA bursts: weight-slice instructions after k-steps 0..2,
+    // the region part after k-step 3 (so the region loads are the youngest and the counted wait can leave them in flight)
+    int nx_issued = 0;
+    auto compute = [&](const char* wb, const char* xb, int tap, int cc, const char* nw_src, char* nw_buf,
+                       bool x_on, int x_n0, int x_cc, int x_part, char* x_buf) {
+        nx_issued = 0;
+        const int ty = (tap * 11) >> 5;                    // tap / 3 for tap < 9
+        const int dy = ty - 1, dx = tap - ty * 3 - 1;
         const int off = dy * p.W + dx;
         const char* rowp[TN];
         int swb[TN];
@@ -165,6 +174,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void conv3x3_halo_kern
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
                 }
             }
+            if (nw_src) {
+#pragma unroll
+                for (int j = 0; j < JW; ++j)
+                    if ((j * 3) / JW == ks) glds16(nw_src + j * wstep, nw_buf + (wave + NW * j) * 1024);
+            }
+            if (ks == 3 && x_on) nx_issued = stage_x_part(x_n0, x_cc, x_part, x_buf);
         }
     };
 
@@ -195,16 +210,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void conv3x3_halo_kern
             const bool last_chunk = (cc + 1 == CC);
             const bool next_chunk_exists = !last_chunk || has_next;
             const int nc_n0 = last_chunk ? n0n : n0, nc_cc = last_chunk ? 0 : cc + 1;
-#pragma unroll
+#pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
-                // weight slice of the next step
-                if (tap < 8) stage_w(m0, tap + 1, cc, wptr(wsel ^ 1));
-                else if (!last_chunk) stage_w(m0, 0, cc + 1, wptr(wsel ^ 1));
-                else if (has_next) stage_w(m0n, 0, 0, wptr(wsel ^ 1));
-                // one eighth of the next region (issued AFTER the weight slice: the counted wait leaves it in flight)
-                int nx = 0;
-                if (tap < 8 && next_chunk_exists) nx = stage_x_part(nc_n0, nc_cc, tap, xptr(xsel ^ 1));
-                compute(wptr(wsel), xptr(xsel), tap, cc);
+                // weight slice of the next step + one eighth of the next region, issued inside compute()
+                const char* nws = nullptr;
+                if (tap < 8) nws = w_src(m0, tap + 1, cc);
+                else if (!last_chunk) nws = w_src(m0, 0, cc + 1);
+                else if (has_next) nws = w_src(m0n, 0, 0);
+                compute(wptr(wsel), xptr(xsel), tap, cc, nws, wptr(wsel ^ 1), tap < 8 && next_chunk_exists, nc_n0, nc_cc, tap,
+                        xptr(xsel ^ 1));
+                const int nx = nx_issued;
                 if (!(last_chunk && tap == 8)) {
                     wait_n(nx);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -243,6 +258,9 @@ const HaloConfig kHalo[] = {
     HCFG(96, 128, 1, 4),    // per-wave 96x32, 4 waves
     HCFG(64, 128, 1, 4),    // per-wave 64x32, 4 waves
     HCFG(256, 128, 4, 2),   // per-wave 64x64
+    HCFG(192, 256, 2, 2),   // per-wave 96x128, 4 waves (one per SIMD, 512 registers): fewest LDS reads per MFMA
+    HCFG(384, 128, 2, 2),   // per-wave 192x64, 4 waves
+    HCFG(256, 256, 2, 4),   // per-wave 128x64
 };
 constexpr int kNumHalo = sizeof(kHalo) / sizeof(kHalo[0]);
 bool g_halo_attr[kNumHalo][2];

@@ -156,28 +156,34 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
         }
     };
 
-    auto stage = [&](int chunk, char* buf) {
-        // weights: rows [0, BM)
-#pragma unroll
-        for (int j = 0; j < JW; ++j) {
-            const int q = wave + NW * j;
-            if (NIW % NW == 0 || q < NIW)
-                glds16(wsrc + j * wstep + (long long)chunk * 128, buf + q * 1024);
+    // Staging of one (tile, chunk) step is split into NL = JW + JX single-instruction slots so that the slots can be
+    // issued BETWEEN the MFMA bursts of the step being computed (LDS-DMA issue is ~100 cycles per instruction; issued
+    // up front by every wave at once it would leave the matrix pipe idle after each barrier).
+    struct StageCtx { bool active; char* buf; long long wofs; int tap; long long tapoff; bool kvalid; };
+    constexpr int NL = JW + JX;
+    auto stage_slot = [&](const StageCtx& c, int i) {
+        if (!c.active) return;
+        if (i < JW) {                                          // weights: rows [0, BM)
+            const int q = wave + NW * i;
+            if (NIW % NW == 0 || q < NIW) glds16(wsrc + i * wstep + c.wofs, c.buf + q * 1024);
+        } else {                                               // activations: rows [BM, BM+BN)
+            const int j = i - JW;
+            const bool ok = c.kvalid && ((xmask[j] >> c.tap) & 1u);
+            const char* src = ok ? p.in + xbase[j] + c.tapoff : p.zero;
+            glds16(src, c.buf + BM * ROWB + (wave + NW * j) * 1024);
         }
-        // activations: rows [BM, BM+BN)
+    };
+    auto stage_ctx = [&](int chunk, char* buf) -> StageCtx {
+        StageCtx c;
+        c.active = true; c.buf = buf; c.wofs = (long long)chunk * 128;
         const int kg = chunk * 8 + gs;
-        const int tap = p.G == 1 ? kg : (int)__umulhi((unsigned)kg, p.magic_G);   // kg / G (exact: kg, G < 2^15)
-        const int cg = kg - tap * p.G;
-        const int ky = p.k == 1 ? tap : (int)__umulhi((unsigned)tap, p.magic_k);  // tap / k
-        const int kx = tap - ky * p.k;
-        const long long tapoff = (long long)(ky * p.W + kx) * p.in_ld_b + cg * 16;
-        const bool kvalid = kg < p.kgroups;
-#pragma unroll
-        for (int j = 0; j < JX; ++j) {
-            const bool ok = kvalid && ((xmask[j] >> tap) & 1u);
-            const char* src = ok ? p.in + xbase[j] + tapoff : p.zero;
-            glds16(src, buf + BM * ROWB + (wave + NW * j) * 1024);
-        }
+        c.tap = p.G == 1 ? kg : (int)__umulhi((unsigned)kg, p.magic_G);   // kg / G (exact: kg, G < 2^15)
+        const int cg = kg - c.tap * p.G;
+        const int ky = p.k == 1 ? c.tap : (int)__umulhi((unsigned)c.tap, p.magic_k);  // tap / k
+        const int kx = c.tap - ky * p.k;
+        c.tapoff = (long long)(ky * p.W + kx) * p.in_ld_b + cg * 16;
+        c.kvalid = kg < p.kgroups;
+        return c;
     };
 
     // ---------------- MFMA state ----------------
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
     const int b_off = BM * ROWB + (wn * (BN / WN) + l31) * ROWB;
     f32x16 acc[TM][TN];
 
-    auto compute = [&](const char* buf) {
+    auto compute = [&](const char* buf, const StageCtx& nx) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int so = (((2 * ks + h) ^ sw) << 4);
@@ -217,6 +223,9 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
             }
+#pragma unroll
+            for (int i = 0; i < NL; ++i)
+                if ((i * 4) / NL == ks) stage_slot(nx, i);     // this k-step's share of the next stage's LDS-DMA
         }
     };
 
@@ -302,12 +311,14 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
     // epilogue's NSTORE stores) outstanding, never draining the queue inside the loop.
     int st_tile = tile, st_chunk = 0, st_step = 0;   // staging cursor
     int sm0, sn0;
-    auto stage_next = [&]() {
-        if (st_tile >= ntiles) return;
+    auto stage_begin = [&]() -> StageCtx {
+        StageCtx c; c.active = false;
+        if (st_tile >= ntiles) return c;
         if (st_chunk == 0) decode_tile(st_tile, sm0, sn0);
-        stage(st_chunk, smem + (st_step % NSTAGE) * BUF);
+        c = stage_ctx(st_chunk, smem + (st_step % NSTAGE) * BUF);
         ++st_step;
         if (++st_chunk == p.nchunks) { st_chunk = 0; st_tile += G; }
+        return c;
     };
     // wait until step `need` has landed in this wave's view: at most (st_step - need - 1) younger stages (+ extra
     // younger non-stage operations) may stay in flight
@@ -321,7 +332,11 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
     using TagS = std::integral_constant<int, NSTORE>;
 
 #pragma unroll
-    for (int d = 0; d < NSTAGE - 1; ++d) stage_next();
+    for (int d = 0; d < NSTAGE - 1; ++d) {
+        const StageCtx c = stage_begin();
+#pragma unroll
+        for (int i = 0; i < NL; ++i) stage_slot(c, i);
+    }
     wait_step(0, Tag0{});
     __builtin_amdgcn_s_barrier();
     int step = 0;
@@ -335,8 +350,8 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
         char* cur = smem;
         for (int c = 0; c < p.nchunks; ++c, ++step) {
             cur = smem + (step % NSTAGE) * BUF;
-            stage_next();                                  // step + NSTAGE - 1 (its buffer was freed by the last barrier)
-            compute(cur);
+            const StageCtx nx = stage_begin();             // step + NSTAGE - 1 (its buffer was freed by the last barrier)
+            compute(cur, nx);                              // ... loaded in slices between this step's MFMA bursts
             if (c + 1 < p.nchunks) {
                 wait_step(step + 1, Tag0{});
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -83,6 +83,46 @@ __global__ __launch_bounds__(256) void maxpool5_kernel(const char* __restrict__ 
     }
 }
 
+// SPPF's three chained pools in ONE launch: a workgroup owns one (image, 16-byte channel group) plane, keeps it in
+// LDS (two ping-pong planes) and writes y1, y2, y3 to their channel slices; x is read from HBM once.
+template <bool F32>
+__device__ __forceinline__ uint4 max16(uint4 a, uint4 v) {
+    if (F32) {
+        a.x = __float_as_uint(fmaxf(__uint_as_float(a.x), __uint_as_float(v.x)));
+        a.y = __float_as_uint(fmaxf(__uint_as_float(a.y), __uint_as_float(v.y)));
+        a.z = __float_as_uint(fmaxf(__uint_as_float(a.z), __uint_as_float(v.z)));
+        a.w = __float_as_uint(fmaxf(__uint_as_float(a.w), __uint_as_float(v.w)));
+    } else {
+        a.x = max_bf16x2(a.x, v.x); a.y = max_bf16x2(a.y, v.y); a.z = max_bf16x2(a.z, v.z); a.w = max_bf16x2(a.w, v.w);
+    }
+    return a;
+}
+
+template <bool F32>
+__global__ __launch_bounds__(256) void sppf_pool3_kernel(char* __restrict__ base, int ld_b, int slice_b, int groups, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int hw = H * W;
+    uint4* plane[2] = {(uint4*)smem, (uint4*)smem + hw};
+    const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+    char* img = base + (long long)b * hw * ld_b + g * 16;
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) plane[0][i] = *(const uint4*)(img + (long long)i * ld_b);
+    __syncthreads();
+    for (int s = 0; s < 3; ++s) {
+        const uint4* src = plane[s & 1];
+        uint4* dst = plane[(s & 1) ^ 1];
+        for (int i = threadIdx.x; i < hw; i += blockDim.x) {
+            const int y = i / W, x = i - y * W;
+            const int y0 = max(y - 2, 0), y1 = min(y + 2, H - 1), x0 = max(x - 2, 0), x1 = min(x + 2, W - 1);
+            uint4 m = src[i];
+            for (int yy = y0; yy <= y1; ++yy)
+                for (int xx = x0; xx <= x1; ++xx) m = max16<F32>(m, src[yy * W + xx]);
+            dst[i] = m;
+            *(uint4*)(img + (long long)i * ld_b + (long long)(s + 1) * slice_b) = m;
+        }
+        __syncthreads();
+    }
+}
+
 // nn.Upsample(scale_factor=2, mode='nearest'): out[b][y][x] = in[b][y/2][x/2]; H, W are the INPUT size.
 __global__ __launch_bounds__(256) void upsample2x_kernel(const char* __restrict__ in, int in_ld_b,
                                                         char* __restrict__ out, int out_ld_b,
@@ -130,6 +170,15 @@ extern "C" int aq_sppf_pool(void* buf_dev, int ld, int ch_off, int c, int B, int
     const long long n = (long long)B * H * W * groups;
     AQ_REQUIRE(n < (1LL << 31), "sppf_pool: batch too large");
     char* base = (char*)buf_dev + (long long)ch_off * eb;
+    const size_t plane_lds = (size_t)2 * H * W * 16;
+    if (plane_lds <= 64 * 1024 && (long long)B * groups < (1LL << 31)) {      // whole plane fits LDS: one fused launch
+        if (precision == AQ_FP32)
+            hipLaunchKernelGGL(sppf_pool3_kernel<true>, dim3((unsigned)(B * groups)), dim3(256), plane_lds, (hipStream_t)stream, base, ld * eb, c * eb, groups, H, W);
+        else
+            hipLaunchKernelGGL(sppf_pool3_kernel<false>, dim3((unsigned)(B * groups)), dim3(256), plane_lds, (hipStream_t)stream, base, ld * eb, c * eb, groups, H, W);
+        AQ_CHECK_HIP(hipGetLastError());
+        return AQ_OK;
+    }
     for (int s = 0; s < 3; ++s) {   // y1 = m(x), y2 = m(y1), y3 = m(y2)  [UPSTREAM SPPF.forward]
         const char* in = base + (long long)s * c * eb;
         char* out = base + (long long)(s + 1) * c * eb;

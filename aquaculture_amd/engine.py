@@ -178,7 +178,7 @@ class Engine:
             _check(self.lib.aq_engine_create(C.byref(desc), device, C.byref(h)))
         self.handle = h
         self._ws: Optional[torch.Tensor] = None
-        self._ws_key: Optional[Tuple[int, int, int]] = None
+        self._slots: Dict[int, torch.Tensor] = {}     # one workspace per in-flight batch (stream slot)
 
     def close(self) -> None:
         if getattr(self, "handle", None):
@@ -192,13 +192,16 @@ class Engine:
             pass
 
     # ---- workspace ----
-    def workspace(self, B: int, H: int, W: int) -> torch.Tensor:
+    def workspace(self, B: int, H: int, W: int, slot: int = 0) -> torch.Tensor:
+        """Workspace of in-flight batch ``slot``: batches issued on different streams must not share one."""
         n = C.c_size_t()
         _check(self.lib.aq_engine_workspace_bytes(self.handle, B, H, W, C.byref(n)))
-        if self._ws is None or self._ws.numel() < n.value:
-            self._ws = None
-            self._ws = torch.empty(n.value, dtype=torch.uint8, device=self.device)
-        return self._ws
+        ws = self._slots.get(slot)
+        if ws is None or ws.numel() < n.value:
+            self._slots.pop(slot, None)
+            ws = self._slots[slot] = torch.empty(n.value, dtype=torch.uint8, device=self.device)
+        self._ws = ws
+        return ws
 
     def num_candidates(self, H: int, W: int) -> int:
         return _spec.num_candidates(H, W, self.ck.na)
@@ -211,10 +214,12 @@ class Engine:
 
     # ---- S1 + S2 ----
     def infer(self, tiles: torch.Tensor, conf_thres: float = 0.25, iou_thres: float = 0.45, max_det: int = 1000,
-              out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """uint8 [B,H,W,3] -> (dets float32 [B,max_det,6] = x1,y1,x2,y2,conf,cls ; counts int32 [B])."""
+              out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, slot: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+        """uint8 [B,H,W,3] -> (dets float32 [B,max_det,6] = x1,y1,x2,y2,conf,cls ; counts int32 [B]).
+        Work is enqueued on torch's current stream; ``slot`` selects the workspace (use one slot per stream when
+        several batches are in flight)."""
         B, H, W = self._check_tiles(tiles)
-        ws = self.workspace(B, H, W)
+        ws = self.workspace(B, H, W, slot)
         if out is None:
             dets = torch.empty((B, max_det, 6), dtype=torch.float32, device=self.device)
             counts = torch.empty((B,), dtype=torch.int32, device=self.device)

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-AQ_DIST_BACKEND=gloo timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 1 2>&1 | grep -v Warning | tail -3 | cut -c1-600
+python bench.py 2>/dev/null | tee gpurun_out/bench_default.json | cut -c1-1500

@@ -98,7 +98,7 @@ def main():
     # kernel sequence of one step: one per op, the SPPF pool op launches 3 kernels
     seq = []
     for i, o in enumerate(plan.ops):
-        seq += [i] * (3 if o.kind == spec.OP_SPPF_POOL else (2 if o.kind == spec.OP_DECODE else 1))   # decode = memset + kernel
+        seq += [i] * (2 if o.kind == spec.OP_DECODE else 1)   # decode = memset + kernel (SPPF pools are one fused launch at 640 px)
     if "stats" in a.groups:
         a.groups = [g for g in a.groups if g != "stats"]
         sd = run_stats(a.out, a.batch)
@@ -109,10 +109,10 @@ def main():
                 for row in csv.DictReader(f):
                     disp.append({"name": row["Kernel_Name"], "dur": int(row["End_Timestamp"]) - int(row["Start_Timestamp"]), "start": int(row["Start_Timestamp"])})
             disp.sort(key=lambda d: d["start"])
-            st = steps_of(disp, len(seq))[-20:]          # the 20 timed steps (warm-up and autotune-free)
+            st = steps_of(disp, len(seq))[-10:]          # the 10 single-stream steps of bench.py's roofline pass (the last ones)
             idx3 = [i for i, o in enumerate(plan.ops) if o.kind == spec.OP_CONV and o.meta.get("class") == "conv3x3"]
             durs = [d["dur"] for step in st for pos, d in enumerate(step) if seq[pos] in idx3]
-            summ = {"steps": len(st), "conv3x3_launches": len(durs), "conv3x3_avg_launch_us": sum(durs) / max(len(durs), 1) / 1e3,
+            summ = {"steps": len(st), "which": "last 10 steps of the run = bench.py's single-stream roofline pass", "conv3x3_launches": len(durs), "conv3x3_avg_launch_us": sum(durs) / max(len(durs), 1) / 1e3,
                     "conv3x3_ms_per_step": sum(durs) / max(len(st), 1) / 1e6,
                     "all_kernels_ms_per_step": sum(d["dur"] for step in st for d in step) / max(len(st), 1) / 1e6}
             with open(os.path.join(a.out, "stats_summary.json"), "w") as f:
