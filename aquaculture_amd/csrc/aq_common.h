@@ -59,6 +59,7 @@ struct ConvParams {
     int act;
     int n_tiles_m, n_tiles_n;
     int bias_n;          // bias entries staged into LDS (filled by aq_launch_conv)
+    unsigned long long* debug;   // diagnostic (stamped) builds only: per-wave phase cycle sums
     int halo, xrows, nixr, xper;   // conv_halo.hip: W + 1, region rows in LDS, region rows / 8, loads per step part
     float inv_hw, inv_wo;        // reciprocals for division-free pixel decode (filled by aq_launch_conv)
     unsigned magic_G, magic_k, magic_ntm;   // floor(2^32 / d) + 1
@@ -68,6 +69,7 @@ int aq_launch_conv(const ConvParams& p, int precision, int out_f32, int cfg, hip
 int aq_conv_pick_config(int cout, int npix, int precision);
 int aq_launch_conv_halo(const ConvParams& p, int precision, int out_f32, int hcfg, hipStream_t stream);
 int aq_conv_halo_num_configs();
+unsigned long long* aq_stamp_buffer(size_t* bytes);
 int aq_conv_halo_tiles(int hcfg, int* bm, int* bn);
 extern "C" int aq_conv_config_tiles(int cfg, int* bm, int* bn);
 extern "C" int aq_conv_num_configs(void);

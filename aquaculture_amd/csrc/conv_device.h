@@ -54,13 +54,29 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, f32x16 (&acc
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cl = 8 * g + 4 * h;
+                if (cblk + 8 * g >= p.cout) continue;          // padding rows of the last M block: nothing to compute
                 const f32x4 bv = *(const f32x4*)(sbias + cblk + cl);
                 f32x4 v;
+                if constexpr (F32) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[i][j][4 * g + e] + bv[e];
-                    if (p.act) t = silu<F32>(t);
-                    v[e] = t;
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[i][j][4 * g + e] + bv[e];
+                        if (p.act) t = silu<true>(t);
+                        v[e] = t;
+                    }
+                } else {
+                    // bf16 mode: bias add, exp argument, 1 + e and the final product as packed 2 x fp32 ops
+                    const f32x4 a4 = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    v = a4 + bv;
+                    if (p.act) {
+                        const f32x4 t = v * -1.44269504f;
+                        f32x4 d = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]),
+                                   __builtin_amdgcn_exp2f(t[3])};
+                        d = d + 1.0f;
+                        const f32x4 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]),
+                                         __builtin_amdgcn_rcpf(d[3])};
+                        v = v * r;
+                    }
                 }
                 *(f32x4*)(stg + l31 * kStgRow + cl * 4) = v;
             }

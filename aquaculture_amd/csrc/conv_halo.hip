@@ -20,7 +20,7 @@ using namespace aqdev;
 
 namespace {
 
-template <bool F32, int BM, int BN, int WM, int WN>
+template <bool F32, int BM, int BN, int WM, int WN, bool STAMP = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) void conv3x3_halo_kernel(const ConvParams p) {
     constexpr int NW = WM * WN;
     constexpr int ROWB = 128;
@@ -37,6 +37,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) v
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long ph_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic build only (STAMP), see conv_igemm.hip
+    unsigned long long ph_t = 0;
+    if constexpr (STAMP) ph_t = clock64();
+    auto stamp = [&](int ph) {
+        if constexpr (STAMP) {
+            const unsigned long long t = clock64();
+            ph_sum[ph] += t - ph_t;
+            ph_t = t;
+        }
+    };
     const int G = gridDim.x;
     int tile = first_tile(G, blockIdx.x);
     const int ntiles = p.n_tiles_m * p.n_tiles_n;
@@ -191,6 +201,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) v
     wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    stamp(0);
 
     int wsel = 0, xsel = 0;
     while (true) {
@@ -205,6 +216,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) v
         const bool has_next = next_tile < ntiles;
         int m0n = 0, n0n = 0;
         if (has_next) tile_origin(next_tile, m0n, n0n);
+        stamp(1);
 
         for (int cc = 0; cc < CC; ++cc) {
             const bool last_chunk = (cc + 1 == CC);
@@ -220,10 +232,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) v
                 compute(wptr(wsel), xptr(xsel), tap, cc, nws, wptr(wsel ^ 1), tap < 8 && next_chunk_exists, nc_n0, nc_cc, tap,
                         xptr(xsel ^ 1));
                 const int nx = nx_issued;
+                if constexpr (STAMP) asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
+                stamp(2);
                 if (!(last_chunk && tap == 8)) {
                     wait_n(nx);
+                    stamp(3);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
+                    stamp(4);
                 }
                 wsel ^= 1;
             }
@@ -232,13 +248,20 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) v
         // every wave is done with the last slices -> the just-consumed buffer becomes the epilogue staging area
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        stamp(5);
         char* region = STAGE_IN_W ? wptr(wsel ^ 1) : xptr(xsel ^ 1);
         epilogue_store<F32, F32, TM, TN>(p, acc, region + wave * kStgBytes, sbias, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+        stamp(6);
         if (!has_next) break;
         wait_vmcnt<NSTORE>();                 // next tile's first weight slice (and all of its first region) has landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        stamp(7);
         tile = next_tile; m0 = m0n; n0 = n0n;
+    }
+    if constexpr (STAMP) {
+        if (lane == 0 && p.debug)
+            for (int i = 0; i < 8; ++i) p.debug[((long long)blockIdx.x * NW + wave) * 8 + i] = ph_sum[i];
     }
 }
 
@@ -318,6 +341,16 @@ int aq_launch_conv_halo(const ConvParams& p_in, int precision, int out_f32, int 
     long long grid = g_halo_cus;          // > 80 KiB of LDS per workgroup: one resident workgroup per CU
     if (lds <= 80 * 1024) grid *= 2;
     if (grid > ntiles) grid = ntiles;
+    size_t sbytes = 0;
+    unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
+    if (sbuf && variant == 0 && hcfg == 0 && (size_t)grid * nw * 64 <= sbytes) {
+        auto sfn = conv3x3_halo_kernel<false, 192, 256, 2, 4, true>;
+        AQ_CHECK_HIP(hipFuncSetAttribute((const void*)sfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        p.debug = sbuf;
+        hipLaunchKernelGGL(sfn, dim3((unsigned)grid), dim3(k.threads), lds, stream, p);
+        AQ_CHECK_HIP(hipGetLastError());
+        return AQ_OK;
+    }
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(k.threads), lds, stream, p);
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;

@@ -64,7 +64,7 @@ constexpr int conv_min_waves(int bm, int bn, int nw, int nstage) {
     return w > 8 ? 8 : w;
 }
 
-template <bool F32, int BM, int BN, int WM, int WN, bool OUT_F32, int NSTAGE, bool BIAS_LDS>
+template <bool F32, int BM, int BN, int WM, int WN, bool OUT_F32, int NSTAGE, bool BIAS_LDS, bool STAMP = false>
 __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAGE)) void conv_igemm_kernel(const ConvParams p) {
     constexpr int NW = WM * WN;
     static_assert(NSTAGE == 2 || NSTAGE == 3, "pipeline depth");
@@ -89,6 +89,18 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // diagnostic build only (STAMP): per-wave cycle sums of 8 phases -> p.debug (tools/stamp_conv.py); the shipped
+    // kernels contain no stamp
+    unsigned long long ph_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ph_t = 0;
+    if constexpr (STAMP) ph_t = clock64();
+    auto stamp = [&](int ph) {
+        if constexpr (STAMP) {
+            const unsigned long long t = clock64();
+            ph_sum[ph] += t - ph_t;
+            ph_t = t;
+        }
+    };
 
     // Persistent workgroups: block w handles tiles w, w + G, w + 2G, ...  The XCD-aware, bijective remap gives the
     // blocks that share an XCD (same blockIdx % 8) consecutive w, so at any moment one L2 serves neighbouring pixel
@@ -128,14 +140,27 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
         m0 = tile_m * BM;
         n0 = tile_n * BN;
         wsrc = p.w + ((long long)(m0 + 8 * wave + lrow) * p.kgroups_pad + gs) * 16;
-        // pixel -> (b, y, x) without integer division: npix < 2^24 (checked on the host) so P is exact in fp32 and
-        // a reciprocal multiply is off by at most one, which the remainder test repairs.
+        if (p.k == 1 && p.stride == 1 && p.pad == 0) {
+            // 1x1 / stride 1: the input pixel IS the output pixel and no tap can fall outside the image
 #pragma unroll
-        for (int j = 0; j < JX; ++j) {
-            const int r = 8 * (wave + NW * j) + lrow;
-            const int P = n0 + r;
-            unsigned mask = 0;
-            long long base = 0;
+            for (int j = 0; j < JX; ++j) {
+                const int P = n0 + 8 * (wave + NW * j) + lrow;
+                xbase[j] = (long long)P * p.in_ld_b;
+                xmask[j] = P < p.npix ? 1u : 0u;
+            }
+            return;
+        }
+        // General case.  The 8 lanes that load one pixel row (same lrow) need the same (base, mask); each of them
+        // decodes ONE of the lane's JX pixels (lane with slot j decodes pixel j) and the results are exchanged inside
+        // the 8-lane group with ds_bpermute: one decode per lane per tile instead of JX.
+        // pixel -> (b, y, x) without integer division: npix < 2^24 (checked on the host) so P is exact in fp32 and a
+        // reciprocal multiply is off by at most one, which the remainder test repairs.
+        static_assert(JX <= 8, "one decode per lane needs JX <= 8");
+        unsigned my_mask = 0;
+        long long my_base = 0;
+        {
+            const int j = lslot < JX ? lslot : 0;
+            const int P = n0 + 8 * (wave + NW * j) + lrow;
             if (P < p.npix) {
                 int b = (int)((float)P * p.inv_hw);
                 int rem = P - b * hw;
@@ -144,22 +169,28 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
                 int x = rem - y * p.Wo;
                 if (x < 0) { --y; x += p.Wo; } else if (x >= p.Wo) { ++y; x -= p.Wo; }
                 const int iy0 = y * p.stride - p.pad, ix0 = x * p.stride - p.pad;
-                base = ((long long)(b * p.H + iy0) * p.W + ix0) * p.in_ld_b;
+                my_base = ((long long)(b * p.H + iy0) * p.W + ix0) * p.in_ld_b;
                 // tap mask = (valid rows) x (valid columns), k bits each
                 unsigned colbits = 0;
                 for (int kx = 0; kx < p.k; ++kx) colbits |= (unsigned)((unsigned)(ix0 + kx) < (unsigned)p.W) << kx;
                 for (int ky = 0; ky < p.k; ++ky)
-                    if ((unsigned)(iy0 + ky) < (unsigned)p.H) mask |= colbits << (ky * p.k);
+                    if ((unsigned)(iy0 + ky) < (unsigned)p.H) my_mask |= colbits << (ky * p.k);
             }
-            xbase[j] = base;
-            xmask[j] = mask;
+        }
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+            const int srcl = (lane & ~7) | j;
+            const unsigned lo = (unsigned)__shfl((int)(unsigned)(my_base & 0xffffffffll), srcl);
+            const unsigned hi = (unsigned)__shfl((int)(my_base >> 32), srcl);
+            xbase[j] = (long long)(((unsigned long long)hi << 32) | lo);
+            xmask[j] = (unsigned)__shfl((int)my_mask, srcl);
         }
     };
 
     // Staging of one (tile, chunk) step is split into NL = JW + JX single-instruction slots so that the slots can be
     // issued BETWEEN the MFMA bursts of the step being computed (LDS-DMA issue is ~100 cycles per instruction; issued
     // up front by every wave at once it would leave the matrix pipe idle after each barrier).
-    struct StageCtx { bool active; char* buf; long long wofs; int tap; long long tapoff; bool kvalid; };
+    struct StageCtx { bool active; char* buf; int wofs; int tap; int tapoff; bool kvalid; };
     constexpr int NL = JW + JX;
     auto stage_slot = [&](const StageCtx& c, int i) {
         if (!c.active) return;
@@ -173,16 +204,27 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
             glds16(src, c.buf + BM * ROWB + (wave + NW * j) * 1024);
         }
     };
+    // This lane's source group walks the flattened K axis 8 groups per chunk; (tap, ky, kx, channel group) advance by
+    // add/compare only (no division per step).  Offsets fit 32 bits: |tap offset| <= (k*W) * pixel stride.
+    int k_tap = 0, k_cg = 0, k_ky = 0, k_kx = 0;
     auto stage_ctx = [&](int chunk, char* buf) -> StageCtx {
+        if (chunk == 0) {
+            k_tap = p.G == 1 ? gs : (int)__umulhi((unsigned)gs, p.magic_G);
+            k_cg = gs - k_tap * p.G;
+            k_ky = p.k == 1 ? k_tap : (int)__umulhi((unsigned)k_tap, p.magic_k);
+            k_kx = k_tap - k_ky * p.k;
+        } else {
+            k_cg += 8;
+            while (k_cg >= p.G) {
+                k_cg -= p.G; ++k_tap;
+                if (++k_kx == p.k) { k_kx = 0; ++k_ky; }
+            }
+        }
         StageCtx c;
-        c.active = true; c.buf = buf; c.wofs = (long long)chunk * 128;
-        const int kg = chunk * 8 + gs;
-        c.tap = p.G == 1 ? kg : (int)__umulhi((unsigned)kg, p.magic_G);   // kg / G (exact: kg, G < 2^15)
-        const int cg = kg - c.tap * p.G;
-        const int ky = p.k == 1 ? c.tap : (int)__umulhi((unsigned)c.tap, p.magic_k);  // tap / k
-        const int kx = c.tap - ky * p.k;
-        c.tapoff = (long long)(ky * p.W + kx) * p.in_ld_b + cg * 16;
-        c.kvalid = kg < p.kgroups;
+        c.active = true; c.buf = buf; c.wofs = chunk * 128;
+        c.tap = k_tap;
+        c.tapoff = (k_ky * p.W + k_kx) * p.in_ld_b + k_cg * 16;
+        c.kvalid = chunk * 8 + gs < p.kgroups;
         return c;
     };
 
@@ -194,34 +236,36 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
     const int b_off = BM * ROWB + (wn * (BN / WN) + l31) * ROWB;
     f32x16 acc[TM][TN];
 
+    // Fragment reads are software-pipelined: the ds_read_b128s of k-step ks+1 are issued before the MFMAs of k-step ks
+    // (second register set), so the matrix pipe does not wait on LDS latency between k-steps.
     auto compute = [&](const char* buf, const StageCtx& nx) {
+        using frag_t = typename std::conditional<F32, f32x4, bf16x8>::type;
+        frag_t a[2][TM], b[2][TN];
+        auto load_frags = [&](int ks, frag_t (&fa)[TM], frag_t (&fb)[TN]) {
+            const int so = (((2 * ks + h) ^ sw) << 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *(const frag_t*)(buf + a_off + i * 32 * ROWB + so);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *(const frag_t*)(buf + b_off + j * 32 * ROWB + so);
+        };
+        load_frags(0, a[0], b[0]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int so = (((2 * ks + h) ^ sw) << 4);
+            if (ks + 1 < 4) load_frags(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
             if constexpr (!F32) {
-                bf16x8 a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8*)(buf + a_off + i * 32 * ROWB + so);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8*)(buf + b_off + j * 32 * ROWB + so);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
             } else {
-                f32x4 a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(buf + a_off + i * 32 * ROWB + so);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(buf + b_off + j * 32 * ROWB + so);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks & 1][i][e], b[ks & 1][j][e], acc[i][j], 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < NL; ++i)
@@ -247,13 +291,29 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int cl = 8 * g + 4 * h;
+                    if (cblk + 8 * g >= p.cout) continue;      // padding rows of the last M block: nothing to compute
                     const f32x4 bv = *(const f32x4*)(sbias + cblk + cl);
                     f32x4 v;
+                    if constexpr (F32) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float t = acc[i][j][4 * g + e] + bv[e];
-                        if (p.act) t = silu<F32>(t);
-                        v[e] = t;
+                        for (int e = 0; e < 4; ++e) {
+                            float t = acc[i][j][4 * g + e] + bv[e];
+                            if (p.act) t = silu<true>(t);
+                            v[e] = t;
+                        }
+                    } else {
+                        // bf16 mode: bias add, exp argument, 1 + e and the final product as packed 2 x fp32 ops
+                        const f32x4 a4 = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        v = a4 + bv;
+                        if (p.act) {
+                            const f32x4 t = v * -1.44269504f;
+                            f32x4 d = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]),
+                                       __builtin_amdgcn_exp2f(t[3])};
+                            d = d + 1.0f;
+                            const f32x4 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]),
+                                             __builtin_amdgcn_rcpf(d[3])};
+                            v = v * r;
+                        }
                     }
                     *(f32x4*)(stg + l31 * SROW + cl * 4) = v;
                 }
@@ -339,6 +399,7 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
     }
     wait_step(0, Tag0{});
     __builtin_amdgcn_s_barrier();
+    stamp(0);
     int step = 0;
     for (; tile < ntiles; tile += G) {
 #pragma unroll
@@ -351,22 +412,34 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
         for (int c = 0; c < p.nchunks; ++c, ++step) {
             cur = smem + (step % NSTAGE) * BUF;
             const StageCtx nx = stage_begin();             // step + NSTAGE - 1 (its buffer was freed by the last barrier)
+            stamp(1);
             compute(cur, nx);                              // ... loaded in slices between this step's MFMA bursts
+            if constexpr (STAMP) asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
+            stamp(2);
             if (c + 1 < p.nchunks) {
                 wait_step(step + 1, Tag0{});
+                stamp(3);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+                stamp(4);
             }
         }
         // every wave is done reading `cur` -> it becomes the epilogue staging area (raw barrier: no vmcnt drain)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        stamp(5);
         const int tile_n = p.n_tiles_m == 1 ? tile : (int)__umulhi((unsigned)tile, p.magic_ntm);
         epilogue(cur, (tile - tile_n * p.n_tiles_m) * BM, tile_n * BN);
+        stamp(6);
         if (tile + G >= ntiles) break;
         wait_step(step, TagS{});                           // the next tile's first chunk has landed (this wave's part)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // ... and everyone's part; staging reads are finished too
+        stamp(7);
+    }
+    if constexpr (STAMP) {
+        if (lane == 0 && p.debug)
+            for (int i = 0; i < 8; ++i) p.debug[((long long)blockIdx.x * NW + wave) * 8 + i] = ph_sum[i];
     }
 }
 
@@ -405,6 +478,17 @@ const ConvConfig kConfigs[] = {
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
+// diagnostic (stamped) builds of a few shapes, bf16 only: used when aq_debug_conv_stamp() armed a buffer
+struct StampedKernel { int cfg; void (*fn)(const ConvParams); };
+const StampedKernel kStamped[] = {
+    {1, conv_igemm_kernel<false, 192, 256, 2, 4, false, 2, true, true>},
+    {6, conv_igemm_kernel<false, 192, 128, 2, 4, false, 2, false, true>},
+    {7, conv_igemm_kernel<false, 128, 128, 2, 2, false, 2, true, true>},
+    {10, conv_igemm_kernel<false, 64, 128, 1, 4, false, 2, true, true>},
+};
+unsigned long long* g_stamp_buf = nullptr;
+size_t g_stamp_bytes = 0;
+
 // dynamic LDS: NSTAGE K-chunk buffers (the epilogue staging lives inside the just-consumed one)
 size_t conv_lds_bytes(const ConvConfig& k, int bias_n) { return (size_t)k.nstage * (k.bm + k.bn) * 128 + (k.bias_lds ? (size_t)bias_n * 4 : 0); }
 bool g_attr_set[kNumConfigs][3];
@@ -415,6 +499,13 @@ int g_num_cus = 0;
 }  // namespace
 
 // one index space for tuning: [0, kNumConfigs) = implicit-GEMM tiles, then the halo-reuse 3x3 kernel's tiles
+unsigned long long* aq_stamp_buffer(size_t* bytes) { if (bytes) *bytes = g_stamp_bytes; return g_stamp_buf; }
+extern "C" int aq_debug_conv_stamp(void* buf_dev, size_t bytes) {
+    g_stamp_buf = (unsigned long long*)buf_dev;
+    g_stamp_bytes = buf_dev ? bytes : 0;
+    return AQ_OK;
+}
+
 extern "C" int aq_conv_num_configs(void) { return kNumConfigs + aq_conv_halo_num_configs(); }
 
 extern "C" int aq_conv_config_tiles(int cfg, int* bm, int* bn) {
@@ -497,6 +588,16 @@ int aq_launch_conv(const ConvParams& p_in, int precision, int out_f32, int cfg, 
     }
     long long grid = (long long)g_num_cus * blocks;
     if (grid > ntiles) grid = ntiles;
+    if (g_stamp_buf && variant == 0) {
+        for (const StampedKernel& sk : kStamped)
+            if (sk.cfg == cfg && (size_t)grid * (k.threads / 64) * 64 <= g_stamp_bytes) {
+                AQ_CHECK_HIP(hipFuncSetAttribute((const void*)sk.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                p.debug = g_stamp_buf;
+                hipLaunchKernelGGL(sk.fn, dim3((unsigned)grid), dim3(k.threads), lds, stream, p);
+                AQ_CHECK_HIP(hipGetLastError());
+                return AQ_OK;
+            }
+    }
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(k.threads), lds, stream, p);
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;

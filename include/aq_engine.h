@@ -123,6 +123,9 @@ int aq_engine_autotune(aq_engine* e, const uint8_t* tiles_dev, int B, int H, int
                        void* workspace_dev, size_t workspace_bytes, int reps, void* stream);
 int aq_engine_get_conv_config(aq_engine* e, int op);
 int aq_conv_num_configs(void);
+/* Diagnostics: arm (buf != NULL) or disarm a device buffer that the STAMPED builds of a few conv tile shapes fill with
+ * per-wave phase cycle sums (8 x uint64 per wave); used by tools/stamp_conv.py only. */
+int aq_debug_conv_stamp(void* buf_dev, size_t bytes);
 int aq_conv_config_tiles(int cfg, int* bm, int* bn);
 
 /* ---- individual kernels --------------------------------------------------------------- */
