@@ -45,6 +45,22 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, f32x16 (&acc
                                                int lane) {
     const int h = lane >> 5, l31 = lane & 31;
     const int pix = lane >> 2, ch = lane & 3;
+    // bf16 shortcut layers: fetch the whole residual tile of this wave up front (TM*TN*2 x 16 B per lane), so the
+    // per-block loop below never waits on a global load
+    uint4 rpre[TM][TN][2];
+    const bool pre = !F32 && p.res != nullptr;
+    if (pre) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int P = pwave + j * 32 + pix + 16 * it, c0 = cwave + i * 32 + ch * 8;
+                    rpre[i][j][it] = (P < p.npix && c0 < p.cout) ? *(const uint4*)(p.res + (long long)P * p.res_ld_b + c0 * 2)
+                                                                  : make_uint4(0, 0, 0, 0);
+                }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int pbase = pwave + j * 32;
@@ -99,7 +115,7 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, f32x16 (&acc
                             for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
                         }
                     } else if (p.res) {
-                        const uint4 rv = *(const uint4*)(p.res + (long long)P * p.res_ld_b + c0 * 2);
+                        const uint4 rv = rpre[i][j][it];
                         const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {

@@ -282,6 +282,20 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
         char* stg = region + wave * STG;
         const int cwave = m0 + wm * (BM / WM);
         const int pix = lane >> 2, ch = lane & 3;            // item = lane (+64): pixel, 8-channel chunk
+        // bf16 shortcut layers: fetch the whole residual tile of this wave up front (TM*TN*2 x 16 B per lane)
+        uint4 rpre[TM][TN][2];
+        if (!F32 && p.res) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int P = n0 + wn * (BN / WN) + j * 32 + pix + 16 * it, c0 = cwave + i * 32 + ch * 8;
+                        rpre[i][j][it] = (P < p.npix && c0 < p.cout) ? *(const uint4*)(p.res + (long long)P * p.res_ld_b + c0 * 2)
+                                                                      : make_uint4(0, 0, 0, 0);
+                    }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int pbase = n0 + wn * (BN / WN) + j * 32;
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
                                 for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
                             }
                         } else if (p.res) {
-                            const uint4 rv = *(const uint4*)(p.res + (long long)P * p.res_ld_b + c0 * 2);
+                            const uint4 rv = rpre[i][j][it];
                             const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
