@@ -140,6 +140,34 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const char* __restrict_
     }
 }
 
+// [UPSTREAM utils/augmentations.py letterbox -> cv2.resize(INTER_LINEAR) + copyMakeBorder(114)] on uint8 RGB tiles.
+// OpenCV's 8-bit bilinear kernel in fixed point (11-bit coefficients): horizontal pass in int (scale 2^11), vertical pass
+// ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.  The coefficient tables (source index pair + weights per
+// destination column / row) are built on the host exactly as resize.cpp does (float32 fractions, cvRound) and passed in.
+__global__ __launch_bounds__(256) void letterbox_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                          const int4* __restrict__ xtab, const int4* __restrict__ ytab,
+                                                          int B, int H0, int W0, int H, int W, int new_w, int new_h, int top, int left) {
+    const unsigned n = (unsigned)B * H * W;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned t = i / (unsigned)W;
+        const int x = (int)(i - t * W);
+        const int b = (int)(t / (unsigned)H), y = (int)(t - (unsigned)b * H);
+        uint8_t* o = dst + (size_t)i * 3;
+        const int yy = y - top, xx = x - left;
+        if (yy < 0 || yy >= new_h || xx < 0 || xx >= new_w) { o[0] = o[1] = o[2] = 114; continue; }
+        const int4 xt = xtab[xx], yt = ytab[yy];        // (i0, i1, w0, w1)
+        const uint8_t* r0 = src + ((size_t)b * H0 + yt.x) * W0 * 3;
+        const uint8_t* r1 = src + ((size_t)b * H0 + yt.y) * W0 * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int h0 = r0[xt.x * 3 + c] * xt.z + r0[xt.y * 3 + c] * xt.w;
+            const int h1 = r1[xt.x * 3 + c] * xt.z + r1[xt.y * 3 + c] * xt.w;
+            int v = (((yt.z * (h0 >> 4)) >> 16) + ((yt.w * (h1 >> 4)) >> 16) + 2) >> 2;
+            o[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
 inline unsigned grid_for(long long n, int block) {
     long long g = (n + block - 1) / block;
     const long long cap = 256 * 16;   // 256 CUs x 16 blocks, grid-stride the rest
@@ -203,6 +231,19 @@ extern "C" int aq_upsample2x(const void* in_dev, int in_ld, int in_choff, void* 
     hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const char*)in_dev + (long long)in_choff * eb, in_ld * eb,
                        (char*)out_dev + (long long)out_choff * eb, out_ld * eb, groups, B, H, W);
+    AQ_CHECK_HIP(hipGetLastError());
+    return AQ_OK;
+}
+
+extern "C" int aq_letterbox_u8(const uint8_t* src_dev, int B, int H0, int W0, uint8_t* dst_dev, int H, int W, int new_w, int new_h,
+                               int top, int left, const int32_t* xtab_dev, const int32_t* ytab_dev, void* stream) {
+    AQ_REQUIRE(src_dev && dst_dev && xtab_dev && ytab_dev, "letterbox: null pointer");
+    AQ_REQUIRE(B > 0 && H0 > 0 && W0 > 0 && H > 0 && W > 0 && new_w > 0 && new_h > 0 && top >= 0 && left >= 0 &&
+               top + new_h <= H && left + new_w <= W, "letterbox: bad geometry");
+    const long long n = (long long)B * H * W;
+    AQ_REQUIRE(n < (1LL << 31), "letterbox: batch too large");
+    hipLaunchKernelGGL(letterbox_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, src_dev, dst_dev,
+                       (const int4*)xtab_dev, (const int4*)ytab_dev, B, H0, W0, H, W, new_w, new_h, top, left);
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;
 }

@@ -116,7 +116,10 @@ class LoadImages:
     """Iterates (path, letterboxed uint8 HWC RGB, original (h, w)) in sorted order; ``shard`` = (rank, world)
     keeps images ``i % world == rank`` (strided tile shard, one process per GPU)."""
 
-    def __init__(self, source: str, img_size=640, stride=32, auto=True, shard: Tuple[int, int] = (0, 1), workers: int = 8):
+    def __init__(self, source: str, img_size=640, stride=32, auto=True, shard: Tuple[int, int] = (0, 1), workers: int = 8,
+                 raw: bool = False):
+        """``raw``: yield the decoded image as is (the caller letterboxes on the device)."""
+        self.raw = raw
         files = list_images(source)
         self.total = len(files)
         rank, world = shard
@@ -131,6 +134,8 @@ class LoadImages:
 
     def load(self, path: str):
         im0 = read_rgb(path)
+        if self.raw:
+            return path, np.ascontiguousarray(im0), im0.shape[:2]
         return path, letterbox(im0, self.img_size, self.auto, True, self.stride), im0.shape[:2]
 
     def __iter__(self) -> Iterator[Tuple[str, np.ndarray, Tuple[int, int]]]:

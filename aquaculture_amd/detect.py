@@ -90,7 +90,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         save_txt=False, save_conf=False, nosave=False, classes=None, agnostic_nms=False,
         project="runs/detect", name="exp", exist_ok=False, half=False, batch_size=64, precision=None,
         workers=8, log=print, **unsupported):
-    from .engine import Engine   # raises if the HIP library or the GPU is missing: there is no fallback
+    from .engine import Engine, letterbox_device   # raises if the HIP library or the GPU is missing: there is no fallback
 
     for k in UNSUPPORTED:
         if unsupported.get(k):
@@ -119,7 +119,8 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     ck = load_checkpoint(weights)
     eng = Engine(ck, precision, dev)
     imgsz = check_img_size(list(imgsz), s=int(max(ck.stride)))
-    dataset = LoadImages(source, img_size=imgsz, stride=int(max(ck.stride)), auto=True, shard=(rank, world), workers=workers)
+    # decoded images go to the GPU as they are; the letterbox (resize INTER_LINEAR + pad 114) runs on the device
+    dataset = LoadImages(source, img_size=imgsz, stride=int(max(ck.stride)), auto=True, shard=(rank, world), workers=workers, raw=True)
 
     copy_stream = torch.cuda.Stream()
     seen, n_labels, n_dets = 0, 0, 0
@@ -133,12 +134,13 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         with torch.cuda.stream(copy_stream):
             tiles = host.to(dev, non_blocking=True)
         torch.cuda.current_stream().wait_stream(copy_stream)
+        tiles = letterbox_device(tiles, tuple(imgsz), int(max(ck.stride)), True)
         t1 = time.perf_counter()
         dets, counts = eng.infer(tiles, conf_thres, iou_thres, max_det)
         counts_h = counts.cpu().numpy()
         dets_h = dets[:, : int(counts_h.max(initial=0))].cpu().numpy() if counts_h.size else dets.cpu().numpy()
         t2 = time.perf_counter()
-        H, W = batch.shape[1:3]
+        H, W = int(tiles.shape[1]), int(tiles.shape[2])
         shape_str = f"(1, 3, {H}, {W})"
         for b, p in enumerate(paths):
             seen += 1

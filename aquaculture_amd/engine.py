@@ -64,7 +64,7 @@ EXPORTS = (
     "aq_engine_op_times", "aq_engine_num_ops", "aq_engine_set_conv_config", "aq_engine_autotune",
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp",
     "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_preprocess_s2d", "aq_sppf_pool",
-    "aq_upsample2x", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
+    "aq_upsample2x", "aq_letterbox_u8", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
 
 _lib = None
@@ -102,6 +102,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_preprocess_s2d.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.aq_sppf_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.aq_upsample2x.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.aq_letterbox_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.aq_detect_decode.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32),
                                      vp, f32, vp, vp, vp, i32, vp]
     lib.aq_nms_scratch_bytes.argtypes = [i32, i32]
@@ -374,4 +375,29 @@ def conv2d_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, strid
             else:
                 os.environ["AQ_CONV_CFG"] = old
     torch.cuda.current_stream().synchronize()   # wbuf/bbuf are freed on return
+    return out
+
+
+_lb_tables: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor, Tuple[int, int, int, int, int, int]]] = {}
+
+
+def letterbox_device(tiles0: torch.Tensor, new_shape=(640, 640), stride: int = 32, auto: bool = True) -> torch.Tensor:
+    """uint8 CUDA [B,H0,W0,3] original tiles -> letterboxed uint8 [B,H,W,3] on the device (aq_letterbox_u8).
+    Geometry and coefficient tables come from dataloader.letterbox_geometry / resize tables (host, cached per shape)."""
+    from . import dataloader
+    _require_gpu()
+    lib = load_library()
+    assert tiles0.is_cuda and tiles0.dtype == torch.uint8 and tiles0.dim() == 4 and tiles0.shape[3] == 3 and tiles0.is_contiguous()
+    B, H0, W0, _ = tiles0.shape
+    key = (H0, W0, tuple(new_shape), stride, auto, tiles0.device.index)
+    if key not in _lb_tables:
+        (nw, nh), (top, bottom, left, right) = dataloader.letterbox_geometry((H0, W0), new_shape, auto, True, stride)
+        xt = np.stack(dataloader._axis_coeffs(W0, nw), 1).astype(np.int32)
+        yt = np.stack(dataloader._axis_coeffs(H0, nh), 1).astype(np.int32)
+        _lb_tables[key] = (torch.from_numpy(xt).to(tiles0.device), torch.from_numpy(yt).to(tiles0.device),
+                           (nw, nh, top, left, nh + top + bottom, nw + left + right))
+    xt, yt, (nw, nh, top, left, H, W) = _lb_tables[key]
+    out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=tiles0.device)
+    _check(lib.aq_letterbox_u8(tiles0.data_ptr(), B, H0, W0, out.data_ptr(), H, W, nw, nh, top, left,
+                               xt.data_ptr(), yt.data_ptr(), _stream_ptr()))
     return out

@@ -145,6 +145,12 @@ int aq_conv2d(const void* in_dev, int in_ld, int in_choff, int cin,
               int precision, int out_f32, const void* zero_page_dev, void* stream);
 /* uint8 RGB NHWC -> 2x2 space-to-depth, 16 channels, value/255 ([UPSTREAM detect.py: im.float()/255]). */
 int aq_preprocess_s2d(const uint8_t* tiles_dev, void* out_dev, int B, int H, int W, int precision, void* stream);
+/* Letterbox on device (the real 1024x1024 tiles of reference src/load_data/tile_tifs.py:13 -> 640x640):
+ * [UPSTREAM utils/augmentations.py letterbox] = cv2.resize(INTER_LINEAR) to (new_w, new_h) + constant border 114, uint8 RGB NHWC.
+ * xtab_dev / ytab_dev: int32 [new_w][4] / [new_h][4] rows (i0, i1, w0, w1): OpenCV's 11-bit fixed-point coefficient tables, built
+ * on the host (aquaculture_amd/dataloader.py resize tables).  UNPINNED: no OpenCV is available to check against. */
+int aq_letterbox_u8(const uint8_t* src_dev, int B, int H0, int W0, uint8_t* dst_dev, int H, int W, int new_w, int new_h,
+                    int top, int left, const int32_t* xtab_dev, const int32_t* ytab_dev, void* stream);
 /* SPPF pools: y1 = mp5(x), y2 = mp5(y1), y3 = mp5(y2) written to channel slices c, 2c, 3c of the same buffer. */
 int aq_sppf_pool(void* buf_dev, int ld, int ch_off, int c, int B, int H, int W, int precision, void* stream);
 /* nearest 2x upsample of a channel slice into a channel slice. */

@@ -81,3 +81,32 @@ def test_cli_two_ranks_write_the_same_label_set(workdir, lib):
     assert sorted(os.listdir(ref)) == sorted(os.listdir(lab))
     for f in os.listdir(ref):
         assert open(ref / f).read() == open(lab / f).read(), f
+
+
+def test_cli_on_real_size_1024_tiles(tmp_path, lib):
+    """Real tiles are 1024x1024 (reference src/load_data/tile_tifs.py:13, src/utils.py:17-19): decoded on the host,
+    letterboxed 1024 -> 640 on the device, boxes written normalised by the ORIGINAL size, as the consumer assumes
+    (reference src/process_yolo/geocode_results.py:160-163 multiplies by IM_WIDTH = 1024)."""
+    from aquaculture_amd import checkpoint, dataloader, tiles
+    from oracle import yolov5_oracle as O
+    idx = [19, 3]
+    tiles.write_synthetic_jpegs(str(tmp_path / "jpegs"), idx, size=1024)
+    checkpoint.write_synthetic_checkpoint(str(tmp_path / "multilabel_farms_synth.pt"), "yolov5m", 5)
+    out, labels = _run(tmp_path, "exp1024")
+    assert "at shape (1, 3, 640, 640)" in out
+    model = O.model_from_checkpoint(checkpoint.synthetic_checkpoint("yolov5m", 5))
+    for i in idx:
+        stem = tiles.tile_name(i)[:-5]
+        im0 = dataloader.read_rgb(str(tmp_path / "jpegs" / (stem + ".jpeg")))
+        assert im0.shape == (1024, 1024, 3)
+        want = O.label_lines(O.detect_tiles(model, dataloader.letterbox(im0)[None])[0], (640, 640), (1024, 1024))
+        got = open(labels / (stem + ".txt")).read().splitlines()
+        assert len(got) == len(want) and len(want) > 20
+        pool = {}
+        for l in got:
+            f = l.split()
+            pool.setdefault(" ".join(f[:5]), []).append(float(f[5]))
+        same = sum(any(abs(c - float(l.split()[5])) <= 1e-4 for c in pool.get(" ".join(l.split()[:5]), [])) for l in want)
+        assert same >= 0.99 * len(want)
+        arr = np.loadtxt(labels / (stem + ".txt"))
+        assert int(1024 * (arr[:, 1] + arr[:, 3] / 2).max()) <= 1024

@@ -199,3 +199,15 @@ def test_full_batch_is_batch_invariant(lib, synth_ck):
     assert torch.equal(c4, c64[:4])
     for b in range(4):
         assert torch.equal(d4[b, :c4[b]], d64[b, :c64[b]])
+
+
+@pytest.mark.parametrize("shape", [(1024, 1024), (640, 640), (500, 700), (1000, 600), (320, 480)])
+def test_device_letterbox_is_bit_exact_with_host_restatement(lib, shape):
+    """aq_letterbox_u8 vs dataloader.letterbox (numpy restatement of cv2.resize INTER_LINEAR + border 114): identical bytes.
+    (Both are unpinned against OpenCV itself: none is installed.)"""
+    from aquaculture_amd import dataloader, engine
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    ims = rng.integers(0, 256, (3,) + shape + (3,), dtype=np.uint8)
+    want = np.stack([dataloader.letterbox(im) for im in ims], 0)
+    got = engine.letterbox_device(torch.from_numpy(ims).cuda()).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
