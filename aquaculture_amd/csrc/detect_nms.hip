@@ -53,26 +53,43 @@ __device__ __forceinline__ void decode_row(const DecodeParams& p, const float* s
 // every row when the full pred tensor is requested (S1 alone), else only rows with obj > conf_thres, which go
 // to the compact candidate list that NMS reads.
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
+    // grid = (ceil(N / 256), B): one candidate per lane.  Passing candidates take a slot from an LDS counter; ONE global
+    // atomic per block reserves the block's range in the image's compact list (same-address global atomics serialise).
+    __shared__ int s_cnt, s_base;
     const int N = p.off[3];
     const int b = blockIdx.y;
-    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < N; w += gridDim.x * blockDim.x) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    bool pass = false;
+    int local = 0, n = 0, lvl = 0, a = 0, x = 0, y = 0;
+    const float* src = nullptr;
+    float obj = 0.f;
+    if (w < N) {
         int m = w;                                         // position in the pixel-major walk of this image
         const int na = p.na;
-        const int lvl = m >= p.off[2] ? 2 : (m >= p.off[1] ? 1 : 0);
+        lvl = m >= p.off[2] ? 2 : (m >= p.off[1] ? 1 : 0);
         m -= p.off[lvl];
         const int ny = p.ny[lvl], nx = p.nx[lvl];
-        const int pix = (int)((unsigned)m / (unsigned)na), a = m - pix * na;
-        const int y = (int)((unsigned)pix / (unsigned)nx), x = pix - y * nx;
-        const int n = p.off[lvl] + a * ny * nx + pix;      // upstream candidate index: a * ny * nx + y * nx + x
-        const float* src = p.head[lvl] + ((long long)(b * ny + y) * nx + x) * p.head_ld + a * p.no;
-        const float obj = sigmoidf_ref(src[4]);
+        const int pix = (int)((unsigned)m / (unsigned)na);
+        a = m - pix * na;
+        y = (int)((unsigned)pix / (unsigned)nx);
+        x = pix - y * nx;
+        n = p.off[lvl] + a * ny * nx + pix;                // upstream candidate index: a * ny * nx + y * nx + x
+        src = p.head[lvl] + ((long long)(b * ny + y) * nx + x) * p.head_ld + a * p.no;
+        obj = sigmoidf_ref(src[4]);
         if (p.pred) decode_row(p, src, lvl, a, x, y, obj, p.pred + ((long long)b * N + n) * p.no);
-        if (p.cand && obj > p.conf_thres) {
-            const int pos = atomicAdd(p.cand_count + b, 1);
-            if (pos < p.cap) {
-                p.cand[(long long)b * p.cap + pos] = n;
-                if (p.cand_rows) decode_row(p, src, lvl, a, x, y, obj, p.cand_rows + ((long long)b * p.cap + pos) * p.no);
-            }
+        pass = p.cand && obj > p.conf_thres;
+        if (pass) local = atomicAdd(&s_cnt, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt > 0) s_base = atomicAdd(p.cand_count + b, s_cnt);
+    __syncthreads();
+    if (pass) {
+        const int pos = s_base + local;
+        if (pos < p.cap) {
+            p.cand[(long long)b * p.cap + pos] = n;
+            if (p.cand_rows) decode_row(p, src, lvl, a, x, y, obj, p.cand_rows + ((long long)b * p.cap + pos) * p.no);
         }
     }
 }
@@ -97,6 +114,10 @@ struct NmsParams {
 constexpr int kFast = 2048;              // candidates handled by the bit-matrix path
 constexpr int kFastWords = kFast / 64;
 constexpr int kIdxBits = 17;             // candidate index / row slot < 2^17 (1280x1280 tiles: 100,800)
+constexpr int kFastLds = kFast * 8 + kFast * 16 + kFast * 4 + kFast * 2;   // keys + boxes + slots + kept ranks = 60 KiB
+constexpr int kMaskLds = 64 * 1024;      // LDS kept for the suppression bit matrix (n <= ~700 candidates)
+constexpr int kSlowLds = kSortLds * 8 + kMaxNms + 16;
+constexpr int kNmsLds = kFastLds + kMaskLds > kSlowLds ? kFastLds + kMaskLds : kSlowLds;
 
 // conf = obj * cls_conf, best class = first maximum; box = xywh2xyxy (x -/+ w/2)
 __device__ __forceinline__ bool candidate_row(const float* row, int nc, float thr, float4& box, float& conf, int& cls) {
@@ -157,9 +178,10 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
 
 __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
     __shared__ int s_n;
-    // one LDS block, two uses: fast path = unsorted keys [kFast] + sorted offset boxes [kFast];
-    //                          slow path = keys for the in-LDS bitonic sort [kSortLds] + suppression flags
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kSortLds * 8 + kMaxNms + 16];
+    // one dynamic LDS block, two uses: fast path = unsorted keys [kFast] + sorted offset boxes [kFast] + slots + kept
+    //                                  list + (when it fits) the suppression bit matrix;
+    //                                  slow path = keys for the in-LDS bitonic sort [kSortLds] + suppression flags
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     __shared__ int s_kept;
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* rows = p.rows + (long long)b * p.rows_per_tile * p.no;
@@ -215,7 +237,10 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
         __syncthreads();
         // D1: suppression bit matrix, upper triangle: bit j of mask[i][w] = IoU(i, 64w + j) > thr, 64w + j > i
         const int nw = (n + 63) >> 6;
-        unsigned long long* mask = p.mask + (long long)b * kFast * kFastWords;
+        // the bit matrix lives in LDS when n * nw words fit behind the fast-path arrays, else in the global scratch
+        unsigned long long* mask = ((size_t)n * nw * 8 <= kMaskLds)
+                                       ? (unsigned long long*)(s_raw + kFastLds)
+                                       : p.mask + (long long)b * kFast * kFastWords;
         for (int item = tid; item < n * nw; item += kNmsThreads) {
             const int i = item / nw, w = item - i * nw;
             unsigned long long bits = 0ull;
@@ -369,7 +394,12 @@ extern "C" int aq_nms(const float* rows_dev, int rows_per_tile, int B, int N, in
     s += align_up((size_t)B * N * sizeof(float4), 256);
     p.mask = (unsigned long long*)s;
     p.dets = dets_dev; p.counts = counts_dev;
-    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(kNmsThreads), 0, (hipStream_t)stream, p);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AQ_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kNmsLds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(kNmsThreads), kNmsLds, (hipStream_t)stream, p);
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;
 }

@@ -85,6 +85,24 @@ __global__ __launch_bounds__(256) void maxpool5_kernel(const char* __restrict__ 
 
 // SPPF's three chained pools in ONE launch: a workgroup owns one (image, 16-byte channel group) plane, keeps it in
 // LDS (two ping-pong planes) and writes y1, y2, y3 to their channel slices; x is read from HBM once.
+// bf16 <-> order-preserving int16 key (an involution): flip the magnitude bits of negative values, then bf16 order ==
+// signed 16-bit integer order and a window maximum is one v_pk_max_i16 per two values.
+typedef __attribute__((ext_vector_type(2))) short short2_t;
+__device__ __forceinline__ uint32_t bf16x2_key(uint32_t x) {
+    short2_t v; __builtin_memcpy(&v, &x, 4);
+    const short2_t m = (v >> 15) & (short)0x7fff;
+    v = v ^ m;
+    uint32_t r; __builtin_memcpy(&r, &v, 4);
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    short2_t x, y; __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
+    const short2_t m = __builtin_elementwise_max(x, y);
+    uint32_t r; __builtin_memcpy(&r, &m, 4);
+    return r;
+}
+__device__ __forceinline__ uint4 key16(uint4 v) { return make_uint4(bf16x2_key(v.x), bf16x2_key(v.y), bf16x2_key(v.z), bf16x2_key(v.w)); }
+
 template <bool F32>
 __device__ __forceinline__ uint4 max16(uint4 a, uint4 v) {
     if (F32) {
@@ -98,26 +116,36 @@ __device__ __forceinline__ uint4 max16(uint4 a, uint4 v) {
     return a;
 }
 
-template <bool F32>
+template <bool F32, int GPB>   // GPB = adjacent 16-byte channel groups per workgroup (GPB * 16 B contiguous per pixel)
 __global__ __launch_bounds__(256) void sppf_pool3_kernel(char* __restrict__ base, int ld_b, int slice_b, int groups, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int hw = H * W;
-    uint4* plane[2] = {(uint4*)smem, (uint4*)smem + hw};
-    const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
-    char* img = base + (long long)b * hw * ld_b + g * 16;
-    for (int i = threadIdx.x; i < hw; i += blockDim.x) plane[0][i] = *(const uint4*)(img + (long long)i * ld_b);
+    const int hw = H * W, n = hw * GPB;
+    uint4* plane[2] = {(uint4*)smem, (uint4*)smem + n};
+    const int gblocks = groups / GPB;
+    const int b = blockIdx.x / gblocks, g0 = (blockIdx.x - b * gblocks) * GPB;
+    char* img = base + (long long)b * hw * ld_b + g0 * 16;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int pix = i / GPB, g = i - pix * GPB;
+        const uint4 v = *(const uint4*)(img + (long long)pix * ld_b + g * 16);
+        plane[0][i] = F32 ? v : key16(v);                  // bf16: keep the planes as order-preserving int16 keys
+    }
     __syncthreads();
     for (int s = 0; s < 3; ++s) {
         const uint4* src = plane[s & 1];
         uint4* dst = plane[(s & 1) ^ 1];
-        for (int i = threadIdx.x; i < hw; i += blockDim.x) {
-            const int y = i / W, x = i - y * W;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int pix = i / GPB, g = i - pix * GPB;
+            const int y = pix / W, x = pix - y * W;
             const int y0 = max(y - 2, 0), y1 = min(y + 2, H - 1), x0 = max(x - 2, 0), x1 = min(x + 2, W - 1);
             uint4 m = src[i];
             for (int yy = y0; yy <= y1; ++yy)
-                for (int xx = x0; xx <= x1; ++xx) m = max16<F32>(m, src[yy * W + xx]);
+                for (int xx = x0; xx <= x1; ++xx) {
+                    const uint4 v = src[(yy * W + xx) * GPB + g];
+                    if (F32) m = max16<true>(m, v);
+                    else { m.x = pk_max_i16(m.x, v.x); m.y = pk_max_i16(m.y, v.y); m.z = pk_max_i16(m.z, v.z); m.w = pk_max_i16(m.w, v.w); }
+                }
             dst[i] = m;
-            *(uint4*)(img + (long long)i * ld_b + (long long)(s + 1) * slice_b) = m;
+            *(uint4*)(img + (long long)pix * ld_b + (long long)(s + 1) * slice_b + g * 16) = F32 ? m : key16(m);
         }
         __syncthreads();
     }
@@ -198,12 +226,14 @@ extern "C" int aq_sppf_pool(void* buf_dev, int ld, int ch_off, int c, int B, int
     const long long n = (long long)B * H * W * groups;
     AQ_REQUIRE(n < (1LL << 31), "sppf_pool: batch too large");
     char* base = (char*)buf_dev + (long long)ch_off * eb;
-    const size_t plane_lds = (size_t)2 * H * W * 16;
-    if (plane_lds <= 64 * 1024 && (long long)B * groups < (1LL << 31)) {      // whole plane fits LDS: one fused launch
+    constexpr int GPB = 4;
+    const size_t plane_lds = (size_t)2 * H * W * 16 * GPB;
+    if (plane_lds <= 64 * 1024 && groups % GPB == 0 && (long long)B * groups < (1LL << 31)) {   // plane fits LDS: one fused launch
+        const unsigned grid = (unsigned)(B * (groups / GPB));
         if (precision == AQ_FP32)
-            hipLaunchKernelGGL(sppf_pool3_kernel<true>, dim3((unsigned)(B * groups)), dim3(256), plane_lds, (hipStream_t)stream, base, ld * eb, c * eb, groups, H, W);
+            hipLaunchKernelGGL((sppf_pool3_kernel<true, GPB>), dim3(grid), dim3(256), plane_lds, (hipStream_t)stream, base, ld * eb, c * eb, groups, H, W);
         else
-            hipLaunchKernelGGL(sppf_pool3_kernel<false>, dim3((unsigned)(B * groups)), dim3(256), plane_lds, (hipStream_t)stream, base, ld * eb, c * eb, groups, H, W);
+            hipLaunchKernelGGL((sppf_pool3_kernel<false, GPB>), dim3(grid), dim3(256), plane_lds, (hipStream_t)stream, base, ld * eb, c * eb, groups, H, W);
         AQ_CHECK_HIP(hipGetLastError());
         return AQ_OK;
     }
