@@ -15,6 +15,7 @@
 //   * rows stay 128 B with the source-side XOR swizzle (slot ^= (row >> 1) & 7): 32 lanes reading 32 consecutive
 //     region rows are ds_read_b128 conflict-free for every tap shift.
 #include "conv_device.h"
+#include <type_traits>
 
 using namespace aqdev;
 
@@ -154,35 +155,45 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) v
             swb[j] = valid ? ((rr >> 1) & 7) : 0;
         }
         const int ksn = (min(8, p.G - 8 * cc) + 1) >> 1;    // k16 steps that hold real channels in this chunk
+        using frag_t = typename std::conditional<F32, f32x4, bf16x8>::type;
+        auto load_frags = [&](int ks, frag_t (&fa)[TM], frag_t (&fb)[TN]) {
+            const int soa = (((2 * ks + h) ^ swa) << 4);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks < ksn) {
-                const int soa = (((2 * ks + h) ^ swa) << 4);
-                if constexpr (!F32) {
-                    bf16x8 a[TM], b[TN];
+            for (int i = 0; i < TM; ++i) fa[i] = *(const frag_t*)(wb + a_off + i * 32 * ROWB + soa);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8*)(wb + a_off + i * 32 * ROWB + soa);
+            for (int j = 0; j < TN; ++j) fb[j] = *(const frag_t*)(rowp[j] + (((2 * ks + h) ^ swb[j]) << 4));
+        };
+        auto mfmas = [&](const frag_t (&fa)[TM], const frag_t (&fb)[TN]) {
+            if constexpr (!F32) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8*)(rowp[j] + (((2 * ks + h) ^ swb[j]) << 4));
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-                } else {
-                    f32x4 a[TM], b[TN];
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+            }
+        };
+        // One wave per SIMD (4-wave shapes, 512 registers): nothing else hides LDS latency, so the fragment reads of
+        // k-step ks+1 are issued before the MFMAs of k-step ks.  With two waves per SIMD the partner wave covers it and
+        // the second register set only costs occupancy (measured).
+        constexpr bool PIPE = (NW == 4);
+        frag_t a[2][TM], b[2][TN];
+        if constexpr (PIPE) load_frags(0, a[0], b[0]);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(wb + a_off + i * 32 * ROWB + soa);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(rowp[j] + (((2 * ks + h) ^ swb[j]) << 4));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-                }
+        for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (PIPE) {
+                if (ks + 1 < 4) load_frags(ks + 1 < ksn ? ks + 1 : 0, a[(ks + 1) & 1], b[(ks + 1) & 1]);
+                if (ks < ksn) mfmas(a[ks & 1], b[ks & 1]);
+            } else if (ks < ksn) {
+                load_frags(ks, a[0], b[0]);
+                mfmas(a[0], b[0]);
             }
             if (nw_src) {
 #pragma unroll
@@ -284,6 +295,7 @@ const HaloConfig kHalo[] = {
     HCFG(192, 256, 2, 2),   // per-wave 96x128, 4 waves (one per SIMD, 512 registers): fewest LDS reads per MFMA
     HCFG(384, 128, 2, 2),   // per-wave 192x64, 4 waves
     HCFG(256, 256, 2, 4),   // per-wave 128x64
+    HCFG(128, 256, 2, 2),   // per-wave 64x128, 4 waves
 };
 constexpr int kNumHalo = sizeof(kHalo) / sizeof(kHalo[0]);
 bool g_halo_attr[kNumHalo][2];

@@ -489,6 +489,8 @@ const ConvConfig kConfigs[] = {
     CFG(64, 128, 1, 4, 3, true),    // 16
     CFG(256, 128, 4, 2, 3, true),   // 17: per-wave 64x64
     CFG(192, 192, 2, 2, 3, true),   // 18: per-wave 96x96, 4 waves
+    CFG(192, 256, 2, 2, 2, true),   // 19: per-wave 96x128, 4 waves (one per SIMD, 512 registers)
+    CFG(128, 256, 2, 2, 3, true),   // 20: per-wave 64x128, 4 waves, 3 stages
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 

@@ -277,3 +277,32 @@ extern "C" int aq_letterbox_u8(const uint8_t* src_dev, int B, int H0, int W0, ui
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;
 }
+
+// Diagnostics: register-only bf16 MFMA loop (no memory traffic) to read the chip's sustained matrix rate under load
+// (tools/mfma_peak.py).  blocks x 256 threads, each wave issues iters x 8 independent v_mfma_f32_32x32x16_bf16.
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, unsigned seed) {
+    f32x16 acc[8];
+    bf16x8 a, b;
+    const unsigned t = threadIdx.x * 2654435761u + seed;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (short)(0x3f80 + ((t >> i) & 0x3f)); b[i] = (short)(0xbf80 + ((t >> (i + 3)) & 0x3f)); }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[k], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += acc[k][threadIdx.x & 15];
+    if (s == 123.456f) out[0] = s;   // keep the loop alive without a store in practice
+}
+
+extern "C" int aq_debug_mfma_peak(int blocks, int iters, void* out_dev, void* stream) {
+    AQ_REQUIRE(blocks > 0 && iters > 0 && out_dev, "mfma_peak: bad argument");
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float*)out_dev, iters, 12345u);
+    AQ_CHECK_HIP(hipGetLastError());
+    return AQ_OK;
+}

@@ -62,7 +62,7 @@ EXPORTS = (
     "aq_last_error", "aq_version", "aq_engine_create", "aq_engine_destroy", "aq_engine_workspace_bytes",
     "aq_engine_infer", "aq_engine_forward_raw", "aq_engine_tensor_ptr", "aq_engine_profile",
     "aq_engine_op_times", "aq_engine_num_ops", "aq_engine_set_conv_config", "aq_engine_autotune",
-    "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp",
+    "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
     "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
@@ -95,6 +95,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_engine_autotune.argtypes = [vp, vp, i32, i32, i32, vp, sz, i32, vp]
     lib.aq_engine_get_conv_config.argtypes = [vp, i32]
     lib.aq_debug_conv_stamp.argtypes = [vp, sz]
+    lib.aq_debug_mfma_peak.argtypes = [i32, i32, vp, vp]
     lib.aq_conv_config_tiles.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
     lib.aq_pack_conv_weights.argtypes = [C.POINTER(f32), i32, i32, i32, i32, vp, C.POINTER(sz), vp]
     lib.aq_conv2d.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, i32, vp, vp,

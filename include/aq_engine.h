@@ -126,6 +126,8 @@ int aq_conv_num_configs(void);
 /* Diagnostics: arm (buf != NULL) or disarm a device buffer that the STAMPED builds of a few conv tile shapes fill with
  * per-wave phase cycle sums (8 x uint64 per wave); used by tools/stamp_conv.py only. */
 int aq_debug_conv_stamp(void* buf_dev, size_t bytes);
+/* Diagnostics: register-only bf16 MFMA loop (blocks x 4 waves x iters x 8 MFMAs) to read the sustained matrix rate. */
+int aq_debug_mfma_peak(int blocks, int iters, void* out_dev, void* stream);
 int aq_conv_config_tiles(int cfg, int* bm, int* bn);
 
 /* ---- individual kernels --------------------------------------------------------------- */

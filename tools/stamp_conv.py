@@ -30,7 +30,7 @@ LAYERS = [
 
 def main():
     lib = engine.load_library()
-    n_igemm = 19
+    n_igemm = 21
     dev = torch.device("cuda", 0)
     buf = torch.zeros(1 << 22, dtype=torch.int64, device=dev)
     g = torch.Generator().manual_seed(0)
