@@ -181,17 +181,32 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) v
             }
         };
         // One wave per SIMD (4-wave shapes, 512 registers): nothing else hides LDS latency, so the fragment reads of
-        // k-step ks+1 are issued before the MFMAs of k-step ks.  With two waves per SIMD the partner wave covers it and
-        // the second register set only costs occupancy (measured).
+        // k-step ks+1 are issued before the MFMAs of k-step ks.  With two waves per SIMD the partner wave covers it.
         constexpr bool PIPE = (NW == 4);
         frag_t a[2][TM], b[2][TN];
-        if constexpr (PIPE) load_frags(0, a[0], b[0]);
+        if (ksn == 4 && nw_src != nullptr) {
+            // Fast path (full chunk, a weight slice to stage): NO data-dependent branch inside, so the whole step is one
+            // basic block and the scheduler can hoist fragment reads over MFMAs of earlier k-steps.
+            if constexpr (PIPE) load_frags(0, a[0], b[0]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if constexpr (PIPE) {
+                    if (ks + 1 < 4) load_frags(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
+                    mfmas(a[ks & 1], b[ks & 1]);
+                } else {
+                    load_frags(ks, a[ks & 1], b[ks & 1]);
+                    mfmas(a[ks & 1], b[ks & 1]);
+                }
+#pragma unroll
+                for (int j = 0; j < JW; ++j)
+                    if ((j * 3) / JW == ks) glds16(nw_src + j * wstep, nw_buf + (wave + NW * j) * 1024);
+            }
+            if (x_on) nx_issued = stage_x_part(x_n0, x_cc, x_part, x_buf);
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if constexpr (PIPE) {
-                if (ks + 1 < 4) load_frags(ks + 1 < ksn ? ks + 1 : 0, a[(ks + 1) & 1], b[(ks + 1) & 1]);
-                if (ks < ksn) mfmas(a[ks & 1], b[ks & 1]);
-            } else if (ks < ksn) {
+            if (ks < ksn) {
                 load_frags(ks, a[0], b[0]);
                 mfmas(a[0], b[0]);
             }
