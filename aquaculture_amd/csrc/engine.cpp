@@ -473,3 +473,27 @@ extern "C" int aq_engine_op_times(aq_engine* e, float* ms_out, int n_ops, int* c
     if (calls_recorded) *calls_recorded = calls;
     return AQ_OK;
 }
+
+// Host helper of the label writer: n rows (cls xc yc w h conf, fp32) -> text exactly as `detect.py --save-txt --save-conf`
+// prints them [UPSTREAM detect.py: ('%g ' * len(line)).rstrip() % line + '\n'], consumed by reference
+// src/process_yolo/geocode_results.py:140.  Returns the number of bytes written, or -(bytes needed) if buf is too small.
+extern "C" long aq_format_label_rows(const float* rows, int n, int save_conf, char* buf, size_t buflen) {
+    if (!rows || !buf || n < 0) return 0;
+    const int cols = save_conf ? 6 : 5;
+    size_t off = 0;
+    bool overflow = false;
+    char tmp[32];
+    for (int i = 0; i < n; ++i) {
+        for (int c = 0; c < cols; ++c) {
+            const int len = snprintf(tmp, sizeof(tmp), "%g", (double)rows[(size_t)i * 6 + c]);
+            if (!overflow && off + (size_t)len + 1 <= buflen) {
+                memcpy(buf + off, tmp, (size_t)len);
+                buf[off + len] = (c + 1 == cols) ? '\n' : ' ';
+            } else {
+                overflow = true;
+            }
+            off += (size_t)len + 1;
+        }
+    }
+    return overflow ? -(long)off : (long)off;
+}

@@ -156,3 +156,41 @@ class LoadImages:
             paths.append(p); ims.append(im); shapes.append(s0)
         if ims:
             yield paths, np.stack(ims, 0), shapes
+
+
+    def pinned_batches(self, batch_size: int, n_buffers: int = 3):
+        """Raw-mode fast path for tile sweeps (every image the same size, as the reference's tiler produces them):
+        decode threads write straight into pre-pinned uint8 batch buffers [batch, H0, W0, 3] (no stack / pin copies).
+        Yields (paths, pinned torch uint8 tensor [b,H0,W0,3], [orig shapes], buffer index); the caller must be done with
+        buffer ``i`` (its H2D copy enqueued AND completed) before the (i + n_buffers)-th batch is produced -- it signals
+        that by calling ``release(i)`` on the returned generator's ``release`` attribute.  Images of a different size end
+        the fast path with a ValueError (use ``batches`` for mixed directories)."""
+        import threading
+
+        import torch
+        assert self.raw, "pinned_batches is the raw (device letterbox) path"
+        if not self.files:
+            return
+        first = read_rgb(self.files[0])
+        H0, W0 = first.shape[:2]
+        bufs = [torch.empty((batch_size, H0, W0, 3), dtype=torch.uint8).pin_memory() for _ in range(n_buffers)]
+        views = [b.numpy() for b in bufs]
+        free = [threading.Semaphore(1) for _ in range(n_buffers)]
+        self.release = lambda i: free[i].release()
+
+        def job(args):
+            path, dst = args
+            im = read_rgb(path)
+            if im.shape != dst.shape:
+                raise ValueError(f"{path}: {im.shape[:2]} differs from the first image {dst.shape[:2]}; mixed sizes need batches()")
+            dst[...] = im
+
+        with ThreadPoolExecutor(self.workers) as ex:
+            k = 0
+            for s in range(0, len(self.files), batch_size):
+                paths = self.files[s:s + batch_size]
+                i = k % n_buffers
+                free[i].acquire()
+                list(ex.map(job, [(p, views[i][j]) for j, p in enumerate(paths)]))
+                yield paths, bufs[i][:len(paths)], [(H0, W0)] * len(paths), i
+                k += 1

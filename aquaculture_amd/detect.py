@@ -81,6 +81,7 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
     p.add_argument("--batch-size", type=int, default=64, help="tiles per engine call")
     p.add_argument("--precision", choices=("fp32", "bf16"), default=None, help="default fp32 (detect.py without --half)")
     p.add_argument("--workers", type=int, default=8, help="jpeg decode threads")
+    p.add_argument("--quiet", action="store_true", help="no per-image log line (the summary lines are still printed)")
     opt = p.parse_args(argv)
     opt.imgsz *= 2 if len(opt.imgsz) == 1 else 1
     return opt
@@ -89,8 +90,8 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
 def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_det=1000, device="",
         save_txt=False, save_conf=False, nosave=False, classes=None, agnostic_nms=False,
         project="runs/detect", name="exp", exist_ok=False, half=False, batch_size=64, precision=None,
-        workers=8, log=print, **unsupported):
-    from .engine import Engine, letterbox_device   # raises if the HIP library or the GPU is missing: there is no fallback
+        workers=8, quiet=False, log=print, **unsupported):
+    from .engine import Engine, format_label_rows, letterbox_device   # raises if the HIP library or the GPU is missing: there is no fallback
 
     for k in UNSUPPORTED:
         if unsupported.get(k):
@@ -122,44 +123,137 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     # decoded images go to the GPU as they are; the letterbox (resize INTER_LINEAR + pad 114) runs on the device
     dataset = LoadImages(source, img_size=imgsz, stride=int(max(ck.stride)), auto=True, shard=(rank, world), workers=workers, raw=True)
 
-    copy_stream = torch.cuda.Stream()
-    seen, n_labels, n_dets = 0, 0, 0
-    t_pre = t_inf = t_post = 0.0
+    # Pipeline: decode threads -> [main thread: H2D, letterbox, engine, async D2H] -> [writer thread: rescale, format, files].
+    # Up to `depth` batches are in flight, each with its own workspace slot, pinned result buffers and stream.
+    import queue
+    import threading
+    depth = 3
+    streams = [torch.cuda.Stream() for _ in range(depth)]
+    slot_free = [threading.Semaphore(1) for _ in range(depth)]   # a slot's pinned result buffers are reused only after its writer is done
+    stats = {"seen": 0, "labels": 0, "dets": 0, "t_post": 0.0}
     gathered: List[torch.Tensor] = []
+    q: "queue.Queue" = queue.Queue(maxsize=depth)
+    err: List[BaseException] = []
+
+    def writer():
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                ev, counts_h, dets_h, paths, shapes0, hw, first, t_inf, slot_id = item
+                ev.synchronize()
+                t0 = time.perf_counter()
+                nlab = ndet = 0
+                H, W = hw
+                cnt = counts_h.numpy()
+                det_all = dets_h.numpy()
+                for b, p in enumerate(paths):
+                    det = det_all[b, : cnt[b]]
+                    ndet += det.shape[0]
+                    rows = postprocess.detections_to_rows(det, (H, W), shapes0[b])
+                    if save_txt and rows.shape[0]:       # no detections => no file (the consumer relies on it)
+                        with open(os.path.join(labels_dir, Path(p).stem + ".txt"), "ab") as f:
+                            f.write(format_label_rows(rows, save_conf))
+                        nlab += 1
+                    if not quiet:
+                        s = f"image {dataset.indices[first + b] + 1}/{dataset.total} {p}: {H}x{W} "
+                        s += postprocess.class_summary(det[:, 5], ck.names) if det.shape[0] else "(no detections), "
+                        log(f"{s}{t_inf * 1e3 / len(paths):.1f}ms")
+                    if world > 1 and det.shape[0]:
+                        idx = torch.full((det.shape[0],), dataset.indices[first + b], dtype=torch.float32)
+                        gathered.append(aqdist.pack_rows(idx, torch.from_numpy(det.copy())))
+                slot_free[slot_id].release()
+                with lock:
+                    stats["seen"] += len(paths)
+                    stats["labels"] += nlab
+                    stats["dets"] += ndet
+                    stats["t_post"] += time.perf_counter() - t0
+        except BaseException as e:   # surfaced by the main thread
+            err.append(e)
+            for sf in slot_free:     # never leave the producer blocked on a slot
+                sf.release()
+            while True:              # keep draining so q.put() cannot block either
+                if q.get() is None:
+                    return
+
+    lock = threading.Lock()
+    n_writers = 4 if quiet else 1          # per-image log lines stay in order with a single writer
+    depth_q = depth
+    wts = [threading.Thread(target=writer, daemon=True) for _ in range(n_writers)]
+    for w_ in wts:
+        w_.start()
+    t_pre = t_inf = 0.0
     t_start = time.perf_counter()
     shape_str = ""
-    for paths, batch, shapes0 in dataset.batches(batch_size):
+    pinned = [None] * depth
+    issued = 0
+    k = 0
+    def batch_source():
+        """Uniform tile directories (the reference's case): zero-copy pinned batches; mixed sizes: the generic path."""
+        try:
+            for item in dataset.pinned_batches(batch_size, depth + 1):
+                yield item
+        except ValueError as e:
+            log(f"note: {e}")
+            raise
+
+    try:
+        from PIL import Image
+        with Image.open(dataset.files[0]) as _im0:
+            _size0 = _im0.size
+        uniform = all(Image.open(f).size == _size0 for f in dataset.files[:: max(1, len(dataset.files) // 16)])
+    except Exception:
+        uniform = False
+    source_iter = batch_source() if uniform and len(dataset) else ((p_, torch.from_numpy(b_).pin_memory(), s_, None)
+                                                                  for p_, b_, s_ in dataset.batches(batch_size))
+    copy_done = []
+    for paths, host, shapes0, buf_i in source_iter:
+        if err:
+            break
         t0 = time.perf_counter()
-        host = torch.from_numpy(batch).pin_memory()
-        with torch.cuda.stream(copy_stream):
+        slot = k % depth
+        slot_free[slot].acquire()
+        st = streams[slot]
+        with torch.cuda.stream(st):
             tiles = host.to(dev, non_blocking=True)
-        torch.cuda.current_stream().wait_stream(copy_stream)
-        tiles = letterbox_device(tiles, tuple(imgsz), int(max(ck.stride)), True)
-        t1 = time.perf_counter()
-        dets, counts = eng.infer(tiles, conf_thres, iou_thres, max_det)
-        counts_h = counts.cpu().numpy()
-        dets_h = dets[:, : int(counts_h.max(initial=0))].cpu().numpy() if counts_h.size else dets.cpu().numpy()
-        t2 = time.perf_counter()
+            if buf_i is not None:                      # hand the pinned buffer back once its H2D copy has completed
+                h2d = torch.cuda.Event()
+                h2d.record(st)
+                copy_done.append((h2d, buf_i))
+            tiles = letterbox_device(tiles, tuple(imgsz), int(max(ck.stride)), True)
+            t1 = time.perf_counter()
+            dets, counts = eng.infer(tiles, conf_thres, iou_thres, max_det, slot=slot)
+            B = tiles.shape[0]
+            if pinned[slot] is None or pinned[slot][0].shape[0] < B:
+                pinned[slot] = (torch.empty((max(B, batch_size),), dtype=torch.int32).pin_memory(),
+                                torch.empty((max(B, batch_size), max_det, 6), dtype=torch.float32).pin_memory())
+            counts_h, dets_h = pinned[slot][0][:B], pinned[slot][1][:B]
+            counts_h.copy_(counts, non_blocking=True)
+            dets_h.copy_(dets, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
         H, W = int(tiles.shape[1]), int(tiles.shape[2])
         shape_str = f"(1, 3, {H}, {W})"
-        for b, p in enumerate(paths):
-            seen += 1
-            det = dets_h[b, : counts_h[b]]
-            n_dets += det.shape[0]
-            rows = postprocess.detections_to_rows(det, (H, W), shapes0[b])
-            if save_txt and postprocess.write_label_file(labels_dir, Path(p).stem, rows, save_conf):
-                n_labels += 1
-            s = f"image {dataset.indices[seen - 1] + 1}/{dataset.total} {p}: {H}x{W} "
-            s += postprocess.class_summary(det[:, 5], ck.names) if det.shape[0] else "(no detections), "
-            log(f"{s}{(t2 - t1) * 1e3 / len(paths):.1f}ms")
-            if world > 1 and det.shape[0]:
-                idx = torch.full((det.shape[0],), dataset.indices[seen - 1], dtype=torch.float32)
-                gathered.append(aqdist.pack_rows(idx, torch.from_numpy(det)))
-        t3 = time.perf_counter()
+        t2 = time.perf_counter()
+        q.put((ev, counts_h, dets_h, paths, shapes0, (H, W), issued, t2 - t1, slot))
+        issued += len(paths)
+        while copy_done and (copy_done[0][0].query() or len(copy_done) > depth):
+            ev_, bi_ = copy_done.pop(0)
+            ev_.synchronize()
+            dataset.release(bi_)
         t_pre += t1 - t0
         t_inf += t2 - t1
-        t_post += t3 - t2
+        k += 1
+    for _ in wts:
+        q.put(None)
+    for w_ in wts:
+        w_.join()
+    if err:
+        raise err[0]
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
+    seen, n_labels, n_dets, t_post = stats["seen"], stats["labels"], stats["dets"], stats["t_post"]
 
     if world > 1:   # the one collective of the path: final detection gather over RCCL/xGMI
         rows = torch.cat(gathered, 0) if gathered else torch.zeros((0, aqdist.ROW))
@@ -170,8 +264,8 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         seen_all, labels_all, dets_all = seen, n_labels, n_dets
     if rank == 0:
         per = lambda t: t * 1e3 / max(seen, 1)
-        log(f"Speed: {per(t_pre):.1f}ms pre-process, {per(t_inf):.1f}ms inference+NMS, {per(t_post):.1f}ms post-process "
-            f"per image at shape {shape_str}")
+        log(f"Speed: {per(t_pre):.1f}ms pre-process, {per(t_inf):.1f}ms inference, {per(t_post):.1f}ms NMS-out/post-process "
+            f"per image at shape {shape_str} (host time per stage; stages overlap)")
         log(f"{seen_all} images, {dets_all} detections, {seen_all / max(elapsed, 1e-9):.1f} images/s on {world} GPU(s) [{precision}]")
         if save_txt:
             log(f"Results saved to {save_dir}\n{labels_all} labels saved to {save_dir / 'labels'}")

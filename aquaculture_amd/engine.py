@@ -64,7 +64,7 @@ EXPORTS = (
     "aq_engine_op_times", "aq_engine_num_ops", "aq_engine_set_conv_config", "aq_engine_autotune",
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
     "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_preprocess_s2d", "aq_sppf_pool",
-    "aq_upsample2x", "aq_letterbox_u8", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
+    "aq_upsample2x", "aq_letterbox_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
 
 _lib = None
@@ -104,6 +104,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_sppf_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.aq_upsample2x.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.aq_letterbox_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.aq_format_label_rows.argtypes = [C.POINTER(f32), i32, i32, C.c_char_p, sz]
+    lib.aq_format_label_rows.restype = C.c_long
     lib.aq_detect_decode.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32),
                                      vp, f32, vp, vp, vp, i32, vp]
     lib.aq_nms_scratch_bytes.argtypes = [i32, i32]
@@ -402,3 +404,18 @@ def letterbox_device(tiles0: torch.Tensor, new_shape=(640, 640), stride: int = 3
     _check(lib.aq_letterbox_u8(tiles0.data_ptr(), B, H0, W0, out.data_ptr(), H, W, nw, nh, top, left,
                                xt.data_ptr(), yt.data_ptr(), _stream_ptr()))
     return out
+
+
+def format_label_rows(rows: np.ndarray, save_conf: bool = True) -> bytes:
+    """rows float32 [n,6] (cls xc yc w h conf) -> label-file bytes via the C formatter (releases the GIL)."""
+    lib = load_library()
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    n = rows.shape[0]
+    if n == 0:
+        return b""
+    buf = C.create_string_buffer(n * 6 * 16)
+    k = lib.aq_format_label_rows(rows.ctypes.data_as(C.POINTER(C.c_float)), n, int(save_conf), buf, len(buf))
+    if k < 0:
+        buf = C.create_string_buffer(-k + 1)
+        k = lib.aq_format_label_rows(rows.ctypes.data_as(C.POINTER(C.c_float)), n, int(save_conf), buf, len(buf))
+    return buf.raw[:k]

@@ -58,12 +58,14 @@ def detections_to_rows(det: np.ndarray, img1_shape, img0_shape) -> np.ndarray:
 
 
 def format_rows(rows: np.ndarray, save_conf: bool = True) -> str:
-    """Text of one label file.  Each value through ``%g`` of the double that equals the fp32 value."""
-    out = []
+    """Text of one label file.  Each value through ``%g`` of the double that equals the fp32 value
+    (one C-level format call for the whole file: the same conversions as upstream's per-line ``%``)."""
     n = 6 if save_conf else 5
-    for r in rows:
-        out.append(("%g " * n).rstrip() % tuple(float(v) for v in r[:n]))
-    return "".join(line + "\n" for line in out)
+    k = rows.shape[0]
+    if k == 0:
+        return ""
+    line = ("%g " * n).rstrip() + "\n"
+    return (line * k) % tuple(np.asarray(rows[:, :n], dtype=np.float64).ravel().tolist())
 
 
 def write_label_file(labels_dir: str, stem: str, rows: np.ndarray, save_conf: bool = True) -> bool:

@@ -176,6 +176,10 @@ int aq_nms(const float* rows_dev, int rows_per_tile, int B, int N, int nc, float
            int max_det, const int32_t* cand_dev, const int32_t* cand_count_dev, int cand_cap,
            void* scratch_dev, aq_det* dets_dev, int32_t* counts_dev, void* stream);
 
+/* Host helper: n label rows (cls xc yc w h conf, fp32, stride 6) -> the text detect.py --save-txt [--save-conf] writes
+ * ("%g" per value, one line per row).  Returns bytes written or -(bytes needed). */
+long aq_format_label_rows(const float* rows, int n, int save_conf, char* buf, size_t buflen);
+
 #ifdef __cplusplus
 }
 #endif
