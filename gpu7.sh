@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -3
+timeout -k 10 900 python -m pytest tests/test_gpu_engine.py -x -q -m gpu -k "ragged or rejects" 2>&1 | tail -12
