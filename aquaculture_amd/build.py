@@ -21,6 +21,7 @@ SOURCES = [
     # (file, extra flags)
     ("conv_igemm.hip", []),
     ("conv_halo.hip", []),
+    ("stem_conv.hip", []),
     ("pointwise.hip", []),
     ("detect_nms.hip", ["-ffp-contract=off"]),   # bit-level parity with the oracle's fp32 op order
     ("engine.cpp", ["-x", "hip"]),

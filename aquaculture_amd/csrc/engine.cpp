@@ -185,6 +185,10 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
         case AQ_OP_CONV:
             rc = run_conv(e, oi, ws, tiles, B, stream);
             break;
+        case AQ_OP_STEM:
+            rc = aq_stem_conv(tiles, tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
+                              op.dst.channels, e->packed[oi].w, e->packed[oi].bias, B, H, W, op.act, prec, stream);
+            break;
         case AQ_OP_SPPF_POOL: {
             const TensorPlace& pl = e->place[op.src.tensor];
             rc = aq_sppf_pool(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
@@ -310,6 +314,28 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
                 aq_set_error("engine_create: op %zu has a slice outside its tensor", oi);
                 return fail(AQ_ERR_INVALID);
             }
+        }
+        if (op.kind == AQ_OP_STEM) {
+            PackedW& pw = e->packed[oi];
+            size_t nb = 0;
+            std::vector<float> bias(64, 0.0f);
+            if (!op.weight || !op.bias || op.k != 6 || op.stride != 2 || op.pad != 2 || op.src.channels != 3 || op.dst.channels > 64 ||
+                aq_pack_stem_weights(op.weight, op.dst.channels, d->precision, nullptr, &nb, nullptr) != AQ_OK) {
+                aq_set_error("engine_create: stem op %zu unsupported (needs k=6 s=2 p=2, 3 -> <=64 channels)", oi);
+                return fail(AQ_ERR_INVALID);
+            }
+            memcpy(bias.data(), op.bias, sizeof(float) * op.dst.channels);
+            if (hipMalloc(&pw.w, nb) != hipSuccess || hipMalloc((void**)&pw.bias, bias.size() * sizeof(float)) != hipSuccess) {
+                aq_set_error("engine_create: stem weight allocation failed");
+                return fail(AQ_ERR_NOMEM);
+            }
+            if (aq_pack_stem_weights(op.weight, op.dst.channels, d->precision, pw.w, &nb, nullptr) != AQ_OK ||
+                hipMemcpy(pw.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+                aq_set_error("engine_create: stem weight upload failed");
+                return fail(AQ_ERR_HIP);
+            }
+            op.weight = nullptr; op.bias = nullptr;
+            continue;
         }
         if (op.kind != AQ_OP_CONV) continue;
         if (!op.weight || !op.bias || (op.src.channels * eb) % 16 != 0 || op.dst.channels % 8 != 0 || op.dst.ch_off % 8 != 0 || op.k * op.k > 25) {

@@ -63,7 +63,7 @@ EXPORTS = (
     "aq_engine_infer", "aq_engine_forward_raw", "aq_engine_tensor_ptr", "aq_engine_profile",
     "aq_engine_op_times", "aq_engine_num_ops", "aq_engine_set_conv_config", "aq_engine_autotune",
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
-    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_preprocess_s2d", "aq_sppf_pool",
+    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
 
@@ -100,6 +100,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_pack_conv_weights.argtypes = [C.POINTER(f32), i32, i32, i32, i32, vp, C.POINTER(sz), vp]
     lib.aq_conv2d.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, i32, vp, vp,
                               i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.aq_pack_stem_weights.argtypes = [C.POINTER(f32), i32, i32, vp, C.POINTER(sz), vp]
+    lib.aq_stem_conv.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.aq_preprocess_s2d.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.aq_sppf_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.aq_upsample2x.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -136,13 +138,13 @@ def _act_dtype(precision: int) -> torch.dtype:
 class Engine:
     """YOLOv5 tile engine on one GPU.  Owns the C engine (packed weights) and a workspace tensor."""
 
-    def __init__(self, ck: Checkpoint, precision: str = "bf16", device: int = 0):
+    def __init__(self, ck: Checkpoint, precision: str = "bf16", device: int = 0, fused_stem: bool = True):
         _require_gpu()
         self.lib = load_library()
         self.ck = ck
         self.precision = PRECISIONS[precision]
         self.device = torch.device("cuda", device)
-        self.plan = _spec.build_plan(ck.variant, ck.nc, ck.na)
+        self.plan = _spec.build_plan(ck.variant, ck.nc, ck.na, fused_stem=fused_stem)
         self.no = ck.nc + 5
         packed = pack_plan_weights(ck, self.plan)
         self._keep = packed   # host arrays must outlive aq_engine_create only, kept for debugging
@@ -160,7 +162,7 @@ class Engine:
                 setattr(d, name, aq_slice(s.tensor, s.ch_off, s.channels) if s is not None else aq_slice(-1, 0, 0))
             d.k, d.stride, d.pad, d.act, d.level = o.k, o.stride, o.pad, o.act, o.level
             d.flops_per_tile = o.flops_per_tile
-            if o.kind == _spec.OP_CONV:
+            if o.kind in (_spec.OP_CONV, _spec.OP_STEM):
                 pw = packed[ci]
                 ci += 1
                 d.weight = pw.weight.ctypes.data_as(C.POINTER(C.c_float))
@@ -419,3 +421,25 @@ def format_label_rows(rows: np.ndarray, save_conf: bool = True) -> bytes:
         buf = C.create_string_buffer(-k + 1)
         k = lib.aq_format_label_rows(rows.ctypes.data_as(C.POINTER(C.c_float)), n, int(save_conf), buf, len(buf))
     return buf.raw[:k]
+
+
+def stem_conv_nhwc(tiles_u8: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, act: bool = True, precision: str = "bf16") -> torch.Tensor:
+    """uint8 [B,H,W,3] -> SiLU(conv6x6/s2/p2(x / 255, w) + b) as NHWC [B,H/2,W/2,cout] through aq_stem_conv (tests)."""
+    _require_gpu()
+    lib = load_library()
+    prec = PRECISIONS[precision]
+    B, H, W, _ = tiles_u8.shape
+    cout = w_oihw.shape[0]
+    w = np.ascontiguousarray(w_oihw.permute(0, 2, 3, 1).float().cpu().numpy())
+    n = C.c_size_t()
+    wp = w.ctypes.data_as(C.POINTER(C.c_float))
+    _check(lib.aq_pack_stem_weights(wp, cout, prec, None, C.byref(n), None))
+    wbuf = torch.empty(n.value, dtype=torch.uint8, device=tiles_u8.device)
+    _check(lib.aq_pack_stem_weights(wp, cout, prec, wbuf.data_ptr(), C.byref(n), _stream_ptr()))
+    bbuf = torch.zeros(64, dtype=torch.float32, device=tiles_u8.device)
+    bbuf[:cout] = bias.float().to(tiles_u8.device)
+    out = torch.empty((B, H // 2, W // 2, cout), dtype=_act_dtype(prec), device=tiles_u8.device)
+    _check(lib.aq_stem_conv(tiles_u8.data_ptr(), out.data_ptr(), cout, 0, cout, wbuf.data_ptr(), bbuf.data_ptr(), B, H, W, int(act), prec,
+                            _stream_ptr()))
+    torch.cuda.current_stream().synchronize()
+    return out

@@ -27,6 +27,7 @@ OP_SPPF_POOL = 2    # three chained 5x5/s1/p2 max pools -> 3 channel slices
 OP_UPSAMPLE2X = 3   # nearest 2x into a channel slice
 OP_DECODE = 4       # sigmoid + grid/anchor decode + obj threshold + compaction
 OP_NMS = 5          # per-tile class-offset greedy NMS
+OP_STEM = 6         # fused u8 -> /255 -> Conv(3, C, 6, 2, 2) + SiLU (stem_conv.hip)
 
 VARIANTS = {
     # name: (depth_multiple, width_multiple)   [UPSTREAM models/yolov5{n,s,m,l,x}.yaml]
@@ -102,7 +103,8 @@ class Plan:
     input_tensor: int
 
     def conv_ops(self) -> List[Op]:
-        return [o for o in self.ops if o.kind == OP_CONV]
+        """Ops that carry weights (implicit-GEMM convs and the fused stem), in plan order."""
+        return [o for o in self.ops if o.kind in (OP_CONV, OP_STEM)]
 
     def flops(self, h: int, w: int) -> Dict[str, float]:
         """Algorithmic FLOPs per tile (2 x MAC, true Cin of the upstream layer, no padding)."""
@@ -157,7 +159,7 @@ class _Builder:
         return dst
 
 
-def build_plan(variant: str = "yolov5m", nc: int = 5, na: int = 3) -> Plan:
+def build_plan(variant: str = "yolov5m", nc: int = 5, na: int = 3, fused_stem: bool = True) -> Plan:
     """Flatten the v6 architecture into ops over sliced NHWC buffers."""
     gd, gw = VARIANTS[variant]
     ch = tuple(make_divisible(c * gw) for c in (64, 128, 256, 512, 1024))
@@ -172,13 +174,19 @@ def build_plan(variant: str = "yolov5m", nc: int = 5, na: int = 3) -> Plan:
     cat19 = b.tensor("cat19", c3 + c3, 16)   # [out18 | out14]
     cat22 = b.tensor("cat22", c4 + c4, 32)   # [out21 | out10]
 
-    # 0: Conv(3, c1, 6, 2, 2) == 3x3/s1/p1 conv over the 2x2 space-to-depth image (12 -> 16 ch)
+    # 0: Conv(3, c1, 6, 2, 2).  Default: ONE fused kernel from the uint8 tiles (stem_conv.hip).  Alternative (kept for
+    # A/B and for channel counts above 64): preprocess to a 2x2 space-to-depth image (12 -> 16 ch) + generic 3x3/s1 conv.
     t_in = b.tensor("tiles_u8", 3, 1, "u8")
-    t_s2d = b.tensor("s2d", STEM_S2D_CH, 2)
-    b.ops.append(Op(OP_PREPROCESS, "preprocess", src=Slice(t_in, 0, 3), dst=Slice(t_s2d, 0, STEM_S2D_CH)))
     t0 = b.tensor("out0", c1, 2)
-    x = b.conv("model.0", Slice(t_s2d, 0, STEM_S2D_CH), Slice(t0, 0, c1), 3, 1, ("model.0",),
-               **{"class": "stem", "true_cin": 3, "true_k": 6, "stem_s2d": True})
+    if fused_stem and c1 <= 64:
+        b.ops.append(Op(OP_STEM, "model.0", src=Slice(t_in, 0, 3), dst=Slice(t0, 0, c1), k=6, stride=2, pad=2, act=1,
+                        weight_keys=("model.0",), meta={"class": "stem"}))
+        x = Slice(t0, 0, c1)
+    else:
+        t_s2d = b.tensor("s2d", STEM_S2D_CH, 2)
+        b.ops.append(Op(OP_PREPROCESS, "preprocess", src=Slice(t_in, 0, 3), dst=Slice(t_s2d, 0, STEM_S2D_CH)))
+        x = b.conv("model.0", Slice(t_s2d, 0, STEM_S2D_CH), Slice(t0, 0, c1), 3, 1, ("model.0",),
+                   **{"class": "stem", "true_cin": 3, "true_k": 6, "stem_s2d": True})
     # 1: Conv(c1, c2, 3, 2)
     t1 = b.tensor("out1", c2, 4)
     x = b.conv("model.1", x, Slice(t1, 0, c2), 3, 2, ("model.1",), **{"class": "conv3x3"})

@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--roof-steps", type=int, default=10, help="steps of the single-stream HIP-event pass that feeds `roofline`")
     p.add_argument("--streams", type=int, default=int(os.environ.get("AQ_BENCH_STREAMS", 2)),
                    help="independent batches in flight (one HIP stream + workspace each)")
+    p.add_argument("--two-kernel-stem", action="store_true", help="A/B: preprocess + space-to-depth conv instead of the fused stem kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle sample budget")
     p.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristic instead of timing configs")
@@ -109,7 +110,7 @@ def main() -> int:
     dev = torch.device("cuda", local)
 
     ck = checkpoint.synthetic_checkpoint(a.variant, 5)
-    eng = Engine(ck, a.precision, local)
+    eng = Engine(ck, a.precision, local, fused_stem=not a.two_kernel_stem)
     B, K, W = a.batch, a.steps, a.warmup
     tiles_dev = torch.from_numpy(make_tiles(rank, B, a.pool, a.size)).to(dev)
     max_det = 1000
@@ -180,7 +181,7 @@ def main() -> int:
         ms, calls = eng.op_times_ms()
         ops_ms = ms
         idx3 = [i for i, o in enumerate(plan.ops) if o.kind == spec.OP_CONV and o.meta.get("class") == "conv3x3"]
-        idxc = [i for i, o in enumerate(plan.ops) if o.kind == spec.OP_CONV]
+        idxc = [i for i, o in enumerate(plan.ops) if o.kind in (spec.OP_CONV, spec.OP_STEM)]
         t3 = float(ms[idx3].sum()) * 1e-3       # seconds per step in the 3x3 conv launches
         tc = float(ms[idxc].sum()) * 1e-3
         peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS

@@ -46,7 +46,7 @@ typedef enum aq_precision {
 
 typedef enum aq_op_kind {
     AQ_OP_PREPROCESS = 0, AQ_OP_CONV = 1, AQ_OP_SPPF_POOL = 2, AQ_OP_UPSAMPLE2X = 3,
-    AQ_OP_DECODE = 4, AQ_OP_NMS = 5
+    AQ_OP_DECODE = 4, AQ_OP_NMS = 5, AQ_OP_STEM = 6
 } aq_op_kind;
 
 typedef enum aq_tensor_dtype { AQ_T_ACT = 0, AQ_T_F32 = 1, AQ_T_U8 = 2 } aq_tensor_dtype;
@@ -145,6 +145,12 @@ int aq_conv2d(const void* in_dev, int in_ld, int in_choff, int cin,
               const void* packed_w_dev, const float* bias_dev,
               int B, int H, int W, int k, int stride, int pad, int act,
               int precision, int out_f32, const void* zero_page_dev, void* stream);
+/* Fused stem: uint8 RGB tiles [B][H][W][3] -> x/255 -> Conv(3, cout, k=6, s=2, p=2) + bias + SiLU -> NHWC [B][H/2][W/2][cout slice].
+ * Replaces `im.float() / 255` + model.0 of the reference's yolov5 dependency [UPSTREAM detect.py, models/common.py Conv].
+ * packed_w_dev comes from aq_pack_stem_weights (fp32 KRSC (cout, 6, 6, 3), BN folded); cout <= 64, H % 4 == 0, W even. */
+int aq_pack_stem_weights(const float* w_krsc_host, int cout, int precision, void* packed_dev, size_t* bytes, void* stream);
+int aq_stem_conv(const uint8_t* tiles_dev, void* out_dev, int out_ld, int out_choff, int cout, const void* packed_w_dev,
+                 const float* bias_dev, int B, int H, int W, int act, int precision, void* stream);
 /* uint8 RGB NHWC -> 2x2 space-to-depth, 16 channels, value/255 ([UPSTREAM detect.py: im.float()/255]). */
 int aq_preprocess_s2d(const uint8_t* tiles_dev, void* out_dev, int B, int H, int W, int precision, void* stream);
 /* Letterbox on device (the real 1024x1024 tiles of reference src/load_data/tile_tifs.py:13 -> 640x640):

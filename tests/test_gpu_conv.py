@@ -85,3 +85,41 @@ def test_conv_f32_out_head(lib):
     ref = _ref(x, w, b, 1, 0, False, None, True)
     assert out.dtype == torch.float32
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 128, 96), (3, 32, 160), (1, 640, 640)])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_fused_stem_matches_reference(lib, shape, precision):
+    """aq_stem_conv: uint8 tiles -> x/255 -> Conv(3, 48, 6, 2, 2) + bias + SiLU, against F.conv2d on the same values
+    (bf16 mode: inputs and weights rounded to bf16 first, fp32 accumulate).  Widths 96/160 exercise partial 64-column tiles."""
+    from aquaculture_amd import engine
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * 31 + W)
+    x = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    w = torch.randn(48, 3, 6, 6, generator=g) * 0.2
+    b = torch.randn(48, generator=g) * 0.1
+    xin = (x.permute(0, 3, 1, 2).float() / 255)
+    wq = w
+    if precision == "bf16":
+        xin, wq = xin.bfloat16().float(), w.bfloat16().float()
+    ref = F.silu(F.conv2d(xin, wq, b, stride=2, padding=2)).permute(0, 2, 3, 1).contiguous()
+    out = engine.stem_conv_nhwc(x.cuda(), w, b, precision=precision).cpu().float()
+    assert out.shape == ref.shape == (B, H // 2, W // 2, 48)
+    if precision == "fp32":
+        torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-5)
+    else:
+        torch.testing.assert_close(out, ref.bfloat16().float(), rtol=2 ** -7, atol=1e-3)
+
+
+def test_fused_and_two_kernel_stems_agree(lib, synth_ck):
+    """The fused stem and the preprocess + space-to-depth conv path are two routes to the same layer."""
+    from aquaculture_amd import engine, tiles
+    x = torch.from_numpy(tiles.synthetic_batch([0, 19], 128)).cuda()
+    outs = []
+    for fused in (True, False):
+        eng = engine.Engine(synth_ck, "fp32", fused_stem=fused)
+        assert (eng.plan.ops[0].kind == 6) == fused
+        eng.forward_raw(x)
+        torch.cuda.synchronize()
+        outs.append(eng.tensor_by_name("out0", 2).float().cpu().clone())
+    torch.testing.assert_close(outs[0], outs[1], rtol=2e-5, atol=2e-5)

@@ -3,7 +3,7 @@
 
 Runs `bench.py` under `rocprofv3 --pmc` once per counter group (counters in their own passes, with
 kernel-trace only -- never with sys/hip/hsa tracing), maps every kernel dispatch of the timed steps back to its
-plan op by position (each engine step launches a fixed kernel sequence starting with preprocess_s2d_kernel) and
+plan op by position (each engine step launches a fixed kernel sequence starting with the stem kernel) and
 writes a per-op table.  FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for
 gfx950 wide coalesced reads; WRITE_SIZE is taken as is; both are in KiB in rocprofv3's output.
 
@@ -73,8 +73,11 @@ def parse(path):
     return [by_id[k] for k in sorted(by_id)]
 
 
+FIRST_KERNELS = ("stem_conv_kernel", "preprocess_s2d_kernel")   # the kernel a step starts with (fused stem / two-kernel stem)
+
+
 def steps_of(disp, kernels_per_step):
-    starts = [i for i, d in enumerate(disp) if "preprocess_s2d_kernel" in d["name"]]
+    starts = [i for i, d in enumerate(disp) if any(k in d["name"] for k in FIRST_KERNELS)]
     return [disp[s:s + kernels_per_step] for s in starts if s + kernels_per_step <= len(disp)]
 
 
