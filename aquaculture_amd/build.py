@@ -22,6 +22,7 @@ SOURCES = [
     ("conv_igemm.hip", []),
     ("conv_halo.hip", []),
     ("stem_conv.hip", []),
+    ("bottleneck.hip", []),
     ("pointwise.hip", []),
     ("detect_nms.hip", ["-ffp-contract=off"]),   # bit-level parity with the oracle's fp32 op order
     ("engine.cpp", ["-x", "hip"]),

@@ -223,6 +223,14 @@ class PackedConv:
 def pack_plan_weights(ck: Checkpoint, plan: _spec.Plan) -> List[PackedConv]:
     packed = []
     for op in plan.conv_ops():
+        if op.kind == _spec.OP_BOTTLENECK:   # cv1 (C,1,1,C) then cv2 (C,3,3,C), KRSC, flattened back to back; bias b1 | b2
+            (w1, b1), (w2, b2) = (fuse_conv_bn(ck.state, key, ck.bn_eps) for key in op.weight_keys)
+            c_ = op.src.channels
+            assert tuple(w1.shape) == (c_, c_, 1, 1) and tuple(w2.shape) == (c_, c_, 3, 3), (op.name, w1.shape, w2.shape)
+            flat = torch.cat([w1.permute(0, 2, 3, 1).reshape(-1), w2.permute(0, 2, 3, 1).reshape(-1)])
+            packed.append(PackedConv(np.ascontiguousarray(flat.numpy(), dtype=np.float32),
+                                     np.ascontiguousarray(torch.cat([b1, b2]).numpy(), dtype=np.float32)))
+            continue
         ws, bs = [], []
         for key in op.weight_keys:
             if key.startswith("model.24.m."):

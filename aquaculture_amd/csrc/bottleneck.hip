@@ -1,0 +1,496 @@
+// Fused Bottleneck for gfx950, hidden widths C = 16, 32, 48, 64 and 96 (bf16):
+//     y = (x +) SiLU(cv2_3x3(SiLU(cv1_1x1(x) + b1)) + b2)        [UPSTREAM models/common.py Bottleneck.forward]
+// (BN folded into both convolutions; reached through reference README.md:77 -> yolov5/detect.py -> C3.m).
+//
+// At 160x160 / 80x80 with 48 / 96 channels (yolov5m's C3 stages 2, 4 and 17) the two-kernel form is bound by HBM round
+// trips and by the 3x3 kernel re-gathering nine shifted copies of its input through L2: cv1 writes t, cv2 reads it back
+// nine times plus the shortcut.  Here one workgroup owns a small output tile and keeps everything on chip:
+//   A. the input patch x (tile + 1-pixel halo, zero outside the image) goes to LDS once, by LDS-DMA (global_load_lds,
+//      16 B per lane, no registers) into the other half of a double buffer while the previous tile is being computed;
+//   B. t = SiLU(W1 x + b1) is evaluated for EVERY patch pixel (the halo is recomputed) on MFMA and written to a second LDS
+//      patch as bf16 -- exactly the rounding the two-kernel path applies when it stores t; pixels outside the image are
+//      forced to 0 (the 3x3 convolution pads t, not x);
+//   C. the 3x3 convolution reads its MFMA B fragments straight from the t patch (a pixel's 8-channel block of one tap is a
+//      contiguous, 16-byte aligned run), adds the shortcut from the x patch and stores y.
+// The 3x3 weights live in REGISTERS as MFMA A fragments for the life of the persistent workgroup (the small 1x1 set is
+// re-read from LDS once per tile)
+// (v_mfma_f32_16x16x32_bf16, M = C in 16-row blocks, no channel padding), so LDS serves activation fragments only.  That
+// costs up to ~300 VGPRs, hence one wave per SIMD; for C = 96 the output channels are split between two wave groups (each
+// wave keeps 48 of the 96 rows of W1 and W2) and both groups read the same activation fragments.
+// The output must not alias the input (neighbouring tiles read each other's halo): the plan ping-pongs Bottleneck pairs
+// between the C3 concat buffer and its temporary.
+#include "conv_device.h"
+
+using namespace aqdev;
+
+namespace {
+
+struct BtlParams {
+    const char* in;
+    char* out;
+    const char* w;           // A-fragment image, see aq_pack_bottleneck_weights
+    const float* bias;       // [2C]: b1 | b2
+    int in_ld_b, out_ld_b;
+    int B, H, W;
+    int tiles_x, tiles_y, n_tiles;
+    int shortcut;
+    unsigned long long* debug;   // STAMP builds only (tools/stamp_conv.py)
+    const char* zero;            // >= 16 zero bytes: DMA source for pixels outside the image
+};
+
+// MBW: 16-row M blocks per wave; MSPLIT: wave groups that split the output channels; TW: tile width in pixels.
+template <int MBW, int MSPLIT, int TW> struct BtlGeom {
+    static constexpr int C = 16 * MBW * MSPLIT;
+    static constexpr int CB = C / 8;                       // 8-channel (16-byte) blocks per pixel
+    static constexpr int PG = 4 / MSPLIT;                  // pixel groups (waves that own different rows)
+    static constexpr int TH = 4 * PG;                      // every wave owns 4 output rows
+    static constexpr int PH = TH + 2, PW = TW + 2, PP = PH * PW;
+    static constexpr int PXB = C * 2 + 16;                 // LDS pixel stride: +16 B puts 16 consecutive pixels on distinct banks
+    static constexpr int KS1 = (CB + 3) / 4;               // k-steps (32 K each) of the 1x1
+    static constexpr int NBLK2 = 9 * CB;                   // K blocks of the 3x3, tap-major
+    static constexpr int KS2 = (NBLK2 + 3) / 4;
+    static constexpr bool UNIFORM_K = CB % 4 == 0;         // a k-step never straddles taps: K offsets are compile-time + 16 g
+    static constexpr int SPP = CB + 1;                     // 16-byte LDS slots per pixel (channels + the pad slot)
+    static constexpr int NQ = (PP * SPP + 63) / 64;        // LDS-DMA wave instructions per x patch (64 slots each)
+    static constexpr int PATCHB = NQ * 1024;               // patch buffer, rounded up to whole DMA instructions
+    static constexpr int W1B = MSPLIT * KS1 * MBW * 1024;  // A fragments of the 1x1 (reloaded into registers every phase B)
+    static constexpr int KTAIL = MBW * KS2 > 64 ? 3 : 0;   // last k-steps of W2 that stay in LDS instead of
+    static constexpr int KREG = KS2 - KTAIL;               // registers (C = 96: 3 of 27, C = 64: 3 of 18): keeps the kernel spill-free
+    static constexpr int W2TB = MSPLIT * KTAIL * MBW * 1024;
+    static constexpr int LDS = 3 * PATCHB + W1B + W2TB + 2 * C * 4;   // x patch (double buffered) | t patch | W1 | W2 tail | b1 | b2
+    static constexpr int NBLK1 = (PP + 15) / 16;           // 16-pixel MFMA column blocks of phase B
+    static constexpr int NBR = TW / 16;                    // 16-pixel blocks per output row
+    static constexpr int RB = 4 / NBR;                     // rows per phase-C step (always 4 pixel blocks per step)
+    static constexpr int STEPS = 4 / RB;                   // phase-C steps per tile (a wave owns 4 rows)
+    static constexpr int WFRAGS = (KS1 + KS2) * MBW;       // A fragments per wave group
+    static constexpr int NST = 4 * MBW;                    // output store instructions per wave and phase-C step (full tile)
+    static_assert(TW == 16 || TW == 32, "tile width");
+    static_assert(LDS <= 160 * 1024, "LDS");
+};
+
+// LDS write the compiler cannot see as one: LLVM's waitcnt pass makes every visible LDS store wait for ALL outstanding
+// LDS-DMA (vmcnt(0)), which would drain the next tile's prefetch at the first write of phase B.  Ordering against the
+// reads of other waves is by lds_barrier() below.
+__device__ __forceinline__ void lds_write_b64(char* dst, uint2 v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"((uint32_t)(uintptr_t)dst), "v"(v));
+}
+// All of this wave's LDS operations are done, then the workgroup barrier -- without the vmcnt(0) a __syncthreads() adds.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ f32x4 silu4(f32x4 v) {          // same sequence as the shared conv epilogue (bf16 mode)
+    const f32x4 t = v * -1.44269504f;
+    f32x4 d = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]), __builtin_amdgcn_exp2f(t[3])};
+    d = d + 1.0f;
+    const f32x4 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
+    return v * r;
+}
+
+template <int MBW, int MSPLIT, int TW, bool STAMP = false>
+__global__ __launch_bounds__(256) void bottleneck_kernel(const BtlParams p) {
+    using G = BtlGeom<MBW, MSPLIT, TW>;
+    constexpr int CB = G::CB, PXB = G::PXB, KS1 = G::KS1, KS2 = G::KS2, PW = G::PW, PP = G::PP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_t = smem + 2 * G::PATCHB;                        // x patches at smem + {0, PATCHB}
+    char* s_w1 = smem + 3 * G::PATCHB;
+    char* s_w2t = s_w1 + G::W1B;
+    float* s_b = (float*)(s_w2t + G::W2TB);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mh = wave % MSPLIT, pg = wave / MSPLIT;       // this wave's channel group / pixel group
+    const int g = lane >> 4, l15 = lane & 15;
+    const int H = p.H, W = p.W;
+    const int cbase = mh * MBW * 16 + g * 4;                 // first of this lane's 4 output channels in M block 0
+
+    // diagnostic build only (STAMP): per-wave cycle sums of 8 phases -> p.debug; the shipped kernels contain no stamp.
+    // 0 prologue | 1 vmcnt wait | 2 tile barrier | 3 DMA issue | 4 phase B | 5 mid barrier | 6 phase C MFMA | 7 phase C epilogue
+    unsigned long long ph_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ph_t = 0;
+    if constexpr (STAMP) ph_t = clock64();
+    auto stamp = [&](int ph) {
+        if constexpr (STAMP) {
+            const unsigned long long t = clock64();
+            ph_sum[ph] += t - ph_t;
+            ph_t = t;
+        }
+    };
+
+    // ---- once per workgroup: this wave group's rows of both weight sets to registers, biases to LDS ----
+    constexpr int KREG = G::KREG;
+    bf16x8 a2[KREG][MBW];
+    {
+        const bf16x8* wsrc = (const bf16x8*)p.w + (size_t)mh * G::WFRAGS * 64 + lane;
+        if (pg == 0) {                                       // one wave per channel group copies its W1 fragments to LDS
+#pragma unroll
+            for (int i = 0; i < KS1 * MBW; ++i) *(bf16x8*)(s_w1 + (mh * KS1 * MBW + i) * 1024 + lane * 16) = wsrc[i * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < KREG; ++s)
+#pragma unroll
+            for (int m = 0; m < MBW; ++m) a2[s][m] = wsrc[((KS1 + s) * MBW + m) * 64];
+        if (pg == 0) {
+#pragma unroll
+            for (int i = 0; i < G::KTAIL * MBW; ++i)
+                *(bf16x8*)(s_w2t + (mh * G::KTAIL * MBW + i) * 1024 + lane * 16) = wsrc[((KS1 + KREG) * MBW + i) * 64];
+        }
+    }
+    for (int i = tid; i < 2 * G::C; i += 256) s_b[i] = p.bias[i];
+    // per-lane byte offset of this lane's K block: inside a pixel (1x1) / relative to the tap-(0,0) pixel (3x3).  K blocks
+    // past the end carry zero weights and read block 0 (any initialised address would do).
+    int koff1[G::UNIFORM_K ? 1 : KS1], koff2[G::UNIFORM_K ? 1 : KS2];
+    if constexpr (G::UNIFORM_K) {
+        koff1[0] = koff2[0] = g * 16;
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+            const int blk = 4 * s + g;
+            koff1[s] = blk < CB ? blk * 16 : 0;
+        }
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) {
+            int blk = 4 * s + g;
+            if (blk >= G::NBLK2) blk = 0;
+            const int tap = blk / CB, cb = blk - tap * CB;
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            koff2[s] = (dy * PW + dx) * PXB + cb * 16;
+        }
+    }
+    auto k1 = [&](int s) -> int {                            // s is a compile-time constant after unrolling
+        if constexpr (G::UNIFORM_K) return koff1[0] + 4 * s * 16;
+        else return koff1[s];
+    };
+    auto k2 = [&](int s) -> int {
+        if constexpr (G::UNIFORM_K) {
+            const int tap = (4 * s) / CB, cb0 = 4 * s - tap * CB;
+            return koff2[0] + ((tap / 3) * PW + tap % 3) * PXB + cb0 * 16;
+        } else return koff2[s];
+    };
+
+    const int tiles_per_img = p.tiles_y * p.tiles_x;
+    // x patch of `tile` -> LDS buffer xb, asynchronously: wave w issues DMA instructions w, w+4, ...; instruction q fills the
+    // 64 consecutive 16-byte slots [64 q, 64 q + 64) of the patch image (slot = pixel * SPP + part; part == CB is the pad).
+    // Pixels outside the image, pad slots and slots past the patch read the zero page.
+    struct PatchOrg { const char* org; int y0, x0; };      // address of patch pixel (0, 0) (may lie outside the image) + tile origin
+    auto patch_org = [&](int tile) -> PatchOrg {
+        const int b = tile / tiles_per_img, tr = tile - b * tiles_per_img;
+        const int ty0 = tr / p.tiles_x, tx0 = tr - ty0 * p.tiles_x;
+        const int y0 = ty0 * G::TH, x0 = tx0 * TW;
+        return {p.in + ((long long)(b * H + y0 - 1) * W + (x0 - 1)) * p.in_ld_b, y0, x0};
+    };
+    auto dma_one = [&](const PatchOrg& o, int q, char* xb) {  // branch-free: it is issued from inside the MFMA loop
+        const int slot = q * 64 + lane;
+        const int px = slot / G::SPP, part = slot - px * G::SPP;
+        const int pr = px / PW, pc = px - pr * PW;
+        const int iy = o.y0 - 1 + pr, ix = o.x0 - 1 + pc;
+        const bool valid = px < PP && part < CB && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const char* src = o.org + (pr * W + pc) * p.in_ld_b + part * 16;
+        glds16(valid ? src : p.zero, xb + q * 1024);
+    };
+    auto issue_dma = [&](int tile, char* xb) {
+        const PatchOrg o = patch_org(tile);
+#pragma unroll 1
+        for (int q = wave; q < G::NQ; q += 4) dma_one(o, q, xb);
+    };
+    // The next tile's DMA instructions are normally issued from INSIDE the phase-C MFMA loop (their address arithmetic fills
+    // VALU slots the matrix pipe leaves free); PER of them per phase-C step, one every SP k-steps.
+    constexpr int STEPS = G::STEPS, NQW = (G::NQ + 3) / 4, PER = (NQW + STEPS - 1) / STEPS;
+    constexpr int SP = KS2 / PER >= 1 ? KS2 / PER : 1;
+    static_assert(PER * SP <= KS2, "not enough k-steps to carry the DMA issue");
+
+    int tile = first_tile(gridDim.x, blockIdx.x);
+    if (tile < p.n_tiles) issue_dma(tile, smem);
+    stamp(0);
+    int cur = 0;
+    bool prev_full = false;                                  // first tile: nothing but the DMA is outstanding, wait for all of it
+    for (; tile < p.n_tiles; tile += gridDim.x, cur ^= 1) {
+        const int b = tile / tiles_per_img, tr = tile - b * tiles_per_img;
+        const int ty0 = tr / p.tiles_x, tx0 = tr - ty0 * p.tiles_x;
+        const int y0 = ty0 * G::TH, x0 = tx0 * TW;
+        const char* s_x = smem + cur * G::PATCHB;
+        // ---- A. this tile's x patch has landed (own DMA: vmcnt, the other waves': barrier); every wave is also done with
+        //      the previous tile, so the other x buffer and the t patch are free: start the next tile's DMA ----
+        // (vmcnt is in-order.  After a full tile the youngest DMA instruction is older than the last phase-C step's
+        //  4 * MBW output stores, which may stay in flight; after a ragged one everything is drained.)
+        if (prev_full) wait_vmcnt<G::NST>(); else wait_vmcnt<0>();
+        stamp(1);
+        lds_barrier();
+        stamp(2);
+        const bool has_next = tile + (int)gridDim.x < p.n_tiles;
+        prev_full = y0 + G::TH <= H && x0 + TW <= W;         // every store instruction of this tile has active lanes
+        char* xbn = smem + (cur ^ 1) * G::PATCHB;
+        PatchOrg on = {nullptr, 0, 0};
+        if (has_next) on = patch_org(tile + (int)gridDim.x);
+        stamp(3);
+        // ---- B. t = SiLU(W1 x + b1) on all patch pixels: two 16-pixel blocks per step, this wave's channel group ----
+        {
+            f32x4 b1v[MBW];
+            bf16x8 a1[KS1][MBW];                             // live in this phase only: phase C needs the registers
+#pragma unroll
+            for (int m = 0; m < MBW; ++m) b1v[m] = *(const f32x4*)(s_b + cbase + m * 16);
+#pragma unroll
+            for (int s = 0; s < KS1; ++s)
+#pragma unroll
+                for (int m = 0; m < MBW; ++m) a1[s][m] = *(const bf16x8*)(s_w1 + ((mh * KS1 + s) * MBW + m) * 1024 + lane * 16);
+#pragma unroll 1
+            for (int nb0 = pg; nb0 < G::NBLK1; nb0 += 2 * G::PG) {
+                int px[2], pxc[2];
+                f32x4 acc[2][MBW];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    px[j] = (nb0 + j * G::PG) * 16 + l15;    // the second block may lie past the patch: clamped reads, no writes
+                    pxc[j] = px[j] < PP ? px[j] : PP - 1;
+#pragma unroll
+                    for (int m = 0; m < MBW; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                bf16x8 f[KS1][2];
+#pragma unroll
+                for (int s = 0; s < KS1; ++s)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) f[s][j] = *(const bf16x8*)(s_x + pxc[j] * PXB + k1(s));
+#pragma unroll
+                for (int s = 0; s < KS1; ++s)
+#pragma unroll
+                    for (int m = 0; m < MBW; ++m)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[s][m], f[s][j], acc[j][m], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int pr = pxc[j] / PW, pc = pxc[j] - pr * PW;
+                    const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
+                    const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
+#pragma unroll
+                    for (int m = 0; m < MBW; ++m) {
+                        const f32x4 v = silu4(acc[j][m] + b1v[m]);
+                        uint2 o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        if (!inside) o = make_uint2(0, 0);   // zero padding of the 3x3 applies to t
+                        if (px[j] < PP) lds_write_b64(s_t + px[j] * PXB + (cbase + m * 16) * 2, o);
+                    }
+                }
+            }
+        }
+        stamp(4);
+        lds_barrier();
+        stamp(5);
+        // ---- C. y = (x +) SiLU(W2 (*) t + b2): FOUR 16-pixel blocks per k-step (4 rows of 16 or 2 rows of 32).  The
+        //      compiler keeps most of W2 in AccVGPRs and copies each fragment to VGPRs before use (4 x v_accvgpr_read);
+        //      with four MFMAs per fragment the loop is bound by the matrix pipe (64 cycles per fragment against 48 issue
+        //      cycles), and the spare issue slots carry the next tile's DMA address arithmetic. ----
+        {
+#pragma unroll 1
+            for (int st = 0; st < G::STEPS; ++st) {
+                const int ty = 4 * pg + st * G::RB;
+                // block j: row ty + j / NBR, columns 16 * (j % NBR) ..
+                int boff[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) boff[j] = ((j / G::NBR) * PW + 16 * (j % G::NBR)) * PXB;
+                const char* base = s_t + (ty * PW + l15) * PXB;
+                f32x4 acc[4][MBW];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < MBW; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                constexpr int D = 1;                         // fragments are fetched one k-step (12+ MFMAs, >= 192 cycles) ahead
+                bf16x8 fq[D][4];
+#pragma unroll
+                for (int s = 0; s < D; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fq[s][j] = *(const bf16x8*)(base + boff[j] + k2(s));
+#pragma unroll
+                for (int s = 0; s < KS2; ++s) {
+                    bf16x8 f[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[j] = fq[s % D][j];
+                    if (s + D < KS2) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) fq[s % D][j] = *(const bf16x8*)(base + boff[j] + k2(s + D));
+                    }
+                    if (s % SP == 0 && s / SP < PER) {       // one DMA instruction of the next tile's x patch
+                        const int q = wave + 4 * (st * PER + s / SP);
+                        if (has_next && q < G::NQ) dma_one(on, q, xbn);
+                    }
+#pragma unroll
+                    for (int m = 0; m < MBW; ++m) {
+                        bf16x8 am;
+                        if constexpr (G::KTAIL > 0) {
+                            if (s >= KREG) am = *(const bf16x8*)(s_w2t + ((mh * G::KTAIL + (s - KREG)) * MBW + m) * 1024 + lane * 16);
+                            else am = a2[s < KREG ? s : 0][m];
+                        } else am = a2[s][m];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, f[j], acc[j][m], 0, 0, 0);
+                    }
+                }
+                if constexpr (STAMP) asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[3][MBW - 1][3]));
+                stamp(6);
+                f32x4 b2v[MBW];
+#pragma unroll
+                for (int m = 0; m < MBW; ++m) b2v[m] = *(const f32x4*)(s_b + G::C + cbase + m * 16);
+                const char* xc = s_x + ((ty + 1) * PW + l15 + 1) * PXB + cbase * 2;   // shortcut: centre pixel of the x patch
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int y = y0 + ty + j / G::NBR, x = x0 + 16 * (j % G::NBR) + l15;
+                    const bool ok = y < H && x < W;
+                    char* o = p.out + ((long long)(b * H + y) * W + x) * p.out_ld_b + cbase * 2;
+                    uint2 xr[MBW];
+                    if (p.shortcut) {
+#pragma unroll
+                        for (int m = 0; m < MBW; ++m) xr[m] = *(const uint2*)(xc + boff[j] + m * 32);
+                    }
+#pragma unroll
+                    for (int m = 0; m < MBW; ++m) {
+                        f32x4 v = silu4(acc[j][m] + b2v[m]);
+                        if (p.shortcut) {
+                            v[0] += __uint_as_float(xr[m].x << 16);
+                            v[1] += __uint_as_float(xr[m].x & 0xffff0000u);
+                            v[2] += __uint_as_float(xr[m].y << 16);
+                            v[3] += __uint_as_float(xr[m].y & 0xffff0000u);
+                        }
+                        if (ok) *(uint2*)(o + m * 32) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    }
+                }
+                stamp(7);
+            }
+        }
+    }
+    if constexpr (STAMP) {
+        if (lane == 0 && p.debug)
+            for (int i = 0; i < 8; ++i) p.debug[((long long)blockIdx.x * 4 + wave) * 8 + i] = ph_sum[i];
+    }
+}
+
+int g_btl_cus = 0;
+
+struct BtlShape { int mbw, msplit, tw; };
+
+bool btl_shape(int C, BtlShape* s) {
+    switch (C) {
+        case 16: *s = {1, 1, 32}; return true;
+        case 32: *s = {2, 1, 32}; return true;
+        case 48: *s = {3, 1, 16}; return true;
+        case 64: *s = {4, 1, 16}; return true;
+        case 96: *s = {3, 2, 16}; return true;
+    }
+    return false;
+}
+
+template <int MBW, int MSPLIT, int TW>
+int launch_btl(BtlParams p, hipStream_t stream) {
+    using G = BtlGeom<MBW, MSPLIT, TW>;
+    static int occ = 0;                                      // resident workgroups per CU (registers + LDS)
+    auto fn = bottleneck_kernel<MBW, MSPLIT, TW>;
+    if constexpr ((MBW == 3) && TW == 16) {                  // stamped diagnostic builds exist for C = 48 and C = 96
+        size_t sbytes = 0;
+        unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
+        if (sbuf && (size_t)g_btl_cus * 4 * 64 <= sbytes) {
+            auto sfn = bottleneck_kernel<MBW, MSPLIT, TW, true>;
+            AQ_CHECK_HIP(hipFuncSetAttribute((const void*)sfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+            p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + G::TH - 1) / G::TH;
+            p.n_tiles = p.B * p.tiles_x * p.tiles_y;
+            p.debug = sbuf;
+            const long long sgrid = g_btl_cus < p.n_tiles ? g_btl_cus : p.n_tiles;
+            hipLaunchKernelGGL(sfn, dim3((unsigned)sgrid), dim3(256), G::LDS, stream, p);
+            AQ_CHECK_HIP(hipGetLastError());
+            return AQ_OK;
+        }
+    }
+    constexpr size_t lds = G::LDS;
+    if (!occ) {
+        AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int o = 0;
+        AQ_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)fn, 256, lds));
+        occ = o > 0 ? o : 1;                                 // a persistent grid must be fully resident
+    }
+    p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + G::TH - 1) / G::TH;
+    AQ_REQUIRE((long long)p.B * p.tiles_x * p.tiles_y < (1LL << 30), "bottleneck: batch too large");
+    p.n_tiles = p.B * p.tiles_x * p.tiles_y;
+    long long grid = (long long)g_btl_cus * occ;
+    if (grid > p.n_tiles) grid = p.n_tiles;
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, stream, p);
+    AQ_CHECK_HIP(hipGetLastError());
+    return AQ_OK;
+}
+
+}  // namespace
+
+// Packs the fused fp32 weights of one Bottleneck -- w1 KRSC (C,1,1,C), w2 KRSC (C,3,3,C) -- into the A-fragment image the
+// kernel loads once per workgroup: [channel group][k-step][M block][lane] x 8 bf16.  Lane (m = lane & 15, g = lane >> 4) of
+// M block mb in channel group mh holds output channel 16 * (mh * MBW + mb) + m and K block 4 * kstep + g (8 consecutive
+// input channels of one tap, tap-major); first the 1x1's k-steps, then the 3x3's.  K blocks past the end are zero.
+extern "C" int aq_pack_bottleneck_weights(const float* w1_host, const float* w2_host, int C, void* packed_dev, size_t* bytes, void* stream) {
+    BtlShape sh;
+    AQ_REQUIRE(w1_host && w2_host && bytes && btl_shape(C, &sh), "pack_bottleneck: C must be 16, 32, 48, 64 or 96 (got %d)", C);
+    const int cb = C / 8, ks1 = (cb + 3) / 4, ks2 = (9 * cb + 3) / 4;
+    const size_t frags = (size_t)sh.msplit * (ks1 + ks2) * sh.mbw;
+    *bytes = frags * 64 * 16;
+    if (!packed_dev) return AQ_OK;
+    bf16_t* host = (bf16_t*)calloc(1, *bytes);
+    AQ_REQUIRE(host, "pack_bottleneck: out of host memory");
+    for (int mh = 0; mh < sh.msplit; ++mh)
+        for (int s = 0; s < ks1 + ks2; ++s)
+            for (int m = 0; m < sh.mbw; ++m)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = (mh * sh.mbw + m) * 16 + (lane & 15), g = lane >> 4;
+                    bf16_t* dst = host + ((((size_t)mh * (ks1 + ks2) + s) * sh.mbw + m) * 64 + lane) * 8;
+                    if (s < ks1) {
+                        const int blk = 4 * s + g;
+                        if (blk < cb)
+                            for (int e = 0; e < 8; ++e) dst[e] = aq_f2bf(w1_host[(size_t)co * C + blk * 8 + e]);
+                    } else {
+                        const int blk = 4 * (s - ks1) + g;
+                        if (blk < 9 * cb) {
+                            const int tap = blk / cb, c8 = blk % cb;
+                            for (int e = 0; e < 8; ++e) dst[e] = aq_f2bf(w2_host[((size_t)co * 9 + tap) * C + c8 * 8 + e]);
+                        }
+                    }
+                }
+    hipError_t e = hipMemcpyAsync(packed_dev, host, *bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    free(host);
+    AQ_CHECK_HIP(e);
+    return AQ_OK;
+}
+
+// in/out: bf16 NHWC [B][H][W][ld] with the C channels at ch_off; out must not overlap in.  bias_dev: [2C] fp32 (b1 | b2).
+extern "C" int aq_bottleneck(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff, int C,
+                             const void* packed_w_dev, const float* bias_dev, int B, int H, int W, int shortcut, void* stream) {
+    BtlShape sh;
+    AQ_REQUIRE(in_dev && out_dev && packed_w_dev && bias_dev, "bottleneck: null pointer");
+    AQ_REQUIRE(btl_shape(C, &sh), "bottleneck: C must be 16, 32, 48, 64 or 96 (got %d)", C);
+    AQ_REQUIRE(B > 0 && H > 0 && W > 0, "bottleneck: empty input");
+    AQ_REQUIRE(in_ld % 8 == 0 && out_ld % 8 == 0 && in_choff % 8 == 0 && out_choff % 8 == 0 && in_choff + C <= in_ld && out_choff + C <= out_ld,
+               "bottleneck: channel slices must be 8-aligned and inside their rows");
+    AQ_REQUIRE((long long)B * H * W < (1LL << 31), "bottleneck: batch too large");
+    BtlParams p{};
+    p.in = (const char*)in_dev + (size_t)in_choff * 2; p.in_ld_b = in_ld * 2;
+    p.out = (char*)out_dev + (size_t)out_choff * 2; p.out_ld_b = out_ld * 2;
+    {   // the kernel reads halos of pixels other workgroups write: refuse aliasing buffers
+        const char* i0 = (const char*)in_dev; const char* i1 = i0 + (size_t)B * H * W * in_ld * 2;
+        const char* o0 = (const char*)out_dev; const char* o1 = o0 + (size_t)B * H * W * out_ld * 2;
+        AQ_REQUIRE(o1 <= i0 || i1 <= o0, "bottleneck: output overlaps input");
+    }
+    p.w = (const char*)packed_w_dev; p.bias = bias_dev;
+    p.B = B; p.H = H; p.W = W; p.shortcut = shortcut;
+    static void* zero_page = nullptr;                        // allocated once per process (the engine never frees it)
+    if (!zero_page) {
+        AQ_CHECK_HIP(hipMalloc(&zero_page, 256));
+        AQ_CHECK_HIP(hipMemset(zero_page, 0, 256));
+    }
+    p.zero = (const char*)zero_page;
+    if (g_btl_cus == 0) {
+        int dev = 0, cus = 256;
+        AQ_CHECK_HIP(hipGetDevice(&dev));
+        AQ_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        g_btl_cus = cus;
+    }
+    const hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+        case 16: return launch_btl<1, 1, 32>(p, st);
+        case 32: return launch_btl<2, 1, 32>(p, st);
+        case 48: return launch_btl<3, 1, 16>(p, st);
+        case 64: return launch_btl<4, 1, 16>(p, st);
+        default: return launch_btl<3, 2, 16>(p, st);
+    }
+}

@@ -33,6 +33,14 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// LDS store the compiler cannot see as one.  LLVM's waitcnt pass makes every visible LDS store wait for ALL outstanding
+// LDS-DMA (s_waitcnt vmcnt(0)): in the epilogue that would drain the next tile's prefetch, which is exactly what the
+// epilogue is meant to overlap.  The "memory" clobber keeps the compiler from moving other LDS accesses across it; the
+// hardware executes one wave's LDS operations in order, and readers wait with an explicit s_waitcnt lgkmcnt(0).
+__device__ __forceinline__ void lds_write_b128(char* dst, f32x4 v) {
+    asm volatile("ds_write_b128 %0, %1" ::"v"((uint32_t)(uintptr_t)dst), "v"(v) : "memory");
+}
+
 constexpr int kStgRow = 32 * 4 + 16;          // padded fp32 row of the 32x32 epilogue staging block
 constexpr int kStgBytes = 32 * kStgRow;       // per wave
 
@@ -94,7 +102,7 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, f32x16 (&acc
                         v = v * r;
                     }
                 }
-                *(f32x4*)(stg + l31 * kStgRow + cl * 4) = v;
+                lds_write_b128(stg + l31 * kStgRow + cl * 4, v);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();

@@ -189,6 +189,13 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
             rc = aq_stem_conv(tiles, tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
                               op.dst.channels, e->packed[oi].w, e->packed[oi].bias, B, H, W, op.act, prec, stream);
             break;
+        case AQ_OP_BOTTLENECK: {
+            const TensorPlace& pl = e->place[op.src.tensor];
+            rc = aq_bottleneck(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
+                               tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
+                               op.src.channels, e->packed[oi].w, e->packed[oi].bias, B, pl.h, pl.w, op.res.tensor >= 0, stream);
+            break;
+        }
         case AQ_OP_SPPF_POOL: {
             const TensorPlace& pl = e->place[op.src.tensor];
             rc = aq_sppf_pool(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
@@ -332,6 +339,28 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
             if (aq_pack_stem_weights(op.weight, op.dst.channels, d->precision, pw.w, &nb, nullptr) != AQ_OK ||
                 hipMemcpy(pw.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
                 aq_set_error("engine_create: stem weight upload failed");
+                return fail(AQ_ERR_HIP);
+            }
+            op.weight = nullptr; op.bias = nullptr;
+            continue;
+        }
+        if (op.kind == AQ_OP_BOTTLENECK) {
+            PackedW& pw = e->packed[oi];
+            const int C = op.src.channels;
+            size_t nb = 0;
+            if (!op.weight || !op.bias || d->precision != AQ_BF16 || op.k != 3 || op.stride != 1 || op.pad != 1 || op.dst.channels != C ||
+                op.src.tensor == op.dst.tensor ||
+                aq_pack_bottleneck_weights(op.weight, op.weight + (size_t)C * C, C, nullptr, &nb, nullptr) != AQ_OK) {
+                aq_set_error("engine_create: bottleneck op %zu unsupported (bf16, C in {16,32,48,64,96}, distinct src/dst tensors)", oi);
+                return fail(AQ_ERR_INVALID);
+            }
+            if (hipMalloc(&pw.w, nb) != hipSuccess || hipMalloc((void**)&pw.bias, 2 * C * sizeof(float)) != hipSuccess) {
+                aq_set_error("engine_create: bottleneck weight allocation failed");
+                return fail(AQ_ERR_NOMEM);
+            }
+            if (aq_pack_bottleneck_weights(op.weight, op.weight + (size_t)C * C, C, pw.w, &nb, nullptr) != AQ_OK ||
+                hipMemcpy(pw.bias, op.bias, 2 * C * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+                aq_set_error("engine_create: bottleneck weight upload failed");
                 return fail(AQ_ERR_HIP);
             }
             op.weight = nullptr; op.bias = nullptr;

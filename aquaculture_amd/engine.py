@@ -63,7 +63,7 @@ EXPORTS = (
     "aq_engine_infer", "aq_engine_forward_raw", "aq_engine_tensor_ptr", "aq_engine_profile",
     "aq_engine_op_times", "aq_engine_num_ops", "aq_engine_set_conv_config", "aq_engine_autotune",
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
-    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_preprocess_s2d", "aq_sppf_pool",
+    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
 
@@ -102,6 +102,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
                               i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.aq_pack_stem_weights.argtypes = [C.POINTER(f32), i32, i32, vp, C.POINTER(sz), vp]
     lib.aq_stem_conv.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.aq_pack_bottleneck_weights.argtypes = [C.POINTER(f32), C.POINTER(f32), i32, vp, C.POINTER(sz), vp]
+    lib.aq_bottleneck.argtypes = [vp, i32, i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp]
     lib.aq_preprocess_s2d.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.aq_sppf_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.aq_upsample2x.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -138,13 +140,19 @@ def _act_dtype(precision: int) -> torch.dtype:
 class Engine:
     """YOLOv5 tile engine on one GPU.  Owns the C engine (packed weights) and a workspace tensor."""
 
-    def __init__(self, ck: Checkpoint, precision: str = "bf16", device: int = 0, fused_stem: bool = True):
+    def __init__(self, ck: Checkpoint, precision: str = "bf16", device: int = 0, fused_stem: bool = True,
+                 fused_bottleneck: Optional[bool] = None):
+        """``fused_bottleneck``: None = on for bf16 engines (the fused kernel is bf16 only), off for fp32 parity engines."""
         _require_gpu()
         self.lib = load_library()
         self.ck = ck
         self.precision = PRECISIONS[precision]
         self.device = torch.device("cuda", device)
-        self.plan = _spec.build_plan(ck.variant, ck.nc, ck.na, fused_stem=fused_stem)
+        if fused_bottleneck is None:
+            fused_bottleneck = precision == "bf16"
+        if fused_bottleneck and precision != "bf16":
+            raise ValueError("the fused Bottleneck kernel is bf16 only")
+        self.plan = _spec.build_plan(ck.variant, ck.nc, ck.na, fused_stem=fused_stem, fused_bottleneck=fused_bottleneck)
         self.no = ck.nc + 5
         packed = pack_plan_weights(ck, self.plan)
         self._keep = packed   # host arrays must outlive aq_engine_create only, kept for debugging
@@ -162,7 +170,7 @@ class Engine:
                 setattr(d, name, aq_slice(s.tensor, s.ch_off, s.channels) if s is not None else aq_slice(-1, 0, 0))
             d.k, d.stride, d.pad, d.act, d.level = o.k, o.stride, o.pad, o.act, o.level
             d.flops_per_tile = o.flops_per_tile
-            if o.kind in (_spec.OP_CONV, _spec.OP_STEM):
+            if o.kind in (_spec.OP_CONV, _spec.OP_STEM, _spec.OP_BOTTLENECK):
                 pw = packed[ci]
                 ci += 1
                 d.weight = pw.weight.ctypes.data_as(C.POINTER(C.c_float))
@@ -441,5 +449,33 @@ def stem_conv_nhwc(tiles_u8: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Ten
     out = torch.empty((B, H // 2, W // 2, cout), dtype=_act_dtype(prec), device=tiles_u8.device)
     _check(lib.aq_stem_conv(tiles_u8.data_ptr(), out.data_ptr(), cout, 0, cout, wbuf.data_ptr(), bbuf.data_ptr(), B, H, W, int(act), prec,
                             _stream_ptr()))
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
+def bottleneck_nhwc(x: torch.Tensor, w1_oihw: torch.Tensor, b1: torch.Tensor, w2_oihw: torch.Tensor, b2: torch.Tensor,
+                    shortcut: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 NHWC [B,H,W,C] (may be a channel slice of a wider tensor) -> x + SiLU(conv3x3(SiLU(conv1x1(x)))) through
+    aq_bottleneck (tests).  ``out`` may be a channel slice too; it must not overlap ``x``."""
+    _require_gpu()
+    lib = load_library()
+    assert x.dtype == torch.bfloat16 and x.stride(3) == 1
+    B, H, W, c = x.shape
+    ld = x.stride(2)
+    assert x.stride(1) == W * ld and x.stride(0) == H * W * ld, "x must be a channel slice of a dense NHWC tensor"
+    w1 = np.ascontiguousarray(w1_oihw.permute(0, 2, 3, 1).float().cpu().numpy())
+    w2 = np.ascontiguousarray(w2_oihw.permute(0, 2, 3, 1).float().cpu().numpy())
+    n = C.c_size_t()
+    p1, p2 = w1.ctypes.data_as(C.POINTER(C.c_float)), w2.ctypes.data_as(C.POINTER(C.c_float))
+    _check(lib.aq_pack_bottleneck_weights(p1, p2, c, None, C.byref(n), None))
+    wbuf = torch.empty(n.value, dtype=torch.uint8, device=x.device)
+    _check(lib.aq_pack_bottleneck_weights(p1, p2, c, wbuf.data_ptr(), C.byref(n), _stream_ptr()))
+    bbuf = torch.cat([b1.float(), b2.float()]).to(x.device).contiguous()
+    if out is None:
+        out = torch.empty((B, H, W, c), dtype=torch.bfloat16, device=x.device)
+    old = out.stride(2)
+    # data_ptr() of a channel slice already points at its first channel: pass ch_off = 0 with the parent's row length
+    _check(lib.aq_bottleneck(x.data_ptr(), ld, 0, out.data_ptr(), old, 0, c, wbuf.data_ptr(), bbuf.data_ptr(), B, H, W, int(shortcut),
+                             _stream_ptr()))
     torch.cuda.current_stream().synchronize()
     return out

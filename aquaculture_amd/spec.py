@@ -28,6 +28,7 @@ OP_UPSAMPLE2X = 3   # nearest 2x into a channel slice
 OP_DECODE = 4       # sigmoid + grid/anchor decode + obj threshold + compaction
 OP_NMS = 5          # per-tile class-offset greedy NMS
 OP_STEM = 6         # fused u8 -> /255 -> Conv(3, C, 6, 2, 2) + SiLU (stem_conv.hip)
+OP_BOTTLENECK = 7   # fused Bottleneck (1x1 -> 3x3 -> + shortcut) for small hidden widths, bf16 engines only
 
 VARIANTS = {
     # name: (depth_multiple, width_multiple)   [UPSTREAM models/yolov5{n,s,m,l,x}.yaml]
@@ -104,7 +105,7 @@ class Plan:
 
     def conv_ops(self) -> List[Op]:
         """Ops that carry weights (implicit-GEMM convs and the fused stem), in plan order."""
-        return [o for o in self.ops if o.kind in (OP_CONV, OP_STEM)]
+        return [o for o in self.ops if o.kind in (OP_CONV, OP_STEM, OP_BOTTLENECK)]
 
     def flops(self, h: int, w: int) -> Dict[str, float]:
         """Algorithmic FLOPs per tile (2 x MAC, true Cin of the upstream layer, no padding)."""
@@ -112,6 +113,13 @@ class Plan:
         for o in self.conv_ops():
             down = self.tensors[o.dst.tensor].down
             ho, wo = h // down, w // down
+            if o.kind == OP_BOTTLENECK:       # cv1 (1x1) + cv2 (3x3), both C -> C
+                f1 = 2.0 * ho * wo * o.dst.channels * o.src.channels
+                o.flops_per_tile = 10.0 * f1
+                out["total"] += 10.0 * f1
+                out["conv1x1"] += f1
+                out["conv3x3"] += 9.0 * f1
+                continue
             cin = o.meta.get("true_cin", o.src.channels)
             kk = o.meta.get("true_k", o.k)
             f = 2.0 * ho * wo * o.dst.channels * cin * kk * kk
@@ -124,10 +132,14 @@ class Plan:
         return out
 
 
+FUSED_BOTTLENECK_WIDTHS = (16, 32, 48, 64, 96)   # hidden widths csrc/bottleneck.hip keeps in registers
+
+
 class _Builder:
-    def __init__(self):
+    def __init__(self, fused_bottleneck: bool = False):
         self.tensors: List[TensorSpec] = []
         self.ops: List[Op] = []
+        self.fused_bottleneck = fused_bottleneck
 
     def tensor(self, name, channels, down, dtype="act") -> int:
         self.tensors.append(TensorSpec(name, channels, down, dtype))
@@ -151,7 +163,14 @@ class _Builder:
         p = f"model.{idx}"
         self.conv(f"{p}.cv1|cv2", src, Slice(cat, 0, 2 * c_), 1, 1, (f"{p}.cv1", f"{p}.cv2"))
         x1 = Slice(cat, 0, c_)
-        for j in range(n):
+        # Fused form (bf16 engines, small c_): Bottlenecks run in PAIRS, ping-ponging cat[:c_] -> tmp -> cat[:c_]
+        # (the fused kernel reads halos, so it cannot run in place); an odd one out runs in the two-kernel form.
+        n_fused = 2 * (n // 2) if (self.fused_bottleneck and c_ in FUSED_BOTTLENECK_WIDTHS) else 0
+        for j in range(n_fused):
+            a, bdst = (x1, Slice(tmp, 0, c_)) if j % 2 == 0 else (Slice(tmp, 0, c_), x1)
+            self.ops.append(Op(OP_BOTTLENECK, f"{p}.m.{j}", src=a, dst=bdst, res=a if shortcut else None, k=3, stride=1, pad=1, act=1,
+                               weight_keys=(f"{p}.m.{j}.cv1", f"{p}.m.{j}.cv2"), meta={"class": "bottleneck"}))
+        for j in range(n_fused, n):
             self.conv(f"{p}.m.{j}.cv1", x1, Slice(tmp, 0, c_), 1, 1, (f"{p}.m.{j}.cv1",))
             self.conv(f"{p}.m.{j}.cv2", Slice(tmp, 0, c_), x1, 3, 1, (f"{p}.m.{j}.cv2",),
                       res=x1 if shortcut else None, **{"class": "conv3x3"})
@@ -159,14 +178,14 @@ class _Builder:
         return dst
 
 
-def build_plan(variant: str = "yolov5m", nc: int = 5, na: int = 3, fused_stem: bool = True) -> Plan:
+def build_plan(variant: str = "yolov5m", nc: int = 5, na: int = 3, fused_stem: bool = True, fused_bottleneck: bool = False) -> Plan:
     """Flatten the v6 architecture into ops over sliced NHWC buffers."""
     gd, gw = VARIANTS[variant]
     ch = tuple(make_divisible(c * gw) for c in (64, 128, 256, 512, 1024))
     c1, c2, c3, c4, c5 = ch
     n3, n6, n9 = scaled_depth(3, gd), scaled_depth(6, gd), scaled_depth(9, gd)
     no = nc + 5
-    b = _Builder()
+    b = _Builder(fused_bottleneck)
 
     # concat buffers that upstream builds with torch.cat (layers 12, 16, 19, 22): producers write slices.
     cat12 = b.tensor("cat12", c4 + c4, 16)   # [up(10) | out6]

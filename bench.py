@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--roof-steps", type=int, default=10, help="steps of the single-stream HIP-event pass that feeds `roofline`")
     p.add_argument("--streams", type=int, default=int(os.environ.get("AQ_BENCH_STREAMS", 2)),
                    help="independent batches in flight (one HIP stream + workspace each)")
+    p.add_argument("--two-kernel-bottleneck", action="store_true", help="A/B: 1x1 + 3x3 launches instead of the fused Bottleneck kernel")
     p.add_argument("--two-kernel-stem", action="store_true", help="A/B: preprocess + space-to-depth conv instead of the fused stem kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle sample budget")
@@ -110,7 +111,8 @@ def main() -> int:
     dev = torch.device("cuda", local)
 
     ck = checkpoint.synthetic_checkpoint(a.variant, 5)
-    eng = Engine(ck, a.precision, local, fused_stem=not a.two_kernel_stem)
+    eng = Engine(ck, a.precision, local, fused_stem=not a.two_kernel_stem,
+                 fused_bottleneck=(a.precision == "bf16" and not a.two_kernel_bottleneck))
     B, K, W = a.batch, a.steps, a.warmup
     tiles_dev = torch.from_numpy(make_tiles(rank, B, a.pool, a.size)).to(dev)
     max_det = 1000
@@ -181,11 +183,15 @@ def main() -> int:
         ms, calls = eng.op_times_ms()
         ops_ms = ms
         idx3 = [i for i, o in enumerate(plan.ops) if o.kind == spec.OP_CONV and o.meta.get("class") == "conv3x3"]
-        idxc = [i for i, o in enumerate(plan.ops) if o.kind in (spec.OP_CONV, spec.OP_STEM)]
+        idxc = [i for i, o in enumerate(plan.ops) if o.kind in (spec.OP_CONV, spec.OP_STEM, spec.OP_BOTTLENECK)]
         t3 = float(ms[idx3].sum()) * 1e-3       # seconds per step in the 3x3 conv launches
         tc = float(ms[idxc].sum()) * 1e-3
         peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
-        ach = fl["conv3x3"] * B / t3 / 1e12
+        f3 = float(sum(plan.ops[i].flops_per_tile for i in idx3)) * B     # the 3x3 layers launched as implicit-GEMM convs
+        idxb = [i for i, o in enumerate(plan.ops) if o.kind == spec.OP_BOTTLENECK]
+        tb = float(ms[idxb].sum()) * 1e-3
+        fb = float(sum(plan.ops[i].flops_per_tile for i in idxb)) * B
+        ach = f3 / t3 / 1e12
         traffic = None
         try:
             with open(a.traffic_json) as f:
@@ -194,9 +200,12 @@ def main() -> int:
             pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": traffic,
-                "kernel": "conv_igemm_kernel / conv3x3_halo_kernel (implicit-GEMM conv, autotuned per layer) on the 28 3x3 layers",
+                "kernel": f"conv_igemm_kernel / conv3x3_halo_kernel (implicit-GEMM conv, autotuned per layer) on the {len(idx3)} 3x3 "
+                          f"layers launched as plain convs ({len(idxb)} Bottlenecks run in bottleneck_kernel, reported separately)",
                 "launches_per_step": len(idx3), "avg_launch_ms": round(1e3 * t3 / len(idx3), 4),
-                "flops_per_step": fl["conv3x3"] * B, "steps_timed": calls,
+                "flops_per_step": f3, "steps_timed": calls,
+                "fused_bottleneck": {"launches_per_step": len(idxb), "ms_per_step": round(1e3 * tb, 3),
+                                     "tflops": round(fb / tb / 1e12, 1) if tb > 0 else None},
                 "pass": f"{calls} single-stream steps with HIP events right after the timed region (same process, same buffers; "
                         f"the timed region keeps {a.streams} batches in flight)",
                 "all_conv_tflops": round((fl["total"]) * B / tc / 1e12, 1),

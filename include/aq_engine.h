@@ -46,7 +46,7 @@ typedef enum aq_precision {
 
 typedef enum aq_op_kind {
     AQ_OP_PREPROCESS = 0, AQ_OP_CONV = 1, AQ_OP_SPPF_POOL = 2, AQ_OP_UPSAMPLE2X = 3,
-    AQ_OP_DECODE = 4, AQ_OP_NMS = 5, AQ_OP_STEM = 6
+    AQ_OP_DECODE = 4, AQ_OP_NMS = 5, AQ_OP_STEM = 6, AQ_OP_BOTTLENECK = 7
 } aq_op_kind;
 
 typedef enum aq_tensor_dtype { AQ_T_ACT = 0, AQ_T_F32 = 1, AQ_T_U8 = 2 } aq_tensor_dtype;
@@ -151,6 +151,15 @@ int aq_conv2d(const void* in_dev, int in_ld, int in_choff, int cin,
 int aq_pack_stem_weights(const float* w_krsc_host, int cout, int precision, void* packed_dev, size_t* bytes, void* stream);
 int aq_stem_conv(const uint8_t* tiles_dev, void* out_dev, int out_ld, int out_choff, int cout, const void* packed_w_dev,
                  const float* bias_dev, int B, int H, int W, int act, int precision, void* stream);
+
+/* Fused Bottleneck (bf16 only, C = 16, 32, 48, 64 or 96): y = (x +) SiLU(cv2_3x3(SiLU(cv1_1x1(x)))) in ONE launch, t never leaves the
+ * chip.  Replaces [UPSTREAM models/common.py Bottleneck.forward] for the C3 stages whose hidden width fits
+ * (yolov5m: model.2, model.4, model.17).
+ * In the plan (op kind AQ_OP_BOTTLENECK): weight = cv1 KRSC [C][1][1][C] followed by cv2 KRSC [C][3][3][C]; bias = b1 | b2.
+ * in/out: NHWC [B][H][W][ld] bf16 with the C channels at ch_off; out must not overlap in (neighbour tiles read halos). */
+int aq_pack_bottleneck_weights(const float* w1_host, const float* w2_host, int C, void* packed_dev, size_t* bytes, void* stream);
+int aq_bottleneck(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff, int C,
+                  const void* packed_w_dev, const float* bias_dev, int B, int H, int W, int shortcut, void* stream);
 /* uint8 RGB NHWC -> 2x2 space-to-depth, 16 channels, value/255 ([UPSTREAM detect.py: im.float()/255]). */
 int aq_preprocess_s2d(const uint8_t* tiles_dev, void* out_dev, int B, int H, int W, int precision, void* stream);
 /* Letterbox on device (the real 1024x1024 tiles of reference src/load_data/tile_tifs.py:13 -> 640x640):

@@ -123,3 +123,61 @@ def test_fused_and_two_kernel_stems_agree(lib, synth_ck):
         torch.cuda.synchronize()
         outs.append(eng.tensor_by_name("out0", 2).float().cpu().clone())
     torch.testing.assert_close(outs[0], outs[1], rtol=2e-5, atol=2e-5)
+
+
+def _bottleneck_reference(x, w1, b1, w2, b2, shortcut=True):
+    """bf16 two-kernel semantics: weights and t rounded to bf16, fp32 accumulation, bf16 output."""
+    xf = x.float().permute(0, 3, 1, 2)
+    t = F.silu(F.conv2d(xf, w1.bfloat16().float(), b1)).bfloat16().float()
+    y = F.silu(F.conv2d(t, w2.bfloat16().float(), b2, padding=1))
+    if shortcut:
+        y = y + xf
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("c", [16, 32, 48, 64, 96])
+@pytest.mark.parametrize("shape", [(2, 16, 32), (1, 40, 56), (3, 160, 160), (1, 7, 5)])
+def test_fused_bottleneck_matches_reference(lib, c, shape):
+    """aq_bottleneck: x + SiLU(cv2_3x3(SiLU(cv1_1x1(x)))) in one launch; input and output are channel slices of wider
+    NHWC tensors (as in the C3 concat buffer).  Shapes cover whole tiles, ragged edges, many tiles and a sub-tile image."""
+    from aquaculture_amd import engine
+    B, H, W = shape
+    g = torch.Generator().manual_seed(c * 1000 + H)
+    xw = (torch.randn(B, H, W, 2 * c, generator=g) * 0.8).bfloat16().cuda()
+    x = xw[..., 8:8 + c]
+    w1 = torch.randn(c, c, 1, 1, generator=g) * (2.0 / c) ** 0.5
+    w2 = torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5
+    b1, b2 = torch.randn(c, generator=g) * 0.2, torch.randn(c, generator=g) * 0.2
+    outw = torch.full((B, H, W, c + 16), 7.0, dtype=torch.bfloat16, device="cuda")
+    for shortcut in (True, False):
+        engine.bottleneck_nhwc(x, w1, b1, w2, b2, shortcut, out=outw[..., 16:])
+        ref = _bottleneck_reference(x.cpu(), w1, b1, w2, b2, shortcut)
+        got = outw[..., 16:].float().cpu()
+        assert (outw[..., :16] == 7.0).all(), "wrote outside its channel slice"
+        err = (got - ref).abs()
+        # one bf16 ulp of the result plus the effect of rare 1-ulp flips of t (accumulation order differs from torch's)
+        assert (err <= 2 ** -7 * ref.abs() + 2e-2).all(), float(err.max())
+        assert float(err.mean()) < 3e-3
+
+
+def test_fused_bottleneck_refuses_in_place(lib):
+    from aquaculture_amd import engine
+    x = torch.zeros(1, 16, 32, 48, dtype=torch.bfloat16, device="cuda")
+    w1, w2, b = torch.zeros(48, 48, 1, 1), torch.zeros(48, 48, 3, 3), torch.zeros(48)
+    with pytest.raises(RuntimeError, match="overlaps"):
+        engine.bottleneck_nhwc(x, w1, b, w2, b, True, out=x)
+
+
+def test_fused_and_two_kernel_bottlenecks_agree(lib, synth_ck):
+    """bf16 engines with and without the fused Bottleneck op: same C3 output up to bf16 rounding noise."""
+    from aquaculture_amd import engine, tiles
+    x = torch.from_numpy(tiles.synthetic_batch([0, 19], 128)).cuda()
+    outs = []
+    for fused in (True, False):
+        eng = engine.Engine(synth_ck, "bf16", fused_bottleneck=fused)
+        assert any(o.kind == 7 for o in eng.plan.ops) == fused
+        eng.forward_raw(x)
+        torch.cuda.synchronize()
+        outs.append(eng.tensor_by_name("out2", 2).float().cpu().clone())
+    err = (outs[0] - outs[1]).abs()
+    assert float(err.mean()) < 5e-3 and float(err.max()) < 0.25, (float(err.mean()), float(err.max()))

@@ -28,8 +28,35 @@ LAYERS = [
 ]
 
 
+BTL_NAMES = ["prologue", "vmcnt-wait", "tile-barrier", "dma-issue", "phase-B", "mid-barrier", "C-mfma", "C-epilogue"]
+
+
+def bottlenecks(lib, dev):
+    """Stamped builds of the fused Bottleneck kernel (csrc/bottleneck.hip) on yolov5m's two shapes."""
+    buf = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
+    g = torch.Generator().manual_seed(0)
+    for name, B, H, W, c in (("model.2.m fused 48@160", 64, 160, 160, 48), ("model.4.m fused 96@80", 64, 80, 80, 96)):
+        x = torch.randn(B, H, W, c, generator=g).bfloat16().to(dev)
+        w1 = torch.randn(c, c, 1, 1, generator=g) * (2.0 / c) ** 0.5
+        w2 = torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5
+        b = torch.randn(c, generator=g) * 0.1
+        buf.zero_()
+        engine._check(lib.aq_debug_conv_stamp(buf.data_ptr(), buf.numel() * 8))
+        try:
+            engine.bottleneck_nhwc(x, w1, b, w2, b, True)
+        finally:
+            lib.aq_debug_conv_stamp(None, 0)
+        t = buf.cpu().view(-1, 8)
+        t = t[t.sum(1) > 0].double()
+        tot = t.sum(1)
+        share = (t / tot[:, None]).mean(0) * 100
+        print(f"{name:26s} waves {t.shape[0]:5d} ticks/wave {tot.mean():9.0f} | " + " ".join(f"{n}={v:4.1f}%" for n, v in zip(BTL_NAMES, share.tolist())))
+
+
 def main():
     lib = engine.load_library()
+    if "--bottleneck" in sys.argv:
+        return bottlenecks(lib, torch.device("cuda", 0))
     n_igemm = 21
     dev = torch.device("cuda", 0)
     buf = torch.zeros(1 << 22, dtype=torch.int64, device=dev)
