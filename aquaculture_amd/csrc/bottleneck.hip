@@ -12,11 +12,15 @@
 //      forced to 0 (the 3x3 convolution pads t, not x);
 //   C. the 3x3 convolution reads its MFMA B fragments straight from the t patch (a pixel's 8-channel block of one tap is a
 //      contiguous, 16-byte aligned run), adds the shortcut from the x patch and stores y.
-// The 3x3 weights live in REGISTERS as MFMA A fragments for the life of the persistent workgroup (the small 1x1 set is
-// re-read from LDS once per tile)
-// (v_mfma_f32_16x16x32_bf16, M = C in 16-row blocks, no channel padding), so LDS serves activation fragments only.  That
-// costs up to ~300 VGPRs, hence one wave per SIMD; for C = 96 the output channels are split between two wave groups (each
-// wave keeps 48 of the 96 rows of W1 and W2) and both groups read the same activation fragments.
+// The 3x3 weights live in REGISTERS as MFMA A fragments for the life of the persistent workgroup (v_mfma_f32_16x16x32_bf16,
+// M = C in 16-row blocks, no channel padding); LDS serves activation fragments (and, where registers are short, the last
+// k-steps of W2).  Two families of tile shapes (table at btl_shape()):
+//   * "one M block per wave" (C = 48, 96: 12 waves, 3 per SIMD, <= 168 registers, weights in plain VGPRs): every MFMA needs
+//     its own 1 KB fragment read, which is exactly the LDS's 256 B/clk at the full MFMA rate -- LDS-bound;
+//   * "wide" (3-4 M blocks per wave, 4 waves, ~500 registers, one wave per SIMD; C = 64 and AQ_BTL_WIDE=1): a third of the
+//     LDS traffic, but the compiler parks most of W2 in AccVGPRs and copies each fragment back before use, and a single
+//     instruction stream per SIMD serialises MFMA issue, SiLU and LDS latency -- issue-bound.
+// Both run at ~28 cycles per MFMA (16 is the pipe rate); the 12-wave shapes are a few percent faster on yolov5m.
 // The output must not alias the input (neighbouring tiles read each other's halo): the plan ping-pongs Bottleneck pairs
 // between the C3 concat buffer and its temporary.
 #include "conv_device.h"
@@ -38,33 +42,45 @@ struct BtlParams {
     const char* zero;            // >= 16 zero bytes: DMA source for pixels outside the image
 };
 
-// MBW: 16-row M blocks per wave; MSPLIT: wave groups that split the output channels; TW: tile width in pixels.
-template <int MBW, int MSPLIT, int TW> struct BtlGeom {
+// MBW: 16-row M blocks per wave; MSPLIT: wave groups that split the output channels; NW: waves per workgroup (NW / MSPLIT
+// pixel groups of 4 output rows each); TW: tile width in pixels; KT: last k-steps of W2 kept in LDS instead of registers;
+// W1REG: the 1x1 weights stay in registers too (else they are re-read from LDS every tile); RESG: the shortcut is re-read from
+// global memory (L2-hot) instead of the x patch, so x is dead after phase B and needs ONE LDS buffer instead of two.
+template <int MBW, int MSPLIT, int NW, int TW, int KT, bool W1REG, bool RESG> struct BtlGeom {
     static constexpr int C = 16 * MBW * MSPLIT;
     static constexpr int CB = C / 8;                       // 8-channel (16-byte) blocks per pixel
-    static constexpr int PG = 4 / MSPLIT;                  // pixel groups (waves that own different rows)
+    static constexpr int PG = NW / MSPLIT;                 // pixel groups (waves that own different rows)
     static constexpr int TH = 4 * PG;                      // every wave owns 4 output rows
     static constexpr int PH = TH + 2, PW = TW + 2, PP = PH * PW;
-    static constexpr int PXB = C * 2 + 16;                 // LDS pixel stride: +16 B puts 16 consecutive pixels on distinct banks
+    // 16-byte LDS slots per pixel (channel blocks + pad).  ds_read_b128 is served in the lane groups {0-3,12-15,20-27},
+    // {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md, LDS): with lanes (pixel = lane & 15, K block = lane >> 4) a group is
+    // conflict-free when the slot stride is 2 mod 4 -- 6 for C = 48 (no padding at all), 14 for C = 96; a stride of CB + 1
+    // would cost two LDS cycles per group on every fragment read.  (C = 64: stride 10 does not fit the LDS, 9 is 2-way.)
+    static constexpr int SPP = C == 16 ? 2 : C == 32 ? 6 : C == 48 ? 6 : C == 64 ? 9 : 14;
+    static constexpr int PXB = SPP * 16;                   // LDS pixel stride in bytes
     static constexpr int KS1 = (CB + 3) / 4;               // k-steps (32 K each) of the 1x1
     static constexpr int NBLK2 = 9 * CB;                   // K blocks of the 3x3, tap-major
     static constexpr int KS2 = (NBLK2 + 3) / 4;
     static constexpr bool UNIFORM_K = CB % 4 == 0;         // a k-step never straddles taps: K offsets are compile-time + 16 g
-    static constexpr int SPP = CB + 1;                     // 16-byte LDS slots per pixel (channels + the pad slot)
     static constexpr int NQ = (PP * SPP + 63) / 64;        // LDS-DMA wave instructions per x patch (64 slots each)
     static constexpr int PATCHB = NQ * 1024;               // patch buffer, rounded up to whole DMA instructions
-    static constexpr int W1B = MSPLIT * KS1 * MBW * 1024;  // A fragments of the 1x1 (reloaded into registers every phase B)
-    static constexpr int KTAIL = MBW * KS2 > 64 ? 3 : 0;   // last k-steps of W2 that stay in LDS instead of
+    static constexpr int W1B = W1REG ? 0 : MSPLIT * KS1 * MBW * 1024;  // A fragments of the 1x1 (reloaded into registers every phase B)
+    static constexpr int KTAIL = KT;                       // last k-steps of W2 that stay in LDS instead of
     static constexpr int KREG = KS2 - KTAIL;               // registers (C = 96: 3 of 27, C = 64: 3 of 18): keeps the kernel spill-free
     static constexpr int W2TB = MSPLIT * KTAIL * MBW * 1024;
-    static constexpr int LDS = 3 * PATCHB + W1B + W2TB + 2 * C * 4;   // x patch (double buffered) | t patch | W1 | W2 tail | b1 | b2
+    static constexpr int XBUFS = RESG ? 1 : 2;
+    static constexpr int LDS = (XBUFS + 1) * PATCHB + W1B + W2TB + 2 * C * 4;   // x patch(es) | t patch | W1 | W2 tail | b1 | b2
     static constexpr int NBLK1 = (PP + 15) / 16;           // 16-pixel MFMA column blocks of phase B
     static constexpr int NBR = TW / 16;                    // 16-pixel blocks per output row
     static constexpr int RB = 4 / NBR;                     // rows per phase-C step (always 4 pixel blocks per step)
     static constexpr int STEPS = 4 / RB;                   // phase-C steps per tile (a wave owns 4 rows)
     static constexpr int WFRAGS = (KS1 + KS2) * MBW;       // A fragments per wave group
     static constexpr int NST = 4 * MBW;                    // output store instructions per wave and phase-C step (full tile)
+    static constexpr int THREADS = NW * 64;
+    static constexpr bool ROWREUSE = UNIFORM_K && NBR == 1 && MBW == 1;   // phase C loads each fragment once per (row, dx, quad)
+    static constexpr bool TIGHT = NW >= 12 && KT > 0;      // 168-register budget with part of W2 resident: smallest working set
     static_assert(TW == 16 || TW == 32, "tile width");
+    static_assert(NW % MSPLIT == 0 && KT < KS2, "shape");
     static_assert(LDS <= 160 * 1024, "LDS");
 };
 
@@ -89,13 +105,13 @@ __device__ __forceinline__ f32x4 silu4(f32x4 v) {          // same sequence as t
     return v * r;
 }
 
-template <int MBW, int MSPLIT, int TW, bool STAMP = false>
-__global__ __launch_bounds__(256) void bottleneck_kernel(const BtlParams p) {
-    using G = BtlGeom<MBW, MSPLIT, TW>;
+template <int MBW, int MSPLIT, int NW, int TW, int KT, bool W1REG, bool RESG, bool STAMP = false>
+__global__ __launch_bounds__(NW * 64) void bottleneck_kernel(const BtlParams p) {
+    using G = BtlGeom<MBW, MSPLIT, NW, TW, KT, W1REG, RESG>;
     constexpr int CB = G::CB, PXB = G::PXB, KS1 = G::KS1, KS2 = G::KS2, PW = G::PW, PP = G::PP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_t = smem + 2 * G::PATCHB;                        // x patches at smem + {0, PATCHB}
-    char* s_w1 = smem + 3 * G::PATCHB;
+    char* s_t = smem + G::XBUFS * G::PATCHB;                 // x patch(es) at smem + {0, PATCHB}
+    char* s_w1 = s_t + G::PATCHB;
     char* s_w2t = s_w1 + G::W1B;
     float* s_b = (float*)(s_w2t + G::W2TB);
 
@@ -122,11 +138,20 @@ __global__ __launch_bounds__(256) void bottleneck_kernel(const BtlParams p) {
     // ---- once per workgroup: this wave group's rows of both weight sets to registers, biases to LDS ----
     constexpr int KREG = G::KREG;
     bf16x8 a2[KREG][MBW];
+    bf16x8 a1r[W1REG ? KS1 : 1][MBW];                        // W1REG: the 1x1 weights, resident
     {
         const bf16x8* wsrc = (const bf16x8*)p.w + (size_t)mh * G::WFRAGS * 64 + lane;
-        if (pg == 0) {                                       // one wave per channel group copies its W1 fragments to LDS
+        if constexpr (!W1REG) {
+            if (pg == 0) {                                   // one wave per channel group copies its W1 fragments to LDS
 #pragma unroll
-            for (int i = 0; i < KS1 * MBW; ++i) *(bf16x8*)(s_w1 + (mh * KS1 * MBW + i) * 1024 + lane * 16) = wsrc[i * 64];
+                for (int i = 0; i < KS1 * MBW; ++i) *(bf16x8*)(s_w1 + (mh * KS1 * MBW + i) * 1024 + lane * 16) = wsrc[i * 64];
+            }
+        }
+        if constexpr (W1REG) {
+#pragma unroll
+            for (int s = 0; s < KS1; ++s)
+#pragma unroll
+                for (int m = 0; m < MBW; ++m) a1r[s][m] = wsrc[(s * MBW + m) * 64];
         }
 #pragma unroll
         for (int s = 0; s < KREG; ++s)
@@ -138,7 +163,7 @@ __global__ __launch_bounds__(256) void bottleneck_kernel(const BtlParams p) {
                 *(bf16x8*)(s_w2t + (mh * G::KTAIL * MBW + i) * 1024 + lane * 16) = wsrc[((KS1 + KREG) * MBW + i) * 64];
         }
     }
-    for (int i = tid; i < 2 * G::C; i += 256) s_b[i] = p.bias[i];
+    for (int i = tid; i < 2 * G::C; i += G::THREADS) s_b[i] = p.bias[i];
     // per-lane byte offset of this lane's K block: inside a pixel (1x1) / relative to the tap-(0,0) pixel (3x3).  K blocks
     // past the end carry zero weights and read block 0 (any initialised address would do).
     int koff1[G::UNIFORM_K ? 1 : KS1], koff2[G::UNIFORM_K ? 1 : KS2];
@@ -172,7 +197,7 @@ __global__ __launch_bounds__(256) void bottleneck_kernel(const BtlParams p) {
 
     const int tiles_per_img = p.tiles_y * p.tiles_x;
     // x patch of `tile` -> LDS buffer xb, asynchronously: wave w issues DMA instructions w, w+4, ...; instruction q fills the
-    // 64 consecutive 16-byte slots [64 q, 64 q + 64) of the patch image (slot = pixel * SPP + part; part == CB is the pad).
+    // 64 consecutive 16-byte slots [64 q, 64 q + 64) of the patch image (slot = pixel * SPP + part; parts >= CB are padding).
     // Pixels outside the image, pad slots and slots past the patch read the zero page.
     struct PatchOrg { const char* org; int y0, x0; };      // address of patch pixel (0, 0) (may lie outside the image) + tile origin
     auto patch_org = [&](int tile) -> PatchOrg {
@@ -182,7 +207,10 @@ __global__ __launch_bounds__(256) void bottleneck_kernel(const BtlParams p) {
         return {p.in + ((long long)(b * H + y0 - 1) * W + (x0 - 1)) * p.in_ld_b, y0, x0};
     };
     auto dma_one = [&](const PatchOrg& o, int q, char* xb) {  // branch-free: it is issued from inside the MFMA loop
-        const int slot = q * 64 + lane;
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));                     // opaque: keeps the compiler from hoisting the per-lane slot decode of
+                                                             // every call site out of the tile loop (dozens of registers for ~20 VALU ops)
+        const int slot = q * 64 + lane_o;
         const int px = slot / G::SPP, part = slot - px * G::SPP;
         const int pr = px / PW, pc = px - pr * PW;
         const int iy = o.y0 - 1 + pr, ix = o.x0 - 1 + pc;
@@ -193,13 +221,14 @@ __global__ __launch_bounds__(256) void bottleneck_kernel(const BtlParams p) {
     auto issue_dma = [&](int tile, char* xb) {
         const PatchOrg o = patch_org(tile);
 #pragma unroll 1
-        for (int q = wave; q < G::NQ; q += 4) dma_one(o, q, xb);
+        for (int q = wave; q < G::NQ; q += NW) dma_one(o, q, xb);
     };
     // The next tile's DMA instructions are normally issued from INSIDE the phase-C MFMA loop (their address arithmetic fills
     // VALU slots the matrix pipe leaves free); PER of them per phase-C step, one every SP k-steps.
-    constexpr int STEPS = G::STEPS, NQW = (G::NQ + 3) / 4, PER = (NQW + STEPS - 1) / STEPS;
+    constexpr int STEPS = G::STEPS, NQW = (G::NQ + NW - 1) / NW, PER = (NQW + STEPS - 1) / STEPS;
     constexpr int SP = KS2 / PER >= 1 ? KS2 / PER : 1;
     static_assert(PER * SP <= KS2, "not enough k-steps to carry the DMA issue");
+    constexpr int RSTEPS = 3 * (CB / 4 > 0 ? CB / 4 : 1) * 6, RSP = RSTEPS / PER >= 1 ? RSTEPS / PER : 1;   // row-reuse form of phase C
 
     int tile = first_tile(gridDim.x, blockIdx.x);
     if (tile < p.n_tiles) issue_dma(tile, smem);
@@ -210,7 +239,7 @@ __global__ __launch_bounds__(256) void bottleneck_kernel(const BtlParams p) {
         const int b = tile / tiles_per_img, tr = tile - b * tiles_per_img;
         const int ty0 = tr / p.tiles_x, tx0 = tr - ty0 * p.tiles_x;
         const int y0 = ty0 * G::TH, x0 = tx0 * TW;
-        const char* s_x = smem + cur * G::PATCHB;
+        const char* s_x = smem + (RESG ? 0 : cur * G::PATCHB);
         // ---- A. this tile's x patch has landed (own DMA: vmcnt, the other waves': barrier); every wave is also done with
         //      the previous tile, so the other x buffer and the t patch are free: start the next tile's DMA ----
         // (vmcnt is in-order.  After a full tile the youngest DMA instruction is older than the last phase-C step's
@@ -221,11 +250,11 @@ __global__ __launch_bounds__(256) void bottleneck_kernel(const BtlParams p) {
         stamp(2);
         const bool has_next = tile + (int)gridDim.x < p.n_tiles;
         prev_full = y0 + G::TH <= H && x0 + TW <= W;         // every store instruction of this tile has active lanes
-        char* xbn = smem + (cur ^ 1) * G::PATCHB;
+        char* xbn = smem + (RESG ? 0 : (cur ^ 1) * G::PATCHB);   // RESG: x is dead once phase B is over (mid barrier)
         PatchOrg on = {nullptr, 0, 0};
         if (has_next) on = patch_org(tile + (int)gridDim.x);
         stamp(3);
-        // ---- B. t = SiLU(W1 x + b1) on all patch pixels: two 16-pixel blocks per step, this wave's channel group ----
+        // ---- B. t = SiLU(W1 x + b1) on all patch pixels: one or two 16-pixel blocks per step, this wave's channel group ----
         {
             f32x4 b1v[MBW];
             bf16x8 a1[KS1][MBW];                             // live in this phase only: phase C needs the registers
@@ -234,31 +263,37 @@ __global__ __launch_bounds__(256) void bottleneck_kernel(const BtlParams p) {
 #pragma unroll
             for (int s = 0; s < KS1; ++s)
 #pragma unroll
-                for (int m = 0; m < MBW; ++m) a1[s][m] = *(const bf16x8*)(s_w1 + ((mh * KS1 + s) * MBW + m) * 1024 + lane * 16);
+                for (int m = 0; m < MBW; ++m) {
+                    if constexpr (W1REG) a1[s][m] = a1r[s][m];
+                    else a1[s][m] = *(const bf16x8*)(s_w1 + ((mh * KS1 + s) * MBW + m) * 1024 + lane * 16);
+                }
+            constexpr int NBB = G::TIGHT ? 1 : 2;            // 16-pixel blocks per iteration
 #pragma unroll 1
-            for (int nb0 = pg; nb0 < G::NBLK1; nb0 += 2 * G::PG) {
-                int px[2], pxc[2];
-                f32x4 acc[2][MBW];
+            for (int nb0 = pg; nb0 < G::NBLK1; nb0 += NBB * G::PG) {
+                int px[NBB], pxc[NBB];
+                f32x4 acc[NBB][MBW];
+                int l15o = l15;
+                asm volatile("" : "+v"(l15o));               // opaque, as in dma_one: no per-block state hoisted across tiles
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    px[j] = (nb0 + j * G::PG) * 16 + l15;    // the second block may lie past the patch: clamped reads, no writes
+                for (int j = 0; j < NBB; ++j) {
+                    px[j] = (nb0 + j * G::PG) * 16 + l15o;    // the second block may lie past the patch: clamped reads, no writes
                     pxc[j] = px[j] < PP ? px[j] : PP - 1;
 #pragma unroll
                     for (int m = 0; m < MBW; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                bf16x8 f[KS1][2];
+                bf16x8 f[KS1][NBB];
 #pragma unroll
                 for (int s = 0; s < KS1; ++s)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) f[s][j] = *(const bf16x8*)(s_x + pxc[j] * PXB + k1(s));
+                    for (int j = 0; j < NBB; ++j) f[s][j] = *(const bf16x8*)(s_x + pxc[j] * PXB + k1(s));
 #pragma unroll
                 for (int s = 0; s < KS1; ++s)
 #pragma unroll
                     for (int m = 0; m < MBW; ++m)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[s][m], f[s][j], acc[j][m], 0, 0, 0);
+                        for (int j = 0; j < NBB; ++j) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[s][m], f[s][j], acc[j][m], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NBB; ++j) {
                     const int pr = pxc[j] / PW, pc = pxc[j] - pr * PW;
                     const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
                     const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
@@ -288,40 +323,113 @@ __global__ __launch_bounds__(256) void bottleneck_kernel(const BtlParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) boff[j] = ((j / G::NBR) * PW + 16 * (j % G::NBR)) * PXB;
                 const char* base = s_t + (ty * PW + l15) * PXB;
+                uint2 xg[RESG ? 4 : 1][MBW];                 // RESG: shortcut values, fetched from global before the MFMA loop
+                if constexpr (RESG) {
+                    if (p.shortcut) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int y = y0 + ty + j / G::NBR, x = x0 + 16 * (j % G::NBR) + l15;
+                            const char* src = p.in + ((long long)(b * H + y) * W + x) * p.in_ld_b + cbase * 2;
+#pragma unroll
+                            for (int m = 0; m < MBW; ++m) xg[j][m] = (y < H && x < W) ? *(const uint2*)(src + m * 32) : make_uint2(0, 0);
+                        }
+                    }
+                }
                 f32x4 acc[4][MBW];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int m = 0; m < MBW; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-                constexpr int D = 1;                         // fragments are fetched one k-step (12+ MFMAs, >= 192 cycles) ahead
-                bf16x8 fq[D][4];
+                auto w2frag = [&](int s, int m) -> bf16x8 {  // A fragment of k-step s (compile-time after unrolling)
+                    if constexpr (G::KTAIL > 0) {
+                        if (s >= KREG) return *(const bf16x8*)(s_w2t + ((mh * G::KTAIL + (s - KREG)) * MBW + m) * 1024 + lane * 16);
+                        return a2[s < KREG ? s : 0][m];
+                    } else return a2[s][m];
+                };
+                if constexpr (G::ROWREUSE) {
+                    // The four blocks are four consecutive output rows: fragment (patch row r, dx, channel quad) is the B operand of
+                    // every (output row j, dy) with j + dy = r -- load it ONCE and issue all of them (up to 3 MFMAs per M block).
+                    // Halves the LDS reads of the shapes that are LDS-bound (one M block per wave: 1 KB of LDS per MFMA otherwise).
+                    constexpr int CQ = CB / 4;
+                    auto frag = [&](int dx, int cq, int r) -> bf16x8 {
+                        return *(const bf16x8*)(base + (r * PW + dx) * PXB + cq * 64 + koff2[0]);
+                    };
+                    // two fragments in flight ahead of the one being multiplied (rotating variables: an indexed buffer would
+                    // keep the loop nest from unrolling and push the weight arrays to scratch)
+                    bf16x8 f0 = frag(0, 0, 0), f1 = frag(0, 0, 1);
+                    int step = 0;
 #pragma unroll
-                for (int s = 0; s < D; ++s)
+                    for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) fq[s][j] = *(const bf16x8*)(base + boff[j] + k2(s));
+                        for (int cq = 0; cq < CQ; ++cq) {
+                            // the three taps (dy = 0..2) of this (dx, quad): fetched ONCE here -- a W2-tail fragment read inside
+                            // the row loop would be re-read from LDS for each of its four output rows
+                            bf16x8 wf[3][MBW];
+#pragma unroll
+                            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                                for (int m = 0; m < MBW; ++m) wf[dy][m] = w2frag((dy * 3 + dx) * CQ + cq, m);
+#pragma unroll
+                            for (int r = 0; r < 6; ++r, ++step) {
+                                int r2 = r + 2, cq2 = cq, dx2 = dx;        // the fragment two steps ahead
+                                if (r2 >= 6) { r2 -= 6; if (++cq2 == CQ) { cq2 = 0; ++dx2; } }
+                                bf16x8 f2 = f0;
+                                if (dx2 < 3) f2 = frag(dx2, cq2, r2);
+                                if (step % RSP == 0 && step / RSP < PER) {   // one DMA instruction of the next tile's x patch
+                                    const int q = wave + NW * (step / RSP);
+                                    if (has_next && q < G::NQ) dma_one(on, q, xbn);
+                                }
+#pragma unroll
+                                for (int dy = 0; dy < 3; ++dy) {
+                                    const int j = r - dy;
+                                    if (j < 0 || j > 3) continue;
+#pragma unroll
+                                    for (int m = 0; m < MBW; ++m)
+                                        acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[dy][m], f0, acc[j][m], 0, 0, 0);
+                                }
+                                f0 = f1; f1 = f2;
+                                if constexpr (G::TIGHT) __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                } else {
+                // fragments are fetched one k-step (12+ MFMAs, >= 192 cycles) ahead, except in the register-tight shape, where
+                // the other two waves of the SIMD cover the LDS latency
+                constexpr int D = G::TIGHT ? 0 : 1;
+                bf16x8 fq[D > 0 ? D : 1][4];
+                if constexpr (D > 0) {
+#pragma unroll
+                    for (int s = 0; s < D; ++s)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) fq[s][j] = *(const bf16x8*)(base + boff[j] + k2(s));
+                }
 #pragma unroll
                 for (int s = 0; s < KS2; ++s) {
                     bf16x8 f[4];
+                    if constexpr (D > 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) f[j] = fq[s % D][j];
-                    if (s + D < KS2) {
+                        for (int j = 0; j < 4; ++j) f[j] = fq[s % D][j];
+                        if (s + D < KS2) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) fq[s % D][j] = *(const bf16x8*)(base + boff[j] + k2(s + D));
+                            for (int j = 0; j < 4; ++j) fq[s % D][j] = *(const bf16x8*)(base + boff[j] + k2(s + D));
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) f[j] = *(const bf16x8*)(base + boff[j] + k2(s));
                     }
                     if (s % SP == 0 && s / SP < PER) {       // one DMA instruction of the next tile's x patch
-                        const int q = wave + 4 * (st * PER + s / SP);
+                        const int q = wave + NW * (st * PER + s / SP);
                         if (has_next && q < G::NQ) dma_one(on, q, xbn);
                     }
 #pragma unroll
                     for (int m = 0; m < MBW; ++m) {
-                        bf16x8 am;
-                        if constexpr (G::KTAIL > 0) {
-                            if (s >= KREG) am = *(const bf16x8*)(s_w2t + ((mh * G::KTAIL + (s - KREG)) * MBW + m) * 1024 + lane * 16);
-                            else am = a2[s < KREG ? s : 0][m];
-                        } else am = a2[s][m];
+                        const bf16x8 am = w2frag(s, m);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, f[j], acc[j][m], 0, 0, 0);
                     }
+                    // register-tight shape: stop the scheduler from hoisting later k-steps' LDS loads (fragments and W2 tail)
+                    // above this point -- it would otherwise keep dozens of them live and spill
+                    if constexpr (G::TIGHT) __builtin_amdgcn_sched_barrier(0);
+                }
                 }
                 if constexpr (STAMP) asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[3][MBW - 1][3]));
                 stamp(6);
@@ -337,7 +445,10 @@ __global__ __launch_bounds__(256) void bottleneck_kernel(const BtlParams p) {
                     uint2 xr[MBW];
                     if (p.shortcut) {
 #pragma unroll
-                        for (int m = 0; m < MBW; ++m) xr[m] = *(const uint2*)(xc + boff[j] + m * 32);
+                        for (int m = 0; m < MBW; ++m) {
+                            if constexpr (RESG) xr[m] = xg[j][m];
+                            else xr[m] = *(const uint2*)(xc + boff[j] + m * 32);
+                        }
                     }
 #pragma unroll
                     for (int m = 0; m < MBW; ++m) {
@@ -357,58 +468,65 @@ __global__ __launch_bounds__(256) void bottleneck_kernel(const BtlParams p) {
     }
     if constexpr (STAMP) {
         if (lane == 0 && p.debug)
-            for (int i = 0; i < 8; ++i) p.debug[((long long)blockIdx.x * 4 + wave) * 8 + i] = ph_sum[i];
+            for (int i = 0; i < 8; ++i) p.debug[((long long)blockIdx.x * NW + wave) * 8 + i] = ph_sum[i];
     }
 }
 
 int g_btl_cus = 0;
 
-struct BtlShape { int mbw, msplit, tw; };
+struct BtlShape { int mbw, msplit, nw, tw, ktail; bool w1reg, resg; };
+
+// Tile shapes.  C = 48 and 96 (yolov5m) run "one M block per wave": 12 waves (3 per SIMD, <= 168 registers each, weights in
+// plain VGPRs), every wave computes 16 output channels for the 4 rows x 16 pixels of its pixel group.  AQ_BTL_WIDE=1 selects
+// the earlier 4-wave shapes (3 M blocks per wave, ~500 registers, one wave per SIMD) for A/B runs; the packed weight image
+// depends on the shape, so the choice is made once per process.
+bool btl_wide() {
+    static const bool wide = [] { const char* e = getenv("AQ_BTL_WIDE"); return e && atoi(e) != 0; }();
+    return wide;
+}
 
 bool btl_shape(int C, BtlShape* s) {
     switch (C) {
-        case 16: *s = {1, 1, 32}; return true;
-        case 32: *s = {2, 1, 32}; return true;
-        case 48: *s = {3, 1, 16}; return true;
-        case 64: *s = {4, 1, 16}; return true;
-        case 96: *s = {3, 2, 16}; return true;
+        case 16: *s = {1, 1, 4, 32, 0, false, false}; return true;
+        case 32: *s = {2, 1, 4, 16, 0, false, false}; return true;
+        case 48: *s = btl_wide() ? BtlShape{3, 1, 4, 16, 0, false, false} : BtlShape{1, 3, 12, 16, 0, true, false}; return true;
+        case 64: *s = {4, 1, 4, 16, 3, false, false}; return true;
+        case 96: *s = btl_wide() ? BtlShape{3, 2, 4, 16, 3, false, false} : BtlShape{1, 6, 12, 16, 12, true, true}; return true;
     }
     return false;
 }
 
-template <int MBW, int MSPLIT, int TW>
+template <int MBW, int MSPLIT, int NW, int TW, int KT, bool W1REG, bool RESG>
 int launch_btl(BtlParams p, hipStream_t stream) {
-    using G = BtlGeom<MBW, MSPLIT, TW>;
+    using G = BtlGeom<MBW, MSPLIT, NW, TW, KT, W1REG, RESG>;
     static int occ = 0;                                      // resident workgroups per CU (registers + LDS)
-    auto fn = bottleneck_kernel<MBW, MSPLIT, TW>;
-    if constexpr ((MBW == 3) && TW == 16) {                  // stamped diagnostic builds exist for C = 48 and C = 96
+    auto fn = bottleneck_kernel<MBW, MSPLIT, NW, TW, KT, W1REG, RESG>;
+    constexpr size_t lds = G::LDS;
+    p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + G::TH - 1) / G::TH;
+    AQ_REQUIRE((long long)p.B * p.tiles_x * p.tiles_y < (1LL << 30), "bottleneck: batch too large");
+    p.n_tiles = p.B * p.tiles_x * p.tiles_y;
+    if constexpr (MBW * MSPLIT == 3 || MBW * MSPLIT == 6) {  // stamped diagnostic builds exist for C = 48 and C = 96
         size_t sbytes = 0;
         unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
-        if (sbuf && (size_t)g_btl_cus * 4 * 64 <= sbytes) {
-            auto sfn = bottleneck_kernel<MBW, MSPLIT, TW, true>;
+        if (sbuf && (size_t)g_btl_cus * NW * 64 <= sbytes) {
+            auto sfn = bottleneck_kernel<MBW, MSPLIT, NW, TW, KT, W1REG, RESG, true>;
             AQ_CHECK_HIP(hipFuncSetAttribute((const void*)sfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
-            p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + G::TH - 1) / G::TH;
-            p.n_tiles = p.B * p.tiles_x * p.tiles_y;
             p.debug = sbuf;
             const long long sgrid = g_btl_cus < p.n_tiles ? g_btl_cus : p.n_tiles;
-            hipLaunchKernelGGL(sfn, dim3((unsigned)sgrid), dim3(256), G::LDS, stream, p);
+            hipLaunchKernelGGL(sfn, dim3((unsigned)sgrid), dim3(G::THREADS), G::LDS, stream, p);
             AQ_CHECK_HIP(hipGetLastError());
             return AQ_OK;
         }
     }
-    constexpr size_t lds = G::LDS;
     if (!occ) {
         AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int o = 0;
-        AQ_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)fn, 256, lds));
+        AQ_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)fn, G::THREADS, lds));
         occ = o > 0 ? o : 1;                                 // a persistent grid must be fully resident
     }
-    p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + G::TH - 1) / G::TH;
-    AQ_REQUIRE((long long)p.B * p.tiles_x * p.tiles_y < (1LL << 30), "bottleneck: batch too large");
-    p.n_tiles = p.B * p.tiles_x * p.tiles_y;
     long long grid = (long long)g_btl_cus * occ;
     if (grid > p.n_tiles) grid = p.n_tiles;
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(G::THREADS), lds, stream, p);
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;
 }
@@ -487,10 +605,10 @@ extern "C" int aq_bottleneck(const void* in_dev, int in_ld, int in_choff, void* 
     }
     const hipStream_t st = (hipStream_t)stream;
     switch (C) {
-        case 16: return launch_btl<1, 1, 32>(p, st);
-        case 32: return launch_btl<2, 1, 32>(p, st);
-        case 48: return launch_btl<3, 1, 16>(p, st);
-        case 64: return launch_btl<4, 1, 16>(p, st);
-        default: return launch_btl<3, 2, 16>(p, st);
+        case 16: return launch_btl<1, 1, 4, 32, 0, false, false>(p, st);
+        case 32: return launch_btl<2, 1, 4, 16, 0, false, false>(p, st);
+        case 48: return btl_wide() ? launch_btl<3, 1, 4, 16, 0, false, false>(p, st) : launch_btl<1, 3, 12, 16, 0, true, false>(p, st);
+        case 64: return launch_btl<4, 1, 4, 16, 3, false, false>(p, st);
+        default: return btl_wide() ? launch_btl<3, 2, 4, 16, 3, false, false>(p, st) : launch_btl<1, 6, 12, 16, 12, true, true>(p, st);
     }
 }

@@ -96,7 +96,7 @@ def main():
                     "--no-cpu-baseline"], env=env, capture_output=True, text=True, check=True)
     sys.path.insert(0, ROOT)
     from aquaculture_amd import spec
-    plan = spec.build_plan("yolov5m", 5)
+    plan = spec.build_plan("yolov5m", 5, fused_bottleneck=True)   # what a bf16 Engine (and bench.py) runs
     fl = plan.flops(640, 640)
     # kernel sequence of one step: one per op, the SPPF pool op launches 3 kernels
     seq = []
@@ -150,10 +150,10 @@ def main():
         rd = sum(2 * r["FETCH_SIZE"] * 1024 for r in r3) / len(r3)
         wr = sum(r["WRITE_SIZE"] * 1024 for r in r3) / len(r3)
         with open(os.path.join(a.out, "hbm_traffic.json"), "w") as f:
-            json.dump({"kernel": "conv_igemm_kernel / conv3x3_halo_kernel on the 28 3x3 layers", "batch": a.batch, "launches_averaged": len(r3),
+            json.dump({"kernel": f"conv_igemm_kernel / conv3x3_halo_kernel on the {len(r3)} 3x3 layers launched as plain convs", "batch": a.batch, "launches_averaged": len(r3),
                        "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr,
                        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 counts 128-B "
-                                 "requests at 64 B, MI355X_MICROARCH.md HBM section), KiB -> bytes; mean over the 28 launches of one step"}, f, indent=1)
+                                 "requests at 64 B, MI355X_MICROARCH.md HBM section), KiB -> bytes; mean over these launches of one step"}, f, indent=1)
     # compact text table
     def g(r, k):
         return r.get(k, 0.0)
