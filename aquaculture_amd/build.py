@@ -23,6 +23,7 @@ SOURCES = [
     ("conv_halo.hip", []),
     ("stem_conv.hip", []),
     ("bottleneck.hip", []),
+    ("downblock.hip", []),
     ("pointwise.hip", []),
     ("detect_nms.hip", ["-ffp-contract=off"]),   # bit-level parity with the oracle's fp32 op order
     ("engine.cpp", ["-x", "hip"]),

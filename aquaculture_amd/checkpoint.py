@@ -223,6 +223,14 @@ class PackedConv:
 def pack_plan_weights(ck: Checkpoint, plan: _spec.Plan) -> List[PackedConv]:
     packed = []
     for op in plan.conv_ops():
+        if op.kind == _spec.OP_DOWNBLOCK:    # wa = model.N (96,3,3,48) then wb = stacked cv1|cv2 (96,1,1,96), KRSC, back to back; bias ba | bb
+            (wa, ba), (w1, b1), (w2, b2) = (fuse_conv_bn(ck.state, key, ck.bn_eps) for key in op.weight_keys)
+            wb, bb = torch.cat([w1, w2], 0), torch.cat([b1, b2], 0)
+            assert tuple(wa.shape) == (96, 48, 3, 3) and tuple(wb.shape) == (96, 96, 1, 1), (op.name, wa.shape, wb.shape)
+            flat = torch.cat([wa.permute(0, 2, 3, 1).reshape(-1), wb.permute(0, 2, 3, 1).reshape(-1)])
+            packed.append(PackedConv(np.ascontiguousarray(flat.numpy(), dtype=np.float32),
+                                     np.ascontiguousarray(torch.cat([ba, bb]).numpy(), dtype=np.float32)))
+            continue
         if op.kind == _spec.OP_BOTTLENECK:   # cv1 (C,1,1,C) then cv2 (C,3,3,C), KRSC, flattened back to back; bias b1 | b2
             (w1, b1), (w2, b2) = (fuse_conv_bn(ck.state, key, ck.bn_eps) for key in op.weight_keys)
             c_ = op.src.channels

@@ -196,6 +196,13 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
                                op.src.channels, e->packed[oi].w, e->packed[oi].bias, B, pl.h, pl.w, op.res.tensor >= 0, stream);
             break;
         }
+        case AQ_OP_DOWNBLOCK: {
+            const TensorPlace& pl = e->place[op.src.tensor];
+            rc = aq_downblock(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
+                              tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
+                              e->packed[oi].w, e->packed[oi].bias, B, pl.h, pl.w, stream);
+            break;
+        }
         case AQ_OP_SPPF_POOL: {
             const TensorPlace& pl = e->place[op.src.tensor];
             rc = aq_sppf_pool(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
@@ -361,6 +368,26 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
             if (aq_pack_bottleneck_weights(op.weight, op.weight + (size_t)C * C, C, pw.w, &nb, nullptr) != AQ_OK ||
                 hipMemcpy(pw.bias, op.bias, 2 * C * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
                 aq_set_error("engine_create: bottleneck weight upload failed");
+                return fail(AQ_ERR_HIP);
+            }
+            op.weight = nullptr; op.bias = nullptr;
+            continue;
+        }
+        if (op.kind == AQ_OP_DOWNBLOCK) {
+            PackedW& pw = e->packed[oi];
+            size_t nb = 0;
+            if (!op.weight || !op.bias || d->precision != AQ_BF16 || op.k != 3 || op.stride != 2 || op.pad != 1 || op.src.channels != 48 ||
+                op.dst.channels != 96 || aq_pack_downblock_weights(op.weight, op.weight + (size_t)96 * 9 * 48, nullptr, &nb, nullptr) != AQ_OK) {
+                aq_set_error("engine_create: downblock op %zu unsupported (bf16, 3x3/s2 48 -> 96 then 1x1 96 -> 96)", oi);
+                return fail(AQ_ERR_INVALID);
+            }
+            if (hipMalloc(&pw.w, nb) != hipSuccess || hipMalloc((void**)&pw.bias, 192 * sizeof(float)) != hipSuccess) {
+                aq_set_error("engine_create: downblock weight allocation failed");
+                return fail(AQ_ERR_NOMEM);
+            }
+            if (aq_pack_downblock_weights(op.weight, op.weight + (size_t)96 * 9 * 48, pw.w, &nb, nullptr) != AQ_OK ||
+                hipMemcpy(pw.bias, op.bias, 192 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+                aq_set_error("engine_create: downblock weight upload failed");
                 return fail(AQ_ERR_HIP);
             }
             op.weight = nullptr; op.bias = nullptr;

@@ -63,7 +63,7 @@ EXPORTS = (
     "aq_engine_infer", "aq_engine_forward_raw", "aq_engine_tensor_ptr", "aq_engine_profile",
     "aq_engine_op_times", "aq_engine_num_ops", "aq_engine_set_conv_config", "aq_engine_autotune",
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
-    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_preprocess_s2d", "aq_sppf_pool",
+    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
 
@@ -104,6 +104,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_stem_conv.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.aq_pack_bottleneck_weights.argtypes = [C.POINTER(f32), C.POINTER(f32), i32, vp, C.POINTER(sz), vp]
     lib.aq_bottleneck.argtypes = [vp, i32, i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp]
+    lib.aq_pack_downblock_weights.argtypes = [C.POINTER(f32), C.POINTER(f32), vp, C.POINTER(sz), vp]
+    lib.aq_downblock.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, i32, vp]
     lib.aq_preprocess_s2d.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.aq_sppf_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.aq_upsample2x.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -170,7 +172,7 @@ class Engine:
                 setattr(d, name, aq_slice(s.tensor, s.ch_off, s.channels) if s is not None else aq_slice(-1, 0, 0))
             d.k, d.stride, d.pad, d.act, d.level = o.k, o.stride, o.pad, o.act, o.level
             d.flops_per_tile = o.flops_per_tile
-            if o.kind in (_spec.OP_CONV, _spec.OP_STEM, _spec.OP_BOTTLENECK):
+            if o.kind in (_spec.OP_CONV, _spec.OP_STEM, _spec.OP_BOTTLENECK, _spec.OP_DOWNBLOCK):
                 pw = packed[ci]
                 ci += 1
                 d.weight = pw.weight.ctypes.data_as(C.POINTER(C.c_float))
@@ -477,5 +479,29 @@ def bottleneck_nhwc(x: torch.Tensor, w1_oihw: torch.Tensor, b1: torch.Tensor, w2
     # data_ptr() of a channel slice already points at its first channel: pass ch_off = 0 with the parent's row length
     _check(lib.aq_bottleneck(x.data_ptr(), ld, 0, out.data_ptr(), old, 0, c, wbuf.data_ptr(), bbuf.data_ptr(), B, H, W, int(shortcut),
                              _stream_ptr()))
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
+def downblock_nhwc(x: torch.Tensor, wa_oihw: torch.Tensor, ba: torch.Tensor, wb_oihw: torch.Tensor, bb: torch.Tensor,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 NHWC [B,H,W,48] (may be a channel slice) -> SiLU(conv1x1(SiLU(conv3x3/s2(x)))) [B,H/2,W/2,96] through aq_downblock (tests)."""
+    _require_gpu()
+    lib = load_library()
+    assert x.dtype == torch.bfloat16 and x.stride(3) == 1 and x.shape[3] == 48
+    B, H, W, _ = x.shape
+    ld = x.stride(2)
+    assert x.stride(1) == W * ld and x.stride(0) == H * W * ld, "x must be a channel slice of a dense NHWC tensor"
+    wa = np.ascontiguousarray(wa_oihw.permute(0, 2, 3, 1).float().cpu().numpy())
+    wb = np.ascontiguousarray(wb_oihw.permute(0, 2, 3, 1).float().cpu().numpy())
+    n = C.c_size_t()
+    pa, pb = wa.ctypes.data_as(C.POINTER(C.c_float)), wb.ctypes.data_as(C.POINTER(C.c_float))
+    _check(lib.aq_pack_downblock_weights(pa, pb, None, C.byref(n), None))
+    wbuf = torch.empty(n.value, dtype=torch.uint8, device=x.device)
+    _check(lib.aq_pack_downblock_weights(pa, pb, wbuf.data_ptr(), C.byref(n), _stream_ptr()))
+    bbuf = torch.cat([ba.float(), bb.float()]).to(x.device).contiguous()
+    if out is None:
+        out = torch.empty((B, H // 2, W // 2, 96), dtype=torch.bfloat16, device=x.device)
+    _check(lib.aq_downblock(x.data_ptr(), ld, 0, out.data_ptr(), out.stride(2), 0, wbuf.data_ptr(), bbuf.data_ptr(), B, H, W, _stream_ptr()))
     torch.cuda.current_stream().synchronize()
     return out

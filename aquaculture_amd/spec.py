@@ -29,6 +29,7 @@ OP_DECODE = 4       # sigmoid + grid/anchor decode + obj threshold + compaction
 OP_NMS = 5          # per-tile class-offset greedy NMS
 OP_STEM = 6         # fused u8 -> /255 -> Conv(3, C, 6, 2, 2) + SiLU (stem_conv.hip)
 OP_BOTTLENECK = 7   # fused Bottleneck (1x1 -> 3x3 -> + shortcut) for small hidden widths, bf16 engines only
+OP_DOWNBLOCK = 8    # fused 3x3/s2 (48 -> 96) + stacked 1x1 (96 -> 96): yolov5m's model.1 + model.2.cv1|cv2, bf16 engines only
 
 VARIANTS = {
     # name: (depth_multiple, width_multiple)   [UPSTREAM models/yolov5{n,s,m,l,x}.yaml]
@@ -105,7 +106,7 @@ class Plan:
 
     def conv_ops(self) -> List[Op]:
         """Ops that carry weights (implicit-GEMM convs and the fused stem), in plan order."""
-        return [o for o in self.ops if o.kind in (OP_CONV, OP_STEM, OP_BOTTLENECK)]
+        return [o for o in self.ops if o.kind in (OP_CONV, OP_STEM, OP_BOTTLENECK, OP_DOWNBLOCK)]
 
     def flops(self, h: int, w: int) -> Dict[str, float]:
         """Algorithmic FLOPs per tile (2 x MAC, true Cin of the upstream layer, no padding)."""
@@ -113,6 +114,14 @@ class Plan:
         for o in self.conv_ops():
             down = self.tensors[o.dst.tensor].down
             ho, wo = h // down, w // down
+            if o.kind == OP_DOWNBLOCK:        # 3x3/s2 (src -> dst channels) + 1x1 (dst -> dst channels)
+                f3 = 2.0 * ho * wo * o.dst.channels * o.src.channels * 9
+                f1 = 2.0 * ho * wo * o.dst.channels * o.dst.channels
+                o.flops_per_tile = f3 + f1
+                out["total"] += f3 + f1
+                out["conv3x3"] += f3
+                out["conv1x1"] += f1
+                continue
             if o.kind == OP_BOTTLENECK:       # cv1 (1x1) + cv2 (3x3), both C -> C
                 f1 = 2.0 * ho * wo * o.dst.channels * o.src.channels
                 o.flops_per_tile = 10.0 * f1
@@ -150,7 +159,7 @@ class _Builder:
                            pad=k // 2, act=act, weight_keys=tuple(keys), meta=dict(meta)))
         return dst
 
-    def c3(self, idx: int, src: Slice, dst: Slice, c2: int, n: int, shortcut: bool, down: int) -> Slice:
+    def c3(self, idx: int, src: Slice, dst: Slice, c2: int, n: int, shortcut: bool, down: int, down_from: Optional[Slice] = None) -> Slice:
         """C3: cv3(cat(m(cv1 x), cv2 x)) [UPSTREAM models/common.py C3, Bottleneck].
 
         cv1 and cv2 read the same x, so they run as ONE 1x1 conv whose Cout is
@@ -161,7 +170,13 @@ class _Builder:
         cat = self.tensor(f"m{idx}.cat", 2 * c_, down)
         tmp = self.tensor(f"m{idx}.tmp", c_, down)
         p = f"model.{idx}"
-        self.conv(f"{p}.cv1|cv2", src, Slice(cat, 0, 2 * c_), 1, 1, (f"{p}.cv1", f"{p}.cv2"))
+        if down_from is not None:
+            # the 3x3/s2 conv in front of this C3 and the stacked cv1|cv2 run as ONE op (csrc/downblock.hip): `src` (the
+            # down-sampling conv's own output buffer) is never written
+            self.ops.append(Op(OP_DOWNBLOCK, f"model.{idx - 1}+{p}.cv1|cv2", src=down_from, dst=Slice(cat, 0, 2 * c_), k=3, stride=2, pad=1,
+                               act=1, weight_keys=(f"model.{idx - 1}", f"{p}.cv1", f"{p}.cv2"), meta={"class": "downblock"}))
+        else:
+            self.conv(f"{p}.cv1|cv2", src, Slice(cat, 0, 2 * c_), 1, 1, (f"{p}.cv1", f"{p}.cv2"))
         x1 = Slice(cat, 0, c_)
         # Fused form (bf16 engines, small c_): Bottlenecks run in PAIRS, ping-ponging cat[:c_] -> tmp -> cat[:c_]
         # (the fused kernel reads halos, so it cannot run in place); an odd one out runs in the two-kernel form.
@@ -206,12 +221,14 @@ def build_plan(variant: str = "yolov5m", nc: int = 5, na: int = 3, fused_stem: b
         b.ops.append(Op(OP_PREPROCESS, "preprocess", src=Slice(t_in, 0, 3), dst=Slice(t_s2d, 0, STEM_S2D_CH)))
         x = b.conv("model.0", Slice(t_s2d, 0, STEM_S2D_CH), Slice(t0, 0, c1), 3, 1, ("model.0",),
                    **{"class": "stem", "true_cin": 3, "true_k": 6, "stem_s2d": True})
-    # 1: Conv(c1, c2, 3, 2)
+    # 1: Conv(c1, c2, 3, 2);  2: C3(c2, c2, n3).  bf16 engines with yolov5m's widths fuse model.1 with the C3's stacked cv1|cv2.
     t1 = b.tensor("out1", c2, 4)
-    x = b.conv("model.1", x, Slice(t1, 0, c2), 3, 2, ("model.1",), **{"class": "conv3x3"})
-    # 2: C3(c2, c2, n3)
     t2 = b.tensor("out2", c2, 4)
-    x = b.c3(2, x, Slice(t2, 0, c2), c2, n3, True, 4)
+    if fused_bottleneck and (c1, c2) == (48, 96):
+        x = b.c3(2, Slice(t1, 0, c2), Slice(t2, 0, c2), c2, n3, True, 4, down_from=x)
+    else:
+        x = b.conv("model.1", x, Slice(t1, 0, c2), 3, 2, ("model.1",), **{"class": "conv3x3"})
+        x = b.c3(2, x, Slice(t2, 0, c2), c2, n3, True, 4)
     # 3: Conv(c2, c3, 3, 2)
     t3 = b.tensor("out3", c3, 8)
     x = b.conv("model.3", x, Slice(t3, 0, c3), 3, 2, ("model.3",), **{"class": "conv3x3"})

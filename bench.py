@@ -183,7 +183,7 @@ def main() -> int:
         ms, calls = eng.op_times_ms()
         ops_ms = ms
         idx3 = [i for i, o in enumerate(plan.ops) if o.kind == spec.OP_CONV and o.meta.get("class") == "conv3x3"]
-        idxc = [i for i, o in enumerate(plan.ops) if o.kind in (spec.OP_CONV, spec.OP_STEM, spec.OP_BOTTLENECK)]
+        idxc = [i for i, o in enumerate(plan.ops) if o.kind in (spec.OP_CONV, spec.OP_STEM, spec.OP_BOTTLENECK, spec.OP_DOWNBLOCK)]
         t3 = float(ms[idx3].sum()) * 1e-3       # seconds per step in the 3x3 conv launches
         tc = float(ms[idxc].sum()) * 1e-3
         peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS

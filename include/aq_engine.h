@@ -46,7 +46,7 @@ typedef enum aq_precision {
 
 typedef enum aq_op_kind {
     AQ_OP_PREPROCESS = 0, AQ_OP_CONV = 1, AQ_OP_SPPF_POOL = 2, AQ_OP_UPSAMPLE2X = 3,
-    AQ_OP_DECODE = 4, AQ_OP_NMS = 5, AQ_OP_STEM = 6, AQ_OP_BOTTLENECK = 7
+    AQ_OP_DECODE = 4, AQ_OP_NMS = 5, AQ_OP_STEM = 6, AQ_OP_BOTTLENECK = 7, AQ_OP_DOWNBLOCK = 8
 } aq_op_kind;
 
 typedef enum aq_tensor_dtype { AQ_T_ACT = 0, AQ_T_F32 = 1, AQ_T_U8 = 2 } aq_tensor_dtype;
@@ -160,6 +160,14 @@ int aq_stem_conv(const uint8_t* tiles_dev, void* out_dev, int out_ld, int out_ch
 int aq_pack_bottleneck_weights(const float* w1_host, const float* w2_host, int C, void* packed_dev, size_t* bytes, void* stream);
 int aq_bottleneck(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff, int C,
                   const void* packed_w_dev, const float* bias_dev, int B, int H, int W, int shortcut, void* stream);
+
+/* Fused down-sampling block (bf16 only, 48 -> 96 -> 96 channels): y = SiLU(Wb_1x1 . SiLU(Wa_3x3/s2 (*) x)) in ONE launch.
+ * Replaces yolov5m's model.1 = Conv(48, 96, 3, 2) followed by the stacked model.2.cv1|cv2 1x1 convs
+ * [UPSTREAM models/common.py Conv.forward_fuse, C3.forward].  In the plan (op kind AQ_OP_DOWNBLOCK): weight = wa KRSC
+ * [96][3][3][48] followed by wb KRSC [96][1][1][96]; bias = ba | bb.  in: NHWC [B][H][W][ld]; out: [B][H/2][W/2][ld]. */
+int aq_pack_downblock_weights(const float* wa_host, const float* wb_host, void* packed_dev, size_t* bytes, void* stream);
+int aq_downblock(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff,
+                 const void* packed_w_dev, const float* bias_dev, int B, int H, int W, void* stream);
 /* uint8 RGB NHWC -> 2x2 space-to-depth, 16 channels, value/255 ([UPSTREAM detect.py: im.float()/255]). */
 int aq_preprocess_s2d(const uint8_t* tiles_dev, void* out_dev, int B, int H, int W, int precision, void* stream);
 /* Letterbox on device (the real 1024x1024 tiles of reference src/load_data/tile_tifs.py:13 -> 640x640):

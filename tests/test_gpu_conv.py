@@ -181,3 +181,42 @@ def test_fused_and_two_kernel_bottlenecks_agree(lib, synth_ck):
         outs.append(eng.tensor_by_name("out2", 2).float().cpu().clone())
     err = (outs[0] - outs[1]).abs()
     assert float(err.mean()) < 5e-3 and float(err.max()) < 0.25, (float(err.mean()), float(err.max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 32), (1, 36, 44), (2, 320, 320), (1, 6, 10)])
+def test_fused_downblock_matches_reference(lib, shape):
+    """aq_downblock: SiLU(conv1x1(SiLU(conv3x3/s2(x)))), 48 -> 96 -> 96, in one launch; the input is a channel slice of a wider
+    tensor, the output a slice too.  Shapes: one exact tile, ragged tiles in both directions, many tiles, a sub-tile image."""
+    from aquaculture_amd import engine
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * 7 + W)
+    xw = (torch.randn(B, H, W, 64, generator=g) * 0.8).bfloat16().cuda()
+    x = xw[..., 8:56]
+    wa = torch.randn(96, 48, 3, 3, generator=g) * (2.0 / (9 * 48)) ** 0.5
+    wb = torch.randn(96, 96, 1, 1, generator=g) * (2.0 / 96) ** 0.5
+    ba, bb = torch.randn(96, generator=g) * 0.2, torch.randn(96, generator=g) * 0.2
+    outw = torch.full((B, H // 2, W // 2, 112), 7.0, dtype=torch.bfloat16, device="cuda")
+    engine.downblock_nhwc(x, wa, ba, wb, bb, out=outw[..., 16:])
+    xf = x.float().cpu().permute(0, 3, 1, 2)
+    t = F.silu(F.conv2d(xf, wa.bfloat16().float(), ba, stride=2, padding=1)).bfloat16().float()
+    ref = F.silu(F.conv2d(t, wb.bfloat16().float(), bb)).permute(0, 2, 3, 1).contiguous()
+    got = outw[..., 16:].float().cpu()
+    assert (outw[..., :16] == 7.0).all(), "wrote outside its channel slice"
+    err = (got - ref).abs()
+    assert (err <= 2 ** -7 * ref.abs() + 2e-2).all(), float(err.max())
+    assert float(err.mean()) < 3e-3
+
+
+def test_fused_downblock_in_engine(lib, synth_ck):
+    """bf16 engines with the fused ops (default) and without them agree on the first C3's output up to bf16 rounding noise."""
+    from aquaculture_amd import engine, tiles
+    x = torch.from_numpy(tiles.synthetic_batch([3, 11], 128)).cuda()
+    outs = []
+    for fused in (True, False):
+        eng = engine.Engine(synth_ck, "bf16", fused_bottleneck=fused)
+        assert any(o.kind == 8 for o in eng.plan.ops) == fused
+        eng.forward_raw(x)
+        torch.cuda.synchronize()
+        outs.append(eng.tensor_by_name("out2", 2).float().cpu().clone())
+    err = (outs[0] - outs[1]).abs()
+    assert float(err.mean()) < 5e-3 and float(err.max()) < 0.25, (float(err.mean()), float(err.max()))
