@@ -24,6 +24,7 @@ SOURCES = [
     ("stem_conv.hip", []),
     ("bottleneck.hip", []),
     ("downblock.hip", []),
+    ("conv1x1_direct.hip", []),
     ("pointwise.hip", []),
     ("detect_nms.hip", ["-ffp-contract=off"]),   # bit-level parity with the oracle's fp32 op order
     ("engine.cpp", ["-x", "hip"]),

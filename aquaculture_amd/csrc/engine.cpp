@@ -34,6 +34,7 @@ struct PackedW {
     void* w = nullptr;      // [cout_rows][kgroups_pad] x 16 B
     float* bias = nullptr;  // [cout_rows]
     int kgroups = 0, kgroups_pad = 0, G = 0, cout_rows = 0;
+    void* w_direct = nullptr;   // 1x1 layers the direct kernel supports: its A-fragment image (csrc/conv1x1_direct.hip)
 };
 
 // Host-side packing: KRSC fp32 -> [cout_rows][kgroups_pad*16 B] of bf16 / fp32, zero padded.
@@ -153,6 +154,12 @@ int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStr
     p.act = op.act;
     int cfg = force_cfg >= 0 ? force_cfg : e->conv_cfg[oi];
     if (cfg < 0 && e->tuned_B == B && e->tuned_H == e->lay_H && e->tuned_W == e->lay_W) cfg = e->tuned_cfg[oi];
+    if (cfg == AQ_CONV_CFG_DIRECT1X1) {
+        if (!pw.w_direct) { aq_set_error("conv op %d has no direct 1x1 form", oi); return AQ_ERR_INVALID; }
+        return aq_conv1x1_direct(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
+                                 tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
+                                 op.src.channels, op.dst.channels, pw.w_direct, pw.bias, (long long)B * pd.h * pd.w, op.act, stream);
+    }
     if (cfg < 0) cfg = aq_conv_pick_config(p.cout, p.npix, prec);
     return aq_launch_conv(p, prec, out_f32, cfg, stream);
 }
@@ -412,6 +419,16 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
             aq_set_error("engine_create: weight upload failed (op %zu)", oi);
             return fail(AQ_ERR_HIP);
         }
+        if (d->precision == AQ_BF16 && op.k == 1 && op.stride == 1 && op.res.tensor < 0 && e->tensors[op.dst.tensor].dtype == AQ_T_ACT &&
+            aq_conv1x1_direct_supported(op.src.channels, op.dst.channels)) {
+            size_t nb = 0;
+            if (aq_pack_conv1x1_direct(op.weight, op.src.channels, op.dst.channels, nullptr, &nb, nullptr) != AQ_OK ||
+                hipMalloc(&pw.w_direct, nb) != hipSuccess ||
+                aq_pack_conv1x1_direct(op.weight, op.src.channels, op.dst.channels, pw.w_direct, &nb, nullptr) != AQ_OK) {
+                aq_set_error("engine_create: direct 1x1 weight upload failed (op %zu)", oi);
+                return fail(AQ_ERR_HIP);
+            }
+        }
         op.weight = nullptr; op.bias = nullptr;   // host pointers are not kept
     }
     *out = e;
@@ -422,6 +439,7 @@ extern "C" void aq_engine_destroy(aq_engine* e) {
     if (!e) return;
     for (PackedW& pw : e->packed) {
         if (pw.w) (void)hipFree(pw.w);
+        if (pw.w_direct) (void)hipFree(pw.w_direct);
         if (pw.bias) (void)hipFree(pw.bias);
     }
     if (e->zero_page) (void)hipFree(e->zero_page);
@@ -466,7 +484,8 @@ extern "C" int aq_engine_num_ops(aq_engine* e) { return e ? (int)e->ops.size() :
 
 extern "C" int aq_engine_set_conv_config(aq_engine* e, int op, int cfg) {
     AQ_REQUIRE(e && op >= 0 && op < (int)e->ops.size() && e->ops[op].kind == AQ_OP_CONV, "set_conv_config: op %d is not a conv", op);
-    AQ_REQUIRE(cfg >= -1 && cfg < aq_conv_num_configs(), "set_conv_config: bad config %d", cfg);
+    AQ_REQUIRE((cfg >= -1 && cfg < aq_conv_num_configs()) || (cfg == AQ_CONV_CFG_DIRECT1X1 && e->packed[op].w_direct),
+               "set_conv_config: bad config %d for op %d", cfg, op);
     e->conv_cfg[op] = cfg;
     return AQ_OK;
 }
@@ -495,7 +514,9 @@ extern "C" int aq_engine_autotune(aq_engine* e, const uint8_t* tiles_dev, int B,
         if (e->ops[oi].kind != AQ_OP_CONV) continue;
         float best = 1e30f;
         int best_cfg = -1;
-        for (int c = 0; c < ncfg && rc == AQ_OK; ++c) {
+        for (int ci = 0; ci <= ncfg && rc == AQ_OK; ++ci) {
+            const int c = ci < ncfg ? ci : AQ_CONV_CFG_DIRECT1X1;     // last candidate: the direct 1x1 kernel, where it applies
+            if (c == AQ_CONV_CFG_DIRECT1X1 && !e->packed[oi].w_direct) continue;
             rc = run_conv(e, (int)oi, ws, tiles_dev, B, stream, c);   // warm-up (also sets the LDS attribute)
             if (rc == AQ_ERR_INVALID) { rc = AQ_OK; continue; }       // this tile shape does not apply to this layer
             if (rc) break;

@@ -63,7 +63,7 @@ EXPORTS = (
     "aq_engine_infer", "aq_engine_forward_raw", "aq_engine_tensor_ptr", "aq_engine_profile",
     "aq_engine_op_times", "aq_engine_num_ops", "aq_engine_set_conv_config", "aq_engine_autotune",
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
-    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_preprocess_s2d", "aq_sppf_pool",
+    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
 
@@ -106,6 +106,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_bottleneck.argtypes = [vp, i32, i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp]
     lib.aq_pack_downblock_weights.argtypes = [C.POINTER(f32), C.POINTER(f32), vp, C.POINTER(sz), vp]
     lib.aq_downblock.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, i32, vp]
+    lib.aq_conv1x1_direct_supported.argtypes = [i32, i32]
+    lib.aq_pack_conv1x1_direct.argtypes = [C.POINTER(f32), i32, i32, vp, C.POINTER(sz), vp]
+    lib.aq_conv1x1_direct.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, C.c_longlong, i32, vp]
     lib.aq_preprocess_s2d.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.aq_sppf_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.aq_upsample2x.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -503,5 +506,31 @@ def downblock_nhwc(x: torch.Tensor, wa_oihw: torch.Tensor, ba: torch.Tensor, wb_
     if out is None:
         out = torch.empty((B, H // 2, W // 2, 96), dtype=torch.bfloat16, device=x.device)
     _check(lib.aq_downblock(x.data_ptr(), ld, 0, out.data_ptr(), out.stride(2), 0, wbuf.data_ptr(), bbuf.data_ptr(), B, H, W, _stream_ptr()))
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
+CONV_CFG_DIRECT1X1 = 1000   # AQ_CONV_CFG_DIRECT1X1
+
+
+def conv1x1_direct_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, act: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 [..., cin] pixels (may be a channel slice of a wider dense tensor) -> SiLU(W x + b) through aq_conv1x1_direct (tests)."""
+    _require_gpu()
+    lib = load_library()
+    assert x.dtype == torch.bfloat16 and x.stride(-1) == 1
+    cin, cout = x.shape[-1], w_oihw.shape[0]
+    ld = x.stride(-2)
+    npix = x.numel() // cin
+    w = np.ascontiguousarray(w_oihw.reshape(cout, cin).float().cpu().numpy())
+    n = C.c_size_t()
+    wp = w.ctypes.data_as(C.POINTER(C.c_float))
+    _check(lib.aq_pack_conv1x1_direct(wp, cin, cout, None, C.byref(n), None))
+    wbuf = torch.empty(n.value, dtype=torch.uint8, device=x.device)
+    _check(lib.aq_pack_conv1x1_direct(wp, cin, cout, wbuf.data_ptr(), C.byref(n), _stream_ptr()))
+    bbuf = bias.float().to(x.device).contiguous()
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (cout,), dtype=torch.bfloat16, device=x.device)
+    _check(lib.aq_conv1x1_direct(x.data_ptr(), ld, 0, out.data_ptr(), out.stride(-2), 0, cin, cout, wbuf.data_ptr(), bbuf.data_ptr(), npix, int(act),
+                                 _stream_ptr()))
     torch.cuda.current_stream().synchronize()
     return out

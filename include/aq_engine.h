@@ -168,6 +168,15 @@ int aq_bottleneck(const void* in_dev, int in_ld, int in_choff, void* out_dev, in
 int aq_pack_downblock_weights(const float* wa_host, const float* wb_host, void* packed_dev, size_t* bytes, void* stream);
 int aq_downblock(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff,
                  const void* packed_w_dev, const float* bias_dev, int B, int H, int W, void* stream);
+
+/* Direct 1x1 convolution (bf16; Cin -> Cout in {96->96, 192->192, 384->192, 384->384}): no K pipeline, whole-K pixel tiles by LDS-DMA, weights
+ * in registers.  Same operation as aq_conv2d with k = 1; the engine's autotuner times it per layer against the implicit-GEMM tile
+ * shapes under the config id AQ_CONV_CFG_DIRECT1X1. */
+#define AQ_CONV_CFG_DIRECT1X1 1000
+int aq_conv1x1_direct_supported(int cin, int cout);
+int aq_pack_conv1x1_direct(const float* w_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream);
+int aq_conv1x1_direct(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff, int cin, int cout,
+                      const void* packed_w_dev, const float* bias_dev, long long npix, int act, void* stream);
 /* uint8 RGB NHWC -> 2x2 space-to-depth, 16 channels, value/255 ([UPSTREAM detect.py: im.float()/255]). */
 int aq_preprocess_s2d(const uint8_t* tiles_dev, void* out_dev, int B, int H, int W, int precision, void* stream);
 /* Letterbox on device (the real 1024x1024 tiles of reference src/load_data/tile_tifs.py:13 -> 640x640):

@@ -220,3 +220,43 @@ def test_fused_downblock_in_engine(lib, synth_ck):
         outs.append(eng.tensor_by_name("out2", 2).float().cpu().clone())
     err = (outs[0] - outs[1]).abs()
     assert float(err.mean()) < 5e-3 and float(err.max()) < 0.25, (float(err.mean()), float(err.max()))
+
+
+@pytest.mark.parametrize("cin,cout", [(96, 96), (192, 192), (384, 192), (384, 384)])
+@pytest.mark.parametrize("npix_shape", [(1, 16, 16), (2, 37, 41), (3, 160, 160)])
+def test_direct_conv1x1_matches_reference(lib, cin, cout, npix_shape):
+    """aq_conv1x1_direct vs F.conv2d on bf16-rounded operands; input and output are channel slices of wider tensors; pixel counts
+    cover one partial tile, ragged multi-tile and many tiles."""
+    from aquaculture_amd import engine
+    B, H, W = npix_shape
+    g = torch.Generator().manual_seed(cin + H)
+    xw = (torch.randn(B, H, W, cin + 16, generator=g) * 0.8).bfloat16().cuda()
+    x = xw[..., 8:8 + cin]
+    w = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.2
+    outw = torch.full((B, H, W, cout + 8), 7.0, dtype=torch.bfloat16, device="cuda")
+    for act in (True, False):
+        engine.conv1x1_direct_nhwc(x, w, b, act, out=outw[..., 8:])
+        ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.bfloat16().float(), b)
+        ref = (F.silu(ref) if act else ref).permute(0, 2, 3, 1)
+        got = outw[..., 8:].float().cpu()
+        assert (outw[..., :8] == 7.0).all()
+        torch.testing.assert_close(got, ref.bfloat16().float(), rtol=2 ** -7, atol=2e-3)
+
+
+def test_direct_conv1x1_in_engine(lib, synth_ck):
+    """Forcing the direct kernel on every 1x1 layer it supports leaves the head outputs within bf16 noise of the default engine."""
+    from aquaculture_amd import engine, tiles
+    x = torch.from_numpy(tiles.synthetic_batch([5], 128)).cuda()
+    ref_eng = engine.Engine(synth_ck, "bf16")
+    ref = ref_eng.forward_raw(x).float().cpu()
+    eng = engine.Engine(synth_ck, "bf16")
+    forced = 0
+    for i, o in enumerate(eng.plan.ops):
+        if o.kind == 1 and o.k == 1 and o.res is None and eng.lib.aq_conv1x1_direct_supported(o.src.channels, o.dst.channels) and o.level < 0:
+            eng.set_conv_config(i, engine.CONV_CFG_DIRECT1X1)
+            forced += 1
+    assert forced >= 5
+    got = eng.forward_raw(x).float().cpu()
+    err = (got - ref).abs()
+    assert float(err[..., 4].max()) < 0.1 and float(err[..., :4].mean()) < 1.0, (float(err[..., 4].max()), float(err[..., :4].mean()))
