@@ -14,6 +14,11 @@
 //      form applies when it stores model.1's output;
 //   2. the 1x1 (3 k-steps, weights in registers) reads its fragments from the t tile and stores y.
 // Per wave 68 weight registers; LDS 2 x 62 KB (x) + 28 KB (t).
+//
+// The same kernel, without the 1x1 stage, also runs a plain 3x3/s2 96 -> 192 (yolov5m's model.3): 12 M blocks x 1 pixel group,
+// 4 x 16 tiles, k-steps that never straddle taps -- so each (input row, dx, channel quad) fragment is loaded once and used for
+// both output rows it serves -- and the last 3 of the 27 weight k-steps in LDS.  The engine's autotuner times that form against
+// the implicit-GEMM tile shapes under the config id AQ_CONV_CFG_DIRECT3X3S2.
 #include "conv_device.h"
 
 using namespace aqdev;
@@ -29,26 +34,41 @@ struct DownParams {
     int in_ld_b, out_ld_b;
     int B, H, W, Ho, Wo;     // input / output spatial size (Ho = H / 2)
     int tiles_x, tiles_y, n_tiles;
+    int act;                 // plain 3x3/s2 form only (the fused form always applies SiLU twice)
 };
 
-constexpr int kCin = 48, kCmid = 96, kCout = 96;
-constexpr int kNW = 12, kPG = 2;                         // 6 M blocks x 2 pixel groups
-constexpr int kTH = 4 * kPG, kTW = 16;                   // output tile: every wave owns 4 rows x 16 pixels
-constexpr int kPH = 2 * kTH + 1, kPW = 2 * kTW + 1;      // input patch 17 x 33 (stride 2, pad 1)
-constexpr int kPP = kPH * kPW;
-constexpr int kCBI = kCin / 8;                           // 16-byte channel blocks of an input pixel
-constexpr int kSPPX = 7, kPXB = kSPPX * 16;              // x patch: 6 channel slots + 1 pad per pixel
-constexpr int kNQ = (kPP * kSPPX + 63) / 64;             // LDS-DMA wave instructions per patch
-constexpr int kXPB = kNQ * 1024;
-constexpr int kKSA = (9 * kCBI + 3) / 4;                 // 14 k-steps (32 K each) of the 3x3; K blocks are tap-major
-constexpr int kNBLKA = 9 * kCBI;
-constexpr int kKSB = kCmid / 32;                         // 3 k-steps of the 1x1
-constexpr int kSPPT = 14, kTPXB = kSPPT * 16;            // t tile: 12 channel slots + 2 pad (conflict-free stride-1 reads)
-constexpr int kTPB = kTH * kTW * kTPXB;
-constexpr int kLDS = 2 * kXPB + kTPB + (kCmid + kCout) * 4;
-constexpr int kWFrags = kKSA + kKSB;                     // A fragments per M block
-static_assert(kLDS <= 160 * 1024, "LDS");
-static_assert(kCmid == kCout, "one M block index per wave serves both convolutions");
+constexpr int kNW = 12;                                  // waves per workgroup (3 per SIMD)
+constexpr int kTW = 16;                                  // output tile width; every wave owns 4 rows x 16 pixels
+
+// CIN -> CMID by the 3x3/s2; FUSE: followed by a 1x1 CMID -> CMID; KT: last k-steps of the 3x3 weights kept in LDS.
+//   <48, 96, true, 0>:   yolov5m model.1 + model.2.cv1|cv2   (6 M blocks x 2 pixel groups, 8 x 16 tile)
+//   <96, 192, false, 3>: yolov5m model.3                     (12 M blocks x 1 pixel group, 4 x 16 tile)
+template <int CIN, int CMID, bool FUSE, int KT> struct DownGeom {
+    static constexpr int MB = CMID / 16;                     // M blocks = wave groups along M
+    static constexpr int PG = kNW / MB;                      // pixel groups
+    static constexpr int TH = 4 * PG;
+    static constexpr int PH = 2 * TH + 1, PW = 2 * kTW + 1;  // input patch (stride 2, pad 1)
+    static constexpr int PP = PH * PW;
+    static constexpr int CBI = CIN / 8;                      // 16-byte channel blocks of an input pixel
+    static constexpr int SPPX = CBI | 1;                     // x patch slots per pixel: odd => conflict-free stride-2 fragment reads
+    static constexpr int PXB = SPPX * 16;
+    static constexpr int NQ = (PP * SPPX + 63) / 64;         // LDS-DMA wave instructions per patch
+    static constexpr int XPB = NQ * 1024;
+    static constexpr int NBLKA = 9 * CBI;
+    static constexpr int KSA = (NBLKA + 3) / 4;              // k-steps (32 K each) of the 3x3; K blocks are tap-major
+    static constexpr bool UNIFORM_K = CBI % 4 == 0;          // a k-step never straddles taps
+    static constexpr int CQ = CBI / 4;                       // channel quads per tap (UNIFORM_K)
+    static constexpr int KREG = KSA - KT;
+    static constexpr int WTB = MB * KT * 1024;               // W tail in LDS
+    static constexpr int KSB = FUSE ? CMID / 32 : 0;         // k-steps of the 1x1
+    static constexpr int SPPT = CMID / 8 + 2, TPXB = SPPT * 16;   // t tile (FUSE): channel slots + 2 pad (conflict-free stride-1 reads)
+    static constexpr int TPB = FUSE ? TH * kTW * TPXB : 0;
+    static constexpr int NBIAS = FUSE ? 2 * CMID : CMID;
+    static constexpr int LDS = 2 * XPB + TPB + WTB + NBIAS * 4;
+    static constexpr int WFRAGS = KSA + KSB;                 // A fragments per M block
+    static_assert(kNW % MB == 0 && LDS <= 160 * 1024, "shape");
+    static_assert(KT == 0 || UNIFORM_K, "the LDS tail is only wired into the uniform-K loop");
+};
 
 __device__ __forceinline__ f32x4 down_silu4(f32x4 v) {   // same sequence as the shared conv epilogue (bf16 mode)
     const f32x4 t = v * -1.44269504f;
@@ -67,37 +87,48 @@ __device__ __forceinline__ void down_lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
+template <int CIN, int CMID, bool FUSE, int KT>
 __global__ __launch_bounds__(kNW * 64) void downblock_kernel(const DownParams p) {
+    using G = DownGeom<CIN, CMID, FUSE, KT>;
+    constexpr int PW = G::PW, PXB = G::PXB, KSA = G::KSA, KSB = G::KSB, KREG = G::KREG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_t = smem + 2 * kXPB;
-    float* s_b = (float*)(s_t + kTPB);
+    char* s_t = smem + 2 * G::XPB;
+    char* s_wt = s_t + G::TPB;
+    float* s_b = (float*)(s_wt + G::WTB);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mb = wave % 6, pg = wave / 6;
+    const int mb = wave % G::MB, pg = wave / G::MB;
     const int g = lane >> 4, l15 = lane & 15;
     const int H = p.H, W = p.W, Ho = p.Ho, Wo = p.Wo;
     const int cbase = mb * 16 + g * 4;                       // this lane's 4 channels (of both the intermediate and the output)
 
-    // ---- once per workgroup: this wave's rows of both weight sets to registers, biases to LDS ----
-    bf16x8 wa[kKSA], wb[kKSB];
+    // ---- once per workgroup: this wave's rows of the weight sets to registers (3x3 tail: LDS), biases to LDS ----
+    bf16x8 wa[KREG], wb[KSB > 0 ? KSB : 1];
     {
-        const bf16x8* wsrc = (const bf16x8*)p.w + (size_t)mb * kWFrags * 64 + lane;
+        const bf16x8* wsrc = (const bf16x8*)p.w + (size_t)mb * G::WFRAGS * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < kKSA; ++s) wa[s] = wsrc[s * 64];
+        for (int s = 0; s < KREG; ++s) wa[s] = wsrc[s * 64];
+        if (pg == 0) {
 #pragma unroll
-        for (int s = 0; s < kKSB; ++s) wb[s] = wsrc[(kKSA + s) * 64];
+            for (int s = 0; s < KT; ++s) *(bf16x8*)(s_wt + (mb * KT + s) * 1024 + lane * 16) = wsrc[(KREG + s) * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < KSB; ++s) wb[s] = wsrc[(KSA + s) * 64];
     }
-    for (int i = tid; i < kCmid + kCout; i += kNW * 64) s_b[i] = p.bias[i];
+    for (int i = tid; i < G::NBIAS; i += kNW * 64) s_b[i] = p.bias[i];
     // per-lane byte offset of this lane's K block relative to the tap-(0,0) pixel of an output pixel's 3x3 window
-    int koffa[kKSA];
+    int koffa[G::UNIFORM_K ? 1 : KSA];
+    if constexpr (G::UNIFORM_K) koffa[0] = g * 16;
+    else {
 #pragma unroll
-    for (int s = 0; s < kKSA; ++s) {
-        int blk = 4 * s + g;
-        if (blk >= kNBLKA) blk = 0;                          // zero weights: any initialised address
-        const int tap = blk / kCBI, cb = blk - tap * kCBI;
-        const int dy = tap / 3, dx = tap - 3 * dy;
-        koffa[s] = (dy * kPW + dx) * kPXB + cb * 16;
+        for (int s = 0; s < KSA; ++s) {
+            int blk = 4 * s + g;
+            if (blk >= G::NBLKA) blk = 0;                    // zero weights: any initialised address
+            const int tap = blk / G::CBI, cb = blk - tap * G::CBI;
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            koffa[s] = (dy * PW + dx) * PXB + cb * 16;
+        }
     }
 
     const int tiles_per_img = p.tiles_y * p.tiles_x;
@@ -105,135 +136,226 @@ __global__ __launch_bounds__(kNW * 64) void downblock_kernel(const DownParams p)
     auto patch_org = [&](int tile) -> PatchOrg {
         const int b = tile / tiles_per_img, tr = tile - b * tiles_per_img;
         const int ty0 = tr / p.tiles_x, tx0 = tr - ty0 * p.tiles_x;
-        const int iy0 = 2 * ty0 * kTH - 1, ix0 = 2 * tx0 * kTW - 1;
+        const int iy0 = 2 * ty0 * G::TH - 1, ix0 = 2 * tx0 * kTW - 1;
         return {p.in + ((long long)(b * H + iy0) * W + ix0) * p.in_ld_b, iy0, ix0};
     };
     auto dma_one = [&](const PatchOrg& o, int q, char* xb) {  // branch-free: issued from inside the MFMA loop
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));                     // opaque: no per-call-site slot decode hoisted out of the tile loop
         const int slot = q * 64 + lane_o;
-        const int px = slot / kSPPX, part = slot - px * kSPPX;
-        const int pr = px / kPW, pc = px - pr * kPW;
+        const int px = slot / G::SPPX, part = slot - px * G::SPPX;
+        const int pr = px / PW, pc = px - pr * PW;
         const int iy = o.iy0 + pr, ix = o.ix0 + pc;
-        const bool valid = px < kPP && part < kCBI && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const bool valid = px < G::PP && part < G::CBI && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         const char* src = o.org + (pr * W + pc) * p.in_ld_b + part * 16;
         glds16(valid ? src : p.zero, xb + q * 1024);
     };
-    constexpr int NQW = (kNQ + kNW - 1) / kNW;               // DMA instructions per wave and tile (6)
-    constexpr int SP = kKSA / NQW;                           // one every SP k-steps of the 3x3 loop
-    static_assert(SP >= 1 && NQW * SP <= kKSA, "not enough k-steps to carry the DMA issue");
+    constexpr int NQW = (G::NQ + kNW - 1) / kNW;             // DMA instructions per wave and tile
+    constexpr int NSTEP = G::UNIFORM_K ? 3 * G::CQ * 9 : KSA;    // MFMA-loop steps that can carry one each
+    constexpr int SP = NSTEP / NQW;
+    static_assert(SP >= 1 && NQW * SP <= NSTEP, "not enough MFMA-loop steps to carry the DMA issue");
 
     int tile = first_tile(gridDim.x, blockIdx.x);
     if (tile < p.n_tiles) {
         const PatchOrg o = patch_org(tile);
 #pragma unroll 1
-        for (int q = wave; q < kNQ; q += kNW) dma_one(o, q, smem);
+        for (int q = wave; q < G::NQ; q += kNW) dma_one(o, q, smem);
     }
     int cur = 0;
     bool prev_full = false;
     for (; tile < p.n_tiles; tile += gridDim.x, cur ^= 1) {
         const int b = tile / tiles_per_img, tr = tile - b * tiles_per_img;
         const int ty0 = tr / p.tiles_x, tx0 = tr - ty0 * p.tiles_x;
-        const int y0 = ty0 * kTH, x0 = tx0 * kTW;
-        const char* s_x = smem + cur * kXPB;
+        const int y0 = ty0 * G::TH, x0 = tx0 * kTW;
+        const char* s_x = smem + cur * G::XPB;
         // this tile's patch has landed (own DMA: vmcnt; the other waves': barrier).  vmcnt is in-order: after a full tile the
         // youngest DMA instruction is older than that tile's 4 output stores, which may stay in flight.
         if (prev_full) wait_vmcnt<4>(); else wait_vmcnt<0>();
         down_lds_barrier();
         const bool has_next = tile + (int)gridDim.x < p.n_tiles;
-        prev_full = y0 + kTH <= Ho && x0 + kTW <= Wo;
-        char* xbn = smem + (cur ^ 1) * kXPB;
+        prev_full = y0 + G::TH <= Ho && x0 + kTW <= Wo;
+        char* xbn = smem + (cur ^ 1) * G::XPB;
         PatchOrg on = {nullptr, 0, 0};
         if (has_next) on = patch_org(tile + (int)gridDim.x);
 
         const int ty = 4 * pg;                               // first of this wave's 4 output rows inside the tile
-        // ---- 1. t = SiLU(Wa (*) x + ba): 4 blocks of 16 pixels (4 rows), one M block ----
-        {
-            const char* base = s_x + ((2 * ty) * kPW + 2 * l15) * kPXB;
-            f32x4 acc[4];
+        // ---- 1. SiLU(Wa (*) x + ba): 4 blocks of 16 pixels (4 rows), one M block ----
+        f32x4 acc[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (G::UNIFORM_K) {
+            // k-steps do not straddle taps: fragment (input row ri, dx, channel quad) serves output row j with dy = ri - 2 j, i.e.
+            // two rows when ri is even -- load it once (9 loads for 12 (row, dy) pairs), two fragments ahead of the MFMAs
+            constexpr int CQ = G::CQ;
+            const char* base = s_x + ((2 * ty) * PW + 2 * l15) * PXB + koffa[0];
+            auto frag = [&](int dx, int cq, int ri) -> bf16x8 { return *(const bf16x8*)(base + (ri * PW + dx) * PXB + cq * 64); };
+            auto wfrag = [&](int s) -> bf16x8 {
+                if constexpr (KT > 0) {
+                    if (s >= KREG) return *(const bf16x8*)(s_wt + (mb * KT + (s - KREG)) * 1024 + lane * 16);
+                    return wa[s < KREG ? s : 0];
+                } else return wa[s];
+            };
+            bf16x8 f0 = frag(0, 0, 0), f1 = frag(0, 0, 1);
+            int step = 0;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int cq = 0; cq < CQ; ++cq) {
+                    bf16x8 wf[3];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) wf[dy] = wfrag((dy * 3 + dx) * CQ + cq);
+#pragma unroll
+                    for (int ri = 0; ri < 9; ++ri, ++step) {
+                        int r2 = ri + 2, cq2 = cq, dx2 = dx;    // the fragment two steps ahead
+                        if (r2 >= 9) { r2 -= 9; if (++cq2 == CQ) { cq2 = 0; ++dx2; } }
+                        bf16x8 f2 = f0;
+                        if (dx2 < 3) f2 = frag(dx2, cq2, r2);
+                        if (step % SP == 0 && step / SP < NQW) {
+                            const int q = wave + kNW * (step / SP);
+                            if (has_next && q < G::NQ) dma_one(on, q, xbn);
+                        }
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int d = ri - dy;
+                            if (d < 0 || (d & 1) || d / 2 > 3) continue;
+                            acc[d / 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[dy], f0, acc[d / 2], 0, 0, 0);
+                        }
+                        f0 = f1; f1 = f2;
+                        __builtin_amdgcn_sched_barrier(0);   // keep later steps' LDS loads from being hoisted into spills
+                    }
+                }
+        } else {
+            const char* base = s_x + ((2 * ty) * PW + 2 * l15) * PXB;
             bf16x8 fn[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fn[j] = *(const bf16x8*)(base + (2 * j * kPW) * kPXB + koffa[0]);
+            for (int j = 0; j < 4; ++j) fn[j] = *(const bf16x8*)(base + (2 * j * PW) * PXB + koffa[0]);
 #pragma unroll
-            for (int s = 0; s < kKSA; ++s) {
+            for (int s = 0; s < KSA; ++s) {
                 bf16x8 f[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) f[j] = fn[j];
-                if (s + 1 < kKSA) {
+                if (s + 1 < KSA) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) fn[j] = *(const bf16x8*)(base + (2 * j * kPW) * kPXB + koffa[s + 1]);
+                    for (int j = 0; j < 4; ++j) fn[j] = *(const bf16x8*)(base + (2 * j * PW) * PXB + koffa[s + 1 < KSA ? s + 1 : 0]);
                 }
                 if (s % SP == 0 && s / SP < NQW) {           // one DMA instruction of the next tile's patch
                     const int q = wave + kNW * (s / SP);
-                    if (has_next && q < kNQ) dma_one(on, q, xbn);
+                    if (has_next && q < G::NQ) dma_one(on, q, xbn);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s], f[j], acc[j], 0, 0, 0);
             }
-            const f32x4 bav = *(const f32x4*)(s_b + cbase);
+        }
+        const f32x4 bav = *(const f32x4*)(s_b + cbase);
+        if constexpr (FUSE) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x4 v = down_silu4(acc[j] + bav);
-                down_lds_write_b64(s_t + ((ty + j) * kTW + l15) * kTPXB + cbase * 2, make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])));
+                down_lds_write_b64(s_t + ((ty + j) * kTW + l15) * G::TPXB + cbase * 2, make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])));
             }
-        }
-        down_lds_barrier();
-        // ---- 2. y = SiLU(Wb t + bb) ----
-        {
-            const char* base = s_t + (ty * kTW + l15) * kTPXB + g * 16;
-            f32x4 acc[4];
+            down_lds_barrier();
+            // ---- 2. y = SiLU(Wb t + bb) ----
+            const char* tb = s_t + (ty * kTW + l15) * G::TPXB + g * 16;
+            f32x4 acc2[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j) acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < kKSB; ++s) {
+            for (int s = 0; s < KSB; ++s) {
                 bf16x8 f[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) f[j] = *(const bf16x8*)(base + j * kTW * kTPXB + s * 64);
+                for (int j = 0; j < 4; ++j) f[j] = *(const bf16x8*)(tb + j * kTW * G::TPXB + s * 64);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s], f[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s], f[j], acc2[j], 0, 0, 0);
             }
-            const f32x4 bbv = *(const f32x4*)(s_b + kCmid + cbase);
-            const int x = x0 + l15;
+            const f32x4 bbv = *(const f32x4*)(s_b + CMID + cbase);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int y = y0 + ty + j;
-                const f32x4 v = down_silu4(acc[j] + bbv);
-                if (y < Ho && x < Wo)
-                    *(uint2*)(p.out + ((long long)(b * Ho + y) * Wo + x) * p.out_ld_b + cbase * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-            }
+            for (int j = 0; j < 4; ++j) acc[j] = acc2[j] + bbv;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + bav;
+        }
+        const int x = x0 + l15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = y0 + ty + j;
+            f32x4 v = acc[j];
+            if (FUSE || p.act) v = down_silu4(v);
+            if (y < Ho && x < Wo)
+                *(uint2*)(p.out + ((long long)(b * Ho + y) * Wo + x) * p.out_ld_b + cbase * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
         }
     }
 }
 
 int g_down_cus = 0;
+void* g_down_zero = nullptr;
 
-}  // namespace
+int down_common(DownParams& p, const void* in_dev, int in_ld, int in_choff, int cin, void* out_dev, int out_ld, int out_choff, int cout,
+                const void* packed_w_dev, const float* bias_dev, int B, int H, int W, int th) {
+    AQ_REQUIRE(in_dev && out_dev && packed_w_dev && bias_dev, "downblock: null pointer");
+    AQ_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "downblock: H and W must be even (got %dx%d)", H, W);
+    AQ_REQUIRE(in_ld % 8 == 0 && out_ld % 8 == 0 && in_choff % 8 == 0 && out_choff % 8 == 0 && in_choff + cin <= in_ld && out_choff + cout <= out_ld,
+               "downblock: channel slices must be 8-aligned and inside their rows");
+    AQ_REQUIRE((long long)B * H * W < (1LL << 31), "downblock: batch too large");
+    p.in = (const char*)in_dev + (size_t)in_choff * 2; p.in_ld_b = in_ld * 2;
+    p.out = (char*)out_dev + (size_t)out_choff * 2; p.out_ld_b = out_ld * 2;
+    p.w = (const char*)packed_w_dev; p.bias = bias_dev;
+    p.B = B; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2;
+    p.tiles_x = (p.Wo + kTW - 1) / kTW; p.tiles_y = (p.Ho + th - 1) / th;
+    AQ_REQUIRE((long long)B * p.tiles_x * p.tiles_y < (1LL << 30), "downblock: batch too large");
+    p.n_tiles = B * p.tiles_x * p.tiles_y;
+    if (!g_down_zero) {                                      // allocated once per process
+        AQ_CHECK_HIP(hipMalloc(&g_down_zero, 256));
+        AQ_CHECK_HIP(hipMemset(g_down_zero, 0, 256));
+    }
+    p.zero = (const char*)g_down_zero;
+    if (g_down_cus == 0) {
+        int dev = 0, cus = 256;
+        AQ_CHECK_HIP(hipGetDevice(&dev));
+        AQ_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        g_down_cus = cus;
+    }
+    return AQ_OK;
+}
 
-// Packs the fused fp32 weights -- wa KRSC (96,3,3,48), wb KRSC (96,1,1,96) -- into the A-fragment image the kernel loads once per
-// workgroup: [M block 6][k-step 14 + 3][lane 64] x 8 bf16; lane (m = lane & 15, g = lane >> 4) holds output channel 16 * Mblock + m
-// and K block 4 * kstep + g (3x3: 8 consecutive input channels of one tap, tap-major; K blocks past 54 are zero).
-extern "C" int aq_pack_downblock_weights(const float* wa_host, const float* wb_host, void* packed_dev, size_t* bytes, void* stream) {
-    AQ_REQUIRE(wa_host && wb_host && bytes, "pack_downblock: null pointer");
-    *bytes = (size_t)6 * kWFrags * 64 * 16;
+template <int CIN, int CMID, bool FUSE, int KT>
+int launch_down(const DownParams& p, hipStream_t stream) {
+    using G = DownGeom<CIN, CMID, FUSE, KT>;
+    static bool attr = false;
+    auto fn = downblock_kernel<CIN, CMID, FUSE, KT>;
+    if (!attr) {
+        AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        attr = true;
+    }
+    long long grid = g_down_cus;                             // > 150 KB of LDS: one persistent workgroup per CU
+    if (grid > p.n_tiles) grid = p.n_tiles;
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kNW * 64), G::LDS, stream, p);
+    AQ_CHECK_HIP(hipGetLastError());
+    return AQ_OK;
+}
+
+// A-fragment image of a 3x3 (tap-major K blocks of 8 input channels) optionally followed by a 1x1:
+// [M block][k-step ksa + ksb][lane 64] x 8 bf16; lane (m = lane & 15, g = lane >> 4) holds output channel 16 * Mblock + m and
+// K block 4 * kstep + g.
+int pack_down(const float* wa_host, const float* wb_host, int cin, int cmid, void* packed_dev, size_t* bytes, void* stream) {
+    const int cbi = cin / 8, nblk = 9 * cbi, ksa = (nblk + 3) / 4, ksb = wb_host ? cmid / 32 : 0, mbn = cmid / 16;
+    *bytes = (size_t)mbn * (ksa + ksb) * 64 * 16;
     if (!packed_dev) return AQ_OK;
     bf16_t* host = (bf16_t*)calloc(1, *bytes);
     AQ_REQUIRE(host, "pack_downblock: out of host memory");
-    for (int mb = 0; mb < 6; ++mb)
-        for (int s = 0; s < kWFrags; ++s)
+    for (int mb = 0; mb < mbn; ++mb)
+        for (int s = 0; s < ksa + ksb; ++s)
             for (int lane = 0; lane < 64; ++lane) {
                 const int co = mb * 16 + (lane & 15), g = lane >> 4;
-                bf16_t* dst = host + (((size_t)mb * kWFrags + s) * 64 + lane) * 8;
-                if (s < kKSA) {
+                bf16_t* dst = host + (((size_t)mb * (ksa + ksb) + s) * 64 + lane) * 8;
+                if (s < ksa) {
                     const int blk = 4 * s + g;
-                    if (blk < kNBLKA) {
-                        const int tap = blk / kCBI, c8 = blk % kCBI;
-                        for (int e = 0; e < 8; ++e) dst[e] = aq_f2bf(wa_host[((size_t)co * 9 + tap) * kCin + c8 * 8 + e]);
+                    if (blk < nblk) {
+                        const int tap = blk / cbi, c8 = blk % cbi;
+                        for (int e = 0; e < 8; ++e) dst[e] = aq_f2bf(wa_host[((size_t)co * 9 + tap) * cin + c8 * 8 + e]);
                     }
                 } else {
-                    const int blk = 4 * (s - kKSA) + g;
-                    for (int e = 0; e < 8; ++e) dst[e] = aq_f2bf(wb_host[(size_t)co * kCmid + blk * 8 + e]);
+                    const int blk = 4 * (s - ksa) + g;
+                    for (int e = 0; e < 8; ++e) dst[e] = aq_f2bf(wb_host[(size_t)co * cmid + blk * 8 + e]);
                 }
             }
     hipError_t e = hipMemcpyAsync(packed_dev, host, *bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
@@ -243,43 +365,38 @@ extern "C" int aq_pack_downblock_weights(const float* wa_host, const float* wb_h
     return AQ_OK;
 }
 
+}  // namespace
+
+// Fused form: wa KRSC (96,3,3,48), wb KRSC (96,1,1,96).
+extern "C" int aq_pack_downblock_weights(const float* wa_host, const float* wb_host, void* packed_dev, size_t* bytes, void* stream) {
+    AQ_REQUIRE(wa_host && wb_host && bytes, "pack_downblock: null pointer");
+    return pack_down(wa_host, wb_host, 48, 96, packed_dev, bytes, stream);
+}
+
 // in: bf16 NHWC [B][H][W][in_ld] with the 48 channels at in_choff; out: [B][H/2][W/2][out_ld] with the 96 channels at out_choff.
 // bias_dev: [192] fp32 (ba | bb).
 extern "C" int aq_downblock(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff,
                             const void* packed_w_dev, const float* bias_dev, int B, int H, int W, void* stream) {
-    AQ_REQUIRE(in_dev && out_dev && packed_w_dev && bias_dev, "downblock: null pointer");
-    AQ_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "downblock: H and W must be even (got %dx%d)", H, W);
-    AQ_REQUIRE(in_ld % 8 == 0 && out_ld % 8 == 0 && in_choff % 8 == 0 && out_choff % 8 == 0 && in_choff + kCin <= in_ld && out_choff + kCout <= out_ld,
-               "downblock: channel slices must be 8-aligned and inside their rows");
-    AQ_REQUIRE((long long)B * H * W < (1LL << 31), "downblock: batch too large");
     DownParams p{};
-    p.in = (const char*)in_dev + (size_t)in_choff * 2; p.in_ld_b = in_ld * 2;
-    p.out = (char*)out_dev + (size_t)out_choff * 2; p.out_ld_b = out_ld * 2;
-    p.w = (const char*)packed_w_dev; p.bias = bias_dev;
-    p.B = B; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2;
-    p.tiles_x = (p.Wo + kTW - 1) / kTW; p.tiles_y = (p.Ho + kTH - 1) / kTH;
-    AQ_REQUIRE((long long)B * p.tiles_x * p.tiles_y < (1LL << 30), "downblock: batch too large");
-    p.n_tiles = B * p.tiles_x * p.tiles_y;
-    static void* zero_page = nullptr;                        // allocated once per process
-    static bool attr = false;
-    if (!zero_page) {
-        AQ_CHECK_HIP(hipMalloc(&zero_page, 256));
-        AQ_CHECK_HIP(hipMemset(zero_page, 0, 256));
-    }
-    p.zero = (const char*)zero_page;
-    if (g_down_cus == 0) {
-        int dev = 0, cus = 256;
-        AQ_CHECK_HIP(hipGetDevice(&dev));
-        AQ_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        g_down_cus = cus;
-    }
-    if (!attr) {
-        AQ_CHECK_HIP(hipFuncSetAttribute((const void*)downblock_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS));
-        attr = true;
-    }
-    long long grid = g_down_cus;                             // 153 KB of LDS: one persistent workgroup per CU
-    if (grid > p.n_tiles) grid = p.n_tiles;
-    hipLaunchKernelGGL(downblock_kernel, dim3((unsigned)grid), dim3(kNW * 64), kLDS, (hipStream_t)stream, p);
-    AQ_CHECK_HIP(hipGetLastError());
-    return AQ_OK;
+    const int rc = down_common(p, in_dev, in_ld, in_choff, 48, out_dev, out_ld, out_choff, 96, packed_w_dev, bias_dev, B, H, W, DownGeom<48, 96, true, 0>::TH);
+    if (rc) return rc;
+    return launch_down<48, 96, true, 0>(p, (hipStream_t)stream);
+}
+
+// Plain 3x3 / stride 2 / pad 1 convolution + bias (+ SiLU), 96 -> 192 channels (the autotuner's AQ_CONV_CFG_DIRECT3X3S2 candidate).
+extern "C" int aq_conv3x3s2_direct_supported(int cin, int cout) { return cin == 96 && cout == 192; }
+
+extern "C" int aq_pack_conv3x3s2_direct(const float* w_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream) {
+    AQ_REQUIRE(w_host && bytes && aq_conv3x3s2_direct_supported(cin, cout), "pack_conv3x3s2_direct: unsupported %d -> %d", cin, cout);
+    return pack_down(w_host, nullptr, cin, cout, packed_dev, bytes, stream);
+}
+
+extern "C" int aq_conv3x3s2_direct(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff, int cin, int cout,
+                                   const void* packed_w_dev, const float* bias_dev, int B, int H, int W, int act, void* stream) {
+    AQ_REQUIRE(aq_conv3x3s2_direct_supported(cin, cout), "conv3x3s2_direct: unsupported %d -> %d", cin, cout);
+    DownParams p{};
+    const int rc = down_common(p, in_dev, in_ld, in_choff, cin, out_dev, out_ld, out_choff, cout, packed_w_dev, bias_dev, B, H, W, DownGeom<96, 192, false, 3>::TH);
+    if (rc) return rc;
+    p.act = act;
+    return launch_down<96, 192, false, 3>(p, (hipStream_t)stream);
 }

@@ -34,7 +34,8 @@ struct PackedW {
     void* w = nullptr;      // [cout_rows][kgroups_pad] x 16 B
     float* bias = nullptr;  // [cout_rows]
     int kgroups = 0, kgroups_pad = 0, G = 0, cout_rows = 0;
-    void* w_direct = nullptr;   // 1x1 layers the direct kernel supports: its A-fragment image (csrc/conv1x1_direct.hip)
+    void* w_direct = nullptr;   // layers a direct kernel supports: its A-fragment image (csrc/conv1x1_direct.hip, csrc/downblock.hip)
+    int direct_cfg = -1;        // AQ_CONV_CFG_DIRECT1X1 / AQ_CONV_CFG_DIRECT3X3S2
 };
 
 // Host-side packing: KRSC fp32 -> [cout_rows][kgroups_pad*16 B] of bf16 / fp32, zero padded.
@@ -154,8 +155,14 @@ int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStr
     p.act = op.act;
     int cfg = force_cfg >= 0 ? force_cfg : e->conv_cfg[oi];
     if (cfg < 0 && e->tuned_B == B && e->tuned_H == e->lay_H && e->tuned_W == e->lay_W) cfg = e->tuned_cfg[oi];
+    if (cfg == AQ_CONV_CFG_DIRECT3X3S2) {
+        if (pw.direct_cfg != cfg) { aq_set_error("conv op %d has no direct 3x3/s2 form", oi); return AQ_ERR_INVALID; }
+        return aq_conv3x3s2_direct(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
+                                   tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
+                                   op.src.channels, op.dst.channels, pw.w_direct, pw.bias, B, ps.h, ps.w, op.act, stream);
+    }
     if (cfg == AQ_CONV_CFG_DIRECT1X1) {
-        if (!pw.w_direct) { aq_set_error("conv op %d has no direct 1x1 form", oi); return AQ_ERR_INVALID; }
+        if (pw.direct_cfg != cfg) { aq_set_error("conv op %d has no direct 1x1 form", oi); return AQ_ERR_INVALID; }
         return aq_conv1x1_direct(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
                                  tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
                                  op.src.channels, op.dst.channels, pw.w_direct, pw.bias, (long long)B * pd.h * pd.w, op.act, stream);
@@ -428,6 +435,18 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
                 aq_set_error("engine_create: direct 1x1 weight upload failed (op %zu)", oi);
                 return fail(AQ_ERR_HIP);
             }
+            pw.direct_cfg = AQ_CONV_CFG_DIRECT1X1;
+        }
+        if (d->precision == AQ_BF16 && op.k == 3 && op.stride == 2 && op.pad == 1 && op.res.tensor < 0 && e->tensors[op.dst.tensor].dtype == AQ_T_ACT &&
+            aq_conv3x3s2_direct_supported(op.src.channels, op.dst.channels)) {
+            size_t nb = 0;
+            if (aq_pack_conv3x3s2_direct(op.weight, op.src.channels, op.dst.channels, nullptr, &nb, nullptr) != AQ_OK ||
+                hipMalloc(&pw.w_direct, nb) != hipSuccess ||
+                aq_pack_conv3x3s2_direct(op.weight, op.src.channels, op.dst.channels, pw.w_direct, &nb, nullptr) != AQ_OK) {
+                aq_set_error("engine_create: direct 3x3/s2 weight upload failed (op %zu)", oi);
+                return fail(AQ_ERR_HIP);
+            }
+            pw.direct_cfg = AQ_CONV_CFG_DIRECT3X3S2;
         }
         op.weight = nullptr; op.bias = nullptr;   // host pointers are not kept
     }
@@ -484,7 +503,7 @@ extern "C" int aq_engine_num_ops(aq_engine* e) { return e ? (int)e->ops.size() :
 
 extern "C" int aq_engine_set_conv_config(aq_engine* e, int op, int cfg) {
     AQ_REQUIRE(e && op >= 0 && op < (int)e->ops.size() && e->ops[op].kind == AQ_OP_CONV, "set_conv_config: op %d is not a conv", op);
-    AQ_REQUIRE((cfg >= -1 && cfg < aq_conv_num_configs()) || (cfg == AQ_CONV_CFG_DIRECT1X1 && e->packed[op].w_direct),
+    AQ_REQUIRE((cfg >= -1 && cfg < aq_conv_num_configs()) || (cfg >= AQ_CONV_CFG_DIRECT1X1 && cfg == e->packed[op].direct_cfg),
                "set_conv_config: bad config %d for op %d", cfg, op);
     e->conv_cfg[op] = cfg;
     return AQ_OK;
@@ -515,8 +534,8 @@ extern "C" int aq_engine_autotune(aq_engine* e, const uint8_t* tiles_dev, int B,
         float best = 1e30f;
         int best_cfg = -1;
         for (int ci = 0; ci <= ncfg && rc == AQ_OK; ++ci) {
-            const int c = ci < ncfg ? ci : AQ_CONV_CFG_DIRECT1X1;     // last candidate: the direct 1x1 kernel, where it applies
-            if (c == AQ_CONV_CFG_DIRECT1X1 && !e->packed[oi].w_direct) continue;
+            const int c = ci < ncfg ? ci : e->packed[oi].direct_cfg;  // last candidate: the direct kernel, where one applies
+            if (c < 0) continue;
             rc = run_conv(e, (int)oi, ws, tiles_dev, B, stream, c);   // warm-up (also sets the LDS attribute)
             if (rc == AQ_ERR_INVALID) { rc = AQ_OK; continue; }       // this tile shape does not apply to this layer
             if (rc) break;

@@ -177,6 +177,15 @@ int aq_conv1x1_direct_supported(int cin, int cout);
 int aq_pack_conv1x1_direct(const float* w_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream);
 int aq_conv1x1_direct(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff, int cin, int cout,
                       const void* packed_w_dev, const float* bias_dev, long long npix, int act, void* stream);
+
+/* Direct 3x3 / stride 2 / pad 1 convolution (bf16; 96 -> 192 channels: yolov5m's model.3), the plain form of the down-block kernel:
+ * input patches by LDS-DMA, weights in registers (last k-steps in LDS), each input-row fragment loaded once for the output rows it
+ * serves.  Autotuner candidate AQ_CONV_CFG_DIRECT3X3S2. */
+#define AQ_CONV_CFG_DIRECT3X3S2 1001
+int aq_conv3x3s2_direct_supported(int cin, int cout);
+int aq_pack_conv3x3s2_direct(const float* w_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream);
+int aq_conv3x3s2_direct(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff, int cin, int cout,
+                        const void* packed_w_dev, const float* bias_dev, int B, int H, int W, int act, void* stream);
 /* uint8 RGB NHWC -> 2x2 space-to-depth, 16 channels, value/255 ([UPSTREAM detect.py: im.float()/255]). */
 int aq_preprocess_s2d(const uint8_t* tiles_dev, void* out_dev, int B, int H, int W, int precision, void* stream);
 /* Letterbox on device (the real 1024x1024 tiles of reference src/load_data/tile_tifs.py:13 -> 640x640):

@@ -256,7 +256,31 @@ def test_direct_conv1x1_in_engine(lib, synth_ck):
         if o.kind == 1 and o.k == 1 and o.res is None and eng.lib.aq_conv1x1_direct_supported(o.src.channels, o.dst.channels) and o.level < 0:
             eng.set_conv_config(i, engine.CONV_CFG_DIRECT1X1)
             forced += 1
+        if o.kind == 1 and o.k == 3 and o.stride == 2 and eng.lib.aq_conv3x3s2_direct_supported(o.src.channels, o.dst.channels):
+            eng.set_conv_config(i, engine.CONV_CFG_DIRECT3X3S2)
+            forced += 1
     assert forced >= 5
     got = eng.forward_raw(x).float().cpu()
     err = (got - ref).abs()
     assert float(err[..., 4].max()) < 0.1 and float(err[..., :4].mean()) < 1.0, (float(err[..., 4].max()), float(err[..., :4].mean()))
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 32), (1, 36, 44), (2, 160, 160), (1, 6, 10)])
+def test_direct_conv3x3s2_matches_reference(lib, shape):
+    """aq_conv3x3s2_direct (96 -> 192, the plain form of the down-block kernel) vs F.conv2d on bf16-rounded operands; slices in and out;
+    one exact tile, ragged tiles, many tiles, a sub-tile image; with and without SiLU."""
+    from aquaculture_amd import engine
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * 5 + W)
+    xw = (torch.randn(B, H, W, 112, generator=g) * 0.8).bfloat16().cuda()
+    x = xw[..., 8:104]
+    w = torch.randn(192, 96, 3, 3, generator=g) * (2.0 / (9 * 96)) ** 0.5
+    b = torch.randn(192, generator=g) * 0.2
+    outw = torch.full((B, H // 2, W // 2, 200), 7.0, dtype=torch.bfloat16, device="cuda")
+    for act in (True, False):
+        engine.conv3x3s2_direct_nhwc(x, w, b, act, out=outw[..., 8:])
+        ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.bfloat16().float(), b, stride=2, padding=1)
+        ref = (F.silu(ref) if act else ref).permute(0, 2, 3, 1)
+        got = outw[..., 8:].float().cpu()
+        assert (outw[..., :8] == 7.0).all()
+        torch.testing.assert_close(got, ref.bfloat16().float(), rtol=2 ** -7, atol=4e-3)
