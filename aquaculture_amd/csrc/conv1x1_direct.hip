@@ -6,9 +6,11 @@
 //   * pixels are a flat list (a 1x1 needs no geometry); a persistent workgroup of 12 waves owns TP consecutive pixels;
 //   * the whole [TP][Cin] input tile arrives by LDS-DMA into one half of a double buffer (the next tile's DMA is issued as soon
 //     as the barrier that frees the other half is passed);
-//   * wave (M block mb, pixel group pg) keeps its 16 output channels' weights in registers (Cin / 8 VGPRs), reads MFMA B
-//     fragments straight from the tile (pixel stride 2 mod 4 sixteen-byte slots: conflict-free for ds_read_b128's lane groups)
-//     and stores bias + SiLU results from the 16x16 C fragments.
+//   * a wave owns a PAIR of 16-row M blocks (32 output channels) and a pixel group; it keeps those weights in registers (Cin / 4
+//     VGPRs), reads MFMA B fragments straight from the tile (pixel stride 2 mod 4 sixteen-byte slots: conflict-free for
+//     ds_read_b128's lane groups), each fragment feeding both blocks;
+//   * the rows of a pair are permuted at packing time -- block m, row 4 g + i holds channel 8 g + 4 m + i -- so that the two C
+//     fragments of a lane are 8 CONSECUTIVE output channels: one 16-byte store per pixel and lane, 64-byte runs per wave.
 // One barrier per tile.  The engine's autotuner times it against the implicit-GEMM tile shapes per layer (config id
 // AQ_CONV_CFG_DIRECT1X1) and keeps whichever is faster.
 #include "conv_device.h"
@@ -59,9 +61,10 @@ __global__ __launch_bounds__(kNW * 64) void conv1x1_direct_kernel(const C1Params
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    static_assert(MBW == 2, "the paired-row layout below is written for two M blocks per wave");
     const int mb0 = (wave % G::MG) * MBW, pg = wave / G::MG;  // first of this wave's M blocks; pixel group
     const int g = lane >> 4, l15 = lane & 15;
-    const int cbase = mb0 * 16 + g * 4;
+    const int cbase = mb0 * 16 + g * 8;                      // this lane's 8 consecutive output channels
 
     bf16x8 wv[KS][MBW];
 #pragma unroll
@@ -90,8 +93,8 @@ __global__ __launch_bounds__(kNW * 64) void conv1x1_direct_kernel(const C1Params
         const long long n0 = (long long)tile * G::TP;
         const char* s_x = smem + cur * G::XPB;
         // this tile has landed (own DMA: vmcnt; other waves': barrier), and every wave is done with the other buffer.  vmcnt is
-        // in-order: after a full tile the DMA is older than that tile's NBW * MBW output stores, which may stay in flight.
-        if (prev_full) wait_vmcnt<NBW * MBW>(); else wait_vmcnt<0>();
+        // in-order: after a full tile the DMA is older than that tile's NBW output stores, which may stay in flight.
+        if (prev_full) wait_vmcnt<NBW>(); else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(kNW * 64) void conv1x1_direct_kernel(const C1Params
 
         f32x4 bv[MBW];
 #pragma unroll
-        for (int m = 0; m < MBW; ++m) bv[m] = *(const f32x4*)(s_b + cbase + m * 16);
+        for (int m = 0; m < MBW; ++m) bv[m] = *(const f32x4*)(s_b + cbase + m * 4);
 #pragma unroll 2
         for (int j = 0; j < NBW; ++j) {
             const int px = (pg * NBW + j) * 16 + l15;
@@ -115,13 +118,11 @@ __global__ __launch_bounds__(kNW * 64) void conv1x1_direct_kernel(const C1Params
             for (int s = 0; s < KS; ++s)
 #pragma unroll
                 for (int m = 0; m < MBW; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[s][m], f[s], acc[m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < MBW; ++m) {
-                f32x4 v = acc[m] + bv[m];
-                if (p.act) v = c1_silu4(v);
-                if (n0 + px < p.npix)
-                    *(uint2*)(p.out + (n0 + px) * p.out_ld_b + (cbase + m * 16) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-            }
+            f32x4 v0 = acc[0] + bv[0], v1 = acc[1] + bv[1];
+            if (p.act) { v0 = c1_silu4(v0); v1 = c1_silu4(v1); }
+            if (n0 + px < p.npix)
+                *(uint4*)(p.out + (n0 + px) * p.out_ld_b + cbase * 2) =
+                    make_uint4(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3]));
         }
     }
 }
@@ -153,7 +154,8 @@ extern "C" int aq_conv1x1_direct_supported(int cin, int cout) {
 }
 
 // Packs fused fp32 weights KRSC (cout, 1, 1, cin) into the A-fragment image the kernel loads once per workgroup:
-// [M block][k-step][lane] x 8 bf16; lane (m = lane & 15, g = lane >> 4) holds output channel 16 * Mblock + m, input channels
+// [M block][k-step][lane] x 8 bf16; M blocks come in pairs covering 32 channels: block 2 P + m, row r = lane & 15 holds output
+// channel 32 P + 8 (r >> 2) + 4 m + (r & 3) (see the kernel header); lane group g = lane >> 4 holds input channels
 // 32 * kstep + 8 * g .. + 7.
 extern "C" int aq_pack_conv1x1_direct(const float* w_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream) {
     AQ_REQUIRE(w_host && bytes && aq_conv1x1_direct_supported(cin, cout), "pack_conv1x1_direct: unsupported %d -> %d", cin, cout);
@@ -165,7 +167,8 @@ extern "C" int aq_pack_conv1x1_direct(const float* w_host, int cin, int cout, vo
     for (int mb = 0; mb < mbt; ++mb)
         for (int s = 0; s < ks; ++s)
             for (int lane = 0; lane < 64; ++lane) {
-                const int co = mb * 16 + (lane & 15), g = lane >> 4;
+                const int r = lane & 15, g = lane >> 4;
+                const int co = (mb >> 1) * 32 + 8 * (r >> 2) + 4 * (mb & 1) + (r & 3);
                 bf16_t* dst = host + (((size_t)mb * ks + s) * 64 + lane) * 8;
                 for (int e = 0; e < 8; ++e) dst[e] = aq_f2bf(w_host[(size_t)co * cin + 32 * s + 8 * g + e]);
             }
@@ -201,8 +204,8 @@ extern "C" int aq_conv1x1_direct(const void* in_dev, int in_ld, int in_choff, vo
         g_c1_cus = cus;
     }
     const hipStream_t st = (hipStream_t)stream;
-    if (cin == 96) return launch_c1<3, 6, 1, 8>(p, st);
-    if (cin == 192) return launch_c1<6, 12, 1, 8>(p, st);
-    if (cout == 192) return launch_c1<12, 12, 1, 4>(p, st);
-    return launch_c1<12, 24, 2, 4>(p, st);
+    if (cin == 96) return launch_c1<3, 6, 2, 4>(p, st);      // 3 channel pairs x 4 pixel groups, 256-pixel tiles
+    if (cin == 192) return launch_c1<6, 12, 2, 4>(p, st);    // 6 x 2, 128-pixel tiles
+    if (cout == 192) return launch_c1<12, 12, 2, 2>(p, st);  // 6 x 2, 64-pixel tiles
+    return launch_c1<12, 24, 2, 4>(p, st);                   // 12 x 1, 64-pixel tiles
 }
