@@ -12,8 +12,10 @@
 //     16-byte run of the patch -- the padded K positions read the neighbouring pixel's (finite) values against zero weights;
 //   * M = cout is tiled with 16-row MFMA blocks (v_mfma_f32_16x16x32_bf16 / 16x16x4_f32), so yolov5m's 48 channels are
 //     exactly 3 blocks; the weights (A fragments) stay in registers for the life of the persistent workgroup;
-//   * in the 16x16 C/D layout a lane holds 4 consecutive channels of one pixel: bias + SiLU in registers, then one
-//     8-byte (bf16) / 16-byte (fp32) NHWC store per block -- no LDS round trip in the epilogue.
+//   * in the 16x16 C/D layout a lane holds rows 4 g .. 4 g + 3 of every M block; the weight rows are PERMUTED at packing time
+//     (block m, row 4 g + i = channel 4 MB g + 4 m + i) so that those are 4 MB consecutive channels: bias + SiLU in registers, then
+//     a lane's stores of one pixel form one contiguous run (24 B for 48 bf16 channels), the four lane groups cover the pixel and
+//     the 16 pixels of a wave are contiguous in NHWC -- no LDS round trip in the epilogue.
 #include "conv_device.h"
 #include <type_traits>
 
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const ConvParams p, c
         for (int m = 0; m < MB; ++m) a[s][m] = ((const afrag_t*)p.w)[(s * MB + m) * 64 + lane];
     f32x4 bias[MB];
 #pragma unroll
-    for (int m = 0; m < MB; ++m) bias[m] = *(const f32x4*)(p.bias + m * 16 + g * 4);      // bias is padded to 64 floats
+    for (int m = 0; m < MB; ++m) bias[m] = *(const f32x4*)(p.bias + (4 * MB) * g + 4 * m);      // bias is padded to 64 floats
     {
         const float v = (float)tid / 255.0f;                 // [UPSTREAM detect.py]: im.float() / 255
         if constexpr (F32) s_lut[tid] = v; else s_lut[tid] = aq_f2bf(v);
@@ -176,12 +178,12 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const ConvParams p, c
                     for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][m], bv, acc[m], 0, 0, 0);
                 }
             }
-            // ---- epilogue: lane = (pixel l15, channels m*16 + 4g .. +3) ----
+            // ---- epilogue: lane = (pixel l15, channels 4 MB g .. 4 MB g + 4 MB - 1): one contiguous run per lane ----
             const int x = x0 + txb + l15;
-            char* orow = p.out + (long long)((b * Ho + y) * Wo + x) * p.out_ld_b;
+            char* orow = p.out + (long long)((b * Ho + y) * Wo + x) * p.out_ld_b + (4 * MB) * g * EB;
+            uint2 pk[MB];                                    // bf16 mode: packed results of the MB blocks
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
-                const int c0 = m * 16 + g * 4;
                 f32x4 v = acc[m] + bias[m];
                 if (p.act) {
                     if constexpr (F32) {
@@ -197,9 +199,20 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const ConvParams p, c
                         v = v * r;
                     }
                 }
-                if (x < Wo && c0 < p.cout) {
-                    if constexpr (F32) *(f32x4*)(orow + c0 * 4) = v;
-                    else *(uint2*)(orow + c0 * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                if constexpr (F32) {
+                    if (x < Wo && (4 * MB) * g + 4 * m < p.cout) *(f32x4*)(orow + m * 16) = v;
+                } else pk[m] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+            if constexpr (!F32) {
+                // 8 MB bytes per lane (24 for 48 channels) at an 8-byte aligned address: 16-byte pieces, then an 8-byte rest.
+                // (cout is a multiple of 8, so a 16-byte piece is written whole or not at all.)
+                struct __attribute__((packed, aligned(8))) U16 { uint32_t v[4]; };
+                if (x < Wo) {
+#pragma unroll
+                    for (int m = 0; m + 1 < MB; m += 2)
+                        if ((4 * MB) * g + 4 * m < p.cout) *(U16*)(orow + m * 8) = U16{{pk[m].x, pk[m].y, pk[m + 1].x, pk[m + 1].y}};
+                    if constexpr (MB & 1)
+                        if ((4 * MB) * g + 4 * (MB - 1) < p.cout) *(uint2*)(orow + (MB - 1) * 8) = pk[MB - 1];
                 }
             }
         }
@@ -251,7 +264,8 @@ extern "C" int aq_pack_stem_weights(const float* w_krsc_host, int cout, int prec
     for (int s = 0; s < ks; ++s)
         for (int m = 0; m < mb; ++m)
             for (int lane = 0; lane < 64; ++lane) {
-                const int co = m * 16 + (lane & 15), g = lane >> 4;
+                const int r = lane & 15, g = lane >> 4;
+                const int co = (4 * mb) * (r >> 2) + 4 * m + (r & 3);   // row permutation, see the kernel header
                 const size_t slot = ((size_t)s * mb + m) * 64 + lane;
                 if (f32) ((float*)host)[slot] = weight(co, s / 6, 4 * (s % 6) + g);
                 else {
