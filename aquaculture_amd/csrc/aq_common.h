@@ -70,6 +70,9 @@ int aq_conv_pick_config(int cout, int npix, int precision);
 int aq_launch_conv_halo(const ConvParams& p, int precision, int out_f32, int hcfg, hipStream_t stream);
 int aq_conv_halo_num_configs();
 unsigned long long* aq_stamp_buffer(size_t* bytes);
+// 256 zero bytes on the CURRENT device (allocated on first use, one per device, never freed): the LDS-DMA source for pixels
+// outside the image in the standalone kernel entry points (the engine passes its own zero page to the conv kernels).
+const char* aq_zero_page();
 int aq_conv_halo_tiles(int hcfg, int* bm, int* bn);
 extern "C" int aq_conv_config_tiles(int cfg, int* bm, int* bn);
 extern "C" int aq_conv_num_configs(void);

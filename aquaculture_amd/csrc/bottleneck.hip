@@ -591,12 +591,8 @@ extern "C" int aq_bottleneck(const void* in_dev, int in_ld, int in_choff, void* 
     }
     p.w = (const char*)packed_w_dev; p.bias = bias_dev;
     p.B = B; p.H = H; p.W = W; p.shortcut = shortcut;
-    static void* zero_page = nullptr;                        // allocated once per process (the engine never frees it)
-    if (!zero_page) {
-        AQ_CHECK_HIP(hipMalloc(&zero_page, 256));
-        AQ_CHECK_HIP(hipMemset(zero_page, 0, 256));
-    }
-    p.zero = (const char*)zero_page;
+    p.zero = aq_zero_page();
+    AQ_REQUIRE(p.zero, "bottleneck: zero page allocation failed");
     if (g_btl_cus == 0) {
         int dev = 0, cus = 256;
         AQ_CHECK_HIP(hipGetDevice(&dev));

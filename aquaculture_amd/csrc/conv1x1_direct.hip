@@ -128,7 +128,6 @@ __global__ __launch_bounds__(kNW * 64) void conv1x1_direct_kernel(const C1Params
 }
 
 int g_c1_cus = 0;
-void* g_c1_zero = nullptr;
 
 template <int KS, int MBT, int MBW, int NBW>
 int launch_c1(C1Params p, hipStream_t stream) {
@@ -192,11 +191,8 @@ extern "C" int aq_conv1x1_direct(const void* in_dev, int in_ld, int in_choff, vo
     p.out = (char*)out_dev + (size_t)out_choff * 2; p.out_ld_b = out_ld * 2;
     p.w = (const char*)packed_w_dev; p.bias = bias_dev;
     p.npix = (int)npix; p.act = act;
-    if (!g_c1_zero) {
-        AQ_CHECK_HIP(hipMalloc(&g_c1_zero, 256));
-        AQ_CHECK_HIP(hipMemset(g_c1_zero, 0, 256));
-    }
-    p.zero = (const char*)g_c1_zero;
+    p.zero = aq_zero_page();
+    AQ_REQUIRE(p.zero, "conv1x1_direct: zero page allocation failed");
     if (g_c1_cus == 0) {
         int dev = 0, cus = 256;
         AQ_CHECK_HIP(hipGetDevice(&dev));

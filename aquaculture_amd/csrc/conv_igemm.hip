@@ -516,6 +516,17 @@ int g_num_cus = 0;
 
 // one index space for tuning: [0, kNumConfigs) = implicit-GEMM tiles, then the halo-reuse 3x3 kernel's tiles
 unsigned long long* aq_stamp_buffer(size_t* bytes) { if (bytes) *bytes = g_stamp_bytes; return g_stamp_buf; }
+const char* aq_zero_page() {
+    static void* pages[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!pages[dev]) {
+        void* q = nullptr;
+        if (hipMalloc(&q, 256) != hipSuccess || hipMemset(q, 0, 256) != hipSuccess) return nullptr;
+        pages[dev] = q;
+    }
+    return (const char*)pages[dev];
+}
 extern "C" int aq_debug_conv_stamp(void* buf_dev, size_t bytes) {
     g_stamp_buf = (unsigned long long*)buf_dev;
     g_stamp_bytes = buf_dev ? bytes : 0;

@@ -287,8 +287,6 @@ __global__ __launch_bounds__(kNW * 64) void downblock_kernel(const DownParams p)
 }
 
 int g_down_cus = 0;
-void* g_down_zero = nullptr;
-
 int down_common(DownParams& p, const void* in_dev, int in_ld, int in_choff, int cin, void* out_dev, int out_ld, int out_choff, int cout,
                 const void* packed_w_dev, const float* bias_dev, int B, int H, int W, int th) {
     AQ_REQUIRE(in_dev && out_dev && packed_w_dev && bias_dev, "downblock: null pointer");
@@ -303,11 +301,8 @@ int down_common(DownParams& p, const void* in_dev, int in_ld, int in_choff, int 
     p.tiles_x = (p.Wo + kTW - 1) / kTW; p.tiles_y = (p.Ho + th - 1) / th;
     AQ_REQUIRE((long long)B * p.tiles_x * p.tiles_y < (1LL << 30), "downblock: batch too large");
     p.n_tiles = B * p.tiles_x * p.tiles_y;
-    if (!g_down_zero) {                                      // allocated once per process
-        AQ_CHECK_HIP(hipMalloc(&g_down_zero, 256));
-        AQ_CHECK_HIP(hipMemset(g_down_zero, 0, 256));
-    }
-    p.zero = (const char*)g_down_zero;
+    p.zero = aq_zero_page();
+    AQ_REQUIRE(p.zero, "downblock: zero page allocation failed");
     if (g_down_cus == 0) {
         int dev = 0, cus = 256;
         AQ_CHECK_HIP(hipGetDevice(&dev));

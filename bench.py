@@ -200,7 +200,7 @@ def main() -> int:
             pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": traffic,
-                "kernel": f"conv_igemm_kernel / conv3x3_halo_kernel (implicit-GEMM conv, autotuned per layer) on the {len(idx3)} 3x3 "
+                "kernel": f"conv3x3_halo_kernel / conv_igemm_kernel / downblock_kernel (3x3 convs, kernel and tile shape autotuned per layer) on the {len(idx3)} 3x3 "
                           f"layers launched as plain convs ({len(idxb)} Bottlenecks run in bottleneck_kernel, reported separately)",
                 "launches_per_step": len(idx3), "avg_launch_ms": round(1e3 * t3 / len(idx3), 4),
                 "flops_per_step": f3, "steps_timed": calls,
