@@ -22,7 +22,7 @@ void aq_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* aq_last_error(void) { return g_err; }
-extern "C" int aq_version(void) { return 1; }
+extern "C" int aq_version(void) { return 2; }   // 2: fused stem / Bottleneck / down-block ops, direct 1x1 and 3x3/s2 autotuner candidates
 
 namespace {
 

@@ -290,7 +290,8 @@ class Engine:
         instead of re-timing (used to keep tuning launches out of rocprof traces)."""
         import json
         B, H, W = self._check_tiles(tiles)
-        key = f"{self.ck.variant}:nc{self.ck.nc}:p{self.precision}:{B}x{H}x{W}:n{self.lib.aq_conv_num_configs()}"
+        key = (f"{self.ck.variant}:nc{self.ck.nc}:p{self.precision}:{B}x{H}x{W}:n{self.lib.aq_conv_num_configs()}"
+               f":v{self.lib.aq_version()}:ops{len(self.plan.ops)}")   # library version + plan shape: new kernels invalidate old tables
         table = {}
         if cache and os.path.exists(cache):
             with open(cache) as f:
