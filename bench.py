@@ -192,6 +192,27 @@ def main() -> int:
         tb = float(ms[idxb].sum()) * 1e-3
         fb = float(sum(plan.ops[i].flops_per_tile for i in idxb)) * B
         ach = f3 / t3 / 1e12
+        # within that family: the one kernel instantiation (autotuned config id) that takes the most time per step
+        single = None
+        if cfgs:
+            groups = {}
+            for i in idx3:
+                groups.setdefault(int(cfgs[i]), []).append(i)
+            cbest = max(groups, key=lambda c: float(ms[groups[c]].sum()))
+            ii = groups[cbest]
+            tt = float(ms[ii].sum()) * 1e-3
+            ff = float(sum(plan.ops[i].flops_per_tile for i in ii)) * B
+            n_ig = eng.lib.aq_conv_num_configs()
+            if cbest >= 1000:
+                kname = "downblock_kernel<96, 192> (direct 3x3/s2)"
+            else:
+                import ctypes as _C
+                bm, bn = _C.c_int(), _C.c_int()
+                eng.lib.aq_conv_config_tiles(cbest, _C.byref(bm), _C.byref(bn))
+                n_igemm = 21                                  # conv_igemm.hip's shape table; halo shapes follow (tools/stamp_conv.py)
+                kname = f"{'conv3x3_halo_kernel' if cbest >= n_igemm else 'conv_igemm_kernel'} tile {bm.value}x{bn.value} (config {cbest} of {n_ig})"
+            single = {"config": cbest, "kernel": kname, "launches_per_step": len(ii), "avg_launch_ms": round(1e3 * tt / len(ii), 4),
+                      "tflops": round(ff / tt / 1e12, 1), "frac": round(ff / tt / 1e12 / peak, 4)}
         traffic = None
         try:
             with open(a.traffic_json) as f:
@@ -204,6 +225,7 @@ def main() -> int:
                           f"layers launched as plain convs ({len(idxb)} Bottlenecks run in bottleneck_kernel, reported separately)",
                 "launches_per_step": len(idx3), "avg_launch_ms": round(1e3 * t3 / len(idx3), 4),
                 "flops_per_step": f3, "steps_timed": calls,
+                "largest_single_kernel": single,
                 "fused_bottleneck": {"launches_per_step": len(idxb), "ms_per_step": round(1e3 * tb, 3),
                                      "tflops": round(fb / tb / 1e12, 1) if tb > 0 else None},
                 "pass": f"{calls} single-stream steps with HIP events right after the timed region (same process, same buffers; "
