@@ -152,20 +152,22 @@ __global__ __launch_bounds__(256) void sppf_pool3_kernel(char* __restrict__ base
 }
 
 // nn.Upsample(scale_factor=2, mode='nearest'): out[b][y][x] = in[b][y/2][x/2]; H, W are the INPUT size.
+// One lane per INPUT 16-byte group: read once, write the 2 x 2 output pixels.  blockIdx.y = input row (b * H + y); one integer
+// division per lane (x from the flat (x, group) index).  (A variant whose blocks loop over rows was not faster.)
 __global__ __launch_bounds__(256) void upsample2x_kernel(const char* __restrict__ in, int in_ld_b,
                                                         char* __restrict__ out, int out_ld_b,
-                                                        int groups, int B, int H, int W) {
-    const int Ho = 2 * H, Wo = 2 * W;
-    const unsigned n = (unsigned)B * Ho * Wo * groups;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        unsigned t = i / (unsigned)groups;
-        const int g = (int)(i - t * groups);
-        unsigned t2 = t / (unsigned)Wo;
-        const int x = (int)(t - t2 * Wo);
-        const int b = (int)(t2 / (unsigned)Ho), y = (int)(t2 - (unsigned)b * Ho);
-        const uint4 v = *(const uint4*)(in + (((long long)b * H + (y >> 1)) * W + (x >> 1)) * in_ld_b + g * 16);
-        *(uint4*)(out + (((long long)b * Ho + y) * Wo + x) * out_ld_b + g * 16) = v;
-    }
+                                                        int groups, int H, int W) {
+    const unsigned xg = blockIdx.x * 256u + threadIdx.x;
+    if (xg >= (unsigned)(W * groups)) return;
+    const unsigned x = xg / (unsigned)groups, g = xg - x * (unsigned)groups;
+    const unsigned row = blockIdx.y;                         // b * H + y; the output rows are 2 * row and 2 * row + 1
+    const uint4 v = *(const uint4*)(in + ((long long)row * W + x) * in_ld_b + g * 16);
+    char* o = out + ((long long)2 * row * (2 * W) + 2 * x) * out_ld_b + g * 16;
+    const long long orow = (long long)2 * W * out_ld_b;
+    *(uint4*)o = v;
+    *(uint4*)(o + out_ld_b) = v;
+    *(uint4*)(o + orow) = v;
+    *(uint4*)(o + orow + out_ld_b) = v;
 }
 
 // [UPSTREAM utils/augmentations.py letterbox -> cv2.resize(INTER_LINEAR) + copyMakeBorder(114)] on uint8 RGB tiles.
@@ -258,9 +260,10 @@ extern "C" int aq_upsample2x(const void* in_dev, int in_ld, int in_choff, void* 
     const int groups = c * eb / 16;
     const long long n = (long long)B * 4 * H * W * groups;
     AQ_REQUIRE(n < (1LL << 31), "upsample2x: batch too large");
-    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+    AQ_REQUIRE((long long)B * H < 65536, "upsample2x: more than 65535 input rows");
+    hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((W * groups + 255) / 256), (unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream,
                        (const char*)in_dev + (long long)in_choff * eb, in_ld * eb,
-                       (char*)out_dev + (long long)out_choff * eb, out_ld * eb, groups, B, H, W);
+                       (char*)out_dev + (long long)out_choff * eb, out_ld * eb, groups, H, W);
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;
 }
