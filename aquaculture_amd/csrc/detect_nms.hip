@@ -109,6 +109,7 @@ struct NmsParams {
     int npow2;
     aq_det* dets;               // [B][max_det]
     int32_t* counts;            // [B]
+    unsigned long long* dbg;    // diagnostics (armed stamp buffer): 8 phase timestamps per tile, else null
 };
 
 constexpr int kFast = 2048;              // candidates handled by the bit-matrix path
@@ -170,6 +171,23 @@ __device__ __forceinline__ bool iou_gt(const float4 bi, float iarea, const float
     return ovr > thr;
 }
 
+// The same predicate, cheaper on average and bit-identical: an empty intersection gives 0 (or NaN) > thr = false without touching
+// the areas; otherwise inter * rcp(union) (relative error < 3 ulp) decides unless it lies within 4e-7 of the threshold, where the
+// exact division is evaluated.
+__device__ __forceinline__ bool iou_gt_fast(const float4 bi, float iarea, const float4 bj, float thr, float thr_lo, float thr_hi) {
+    const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+    const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+    const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+    const float inter = w * h;
+    if (!(inter > 0.0f)) return false;                       // also the NaN case
+    const float jarea = (bj.z - bj.x) * (bj.w - bj.y);
+    const float uni = iarea + jarea - inter;
+    const float q = inter * __builtin_amdgcn_rcpf(uni);
+    if (q > thr_hi) return true;
+    if (q < thr_lo) return false;
+    return inter / uni > thr;                                // ambiguous band (and non-finite q): the reference's own expression
+}
+
 __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), lane);
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
@@ -184,6 +202,8 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     __shared__ int s_kept;
     const int b = blockIdx.x, tid = threadIdx.x;
+    auto stamp = [&](int i) { if (p.dbg && tid == 0) p.dbg[(long long)b * 8 + i] = clock64(); };
+    stamp(0);
     const float* rows = p.rows + (long long)b * p.rows_per_tile * p.no;
     unsigned long long* keys = p.keys + (long long)b * p.npow2;
 
@@ -200,6 +220,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
         }
     }
     __syncthreads();
+    stamp(1);
     int n = s_n;
     if (n == 0) {
         if (tid == 0) p.counts[b] = 0;
@@ -235,55 +256,90 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
             sb[r] = box;
         }
         __syncthreads();
+        stamp(2);
         // D1: suppression bit matrix, upper triangle: bit j of mask[i][w] = IoU(i, 64w + j) > thr, 64w + j > i
         const int nw = (n + 63) >> 6;
-        // the bit matrix lives in LDS when n * nw words fit behind the fast-path arrays, else in the global scratch
-        unsigned long long* mask = ((size_t)n * nw * 8 <= kMaskLds)
-                                       ? (unsigned long long*)(s_raw + kFastLds)
-                                       : p.mask + (long long)b * kFast * kFastWords;
-        for (int item = tid; item < n * nw; item += kNmsThreads) {
-            const int i = item / nw, w = item - i * nw;
-            unsigned long long bits = 0ull;
-            if (w >= (i >> 6)) {
-                const float4 bi = sb[i];
-                const float iarea = (bi.z - bi.x) * (bi.w - bi.y);
+        // the bit matrix lives in LDS when n * nw words fit behind the fast-path arrays, else in the global scratch.  The two
+        // cases run separate copies of the code below so that the LDS case compiles to ds_read/ds_write instead of the flat
+        // loads a run-time selected pointer would need (the greedy scan's critical path is a chain of row loads).
+        const float thr_lo = p.iou_thres * (1.0f - 4e-7f), thr_hi = p.iou_thres * (1.0f + 4e-7f);
+        auto matrix_and_scan = [&](unsigned long long* mask) __attribute__((always_inline)) {
+            // Only words on or right of the diagonal are needed (and read): row block bi = i >> 6 has nw - bi of them.  Items are
+            // enumerated over exactly those words so that every thread gets the same amount of work (a plain (i, w) grid gives
+            // the threads that own the last word column four times the pairs of those that own the first).
+            int total_items = 0;
+            for (int bi = 0; bi < nw; ++bi) total_items += 64 * (nw - bi);
+            for (int item = tid; item < total_items; item += kNmsThreads) {
+                int bi = 0, rem = item;
+                while (rem >= 64 * (nw - bi)) { rem -= 64 * (nw - bi); ++bi; }      // <= nw iterations
+                const int wpr = nw - bi;                     // words per row in this row block
+                const int i = 64 * bi + rem / wpr, w = bi + rem % wpr;
+                if (i >= n) continue;
+                const float4 bi4 = sb[i];
+                const float iarea = (bi4.z - bi4.x) * (bi4.w - bi4.y);
                 const int j0 = w << 6;
                 const int jbeg = max(j0, i + 1), jend = min(j0 + 64, n);
+                unsigned long long bits = 0ull;
+#pragma unroll 4
                 for (int j = jbeg; j < jend; ++j)
-                    if (iou_gt(bi, iarea, sb[j], p.iou_thres)) bits |= 1ull << (j - j0);
+                    if (iou_gt_fast(bi4, iarea, sb[j], p.iou_thres, thr_lo, thr_hi)) bits |= 1ull << (j - j0);
+                mask[(long long)i * nw + w] = bits;
             }
-            mask[(long long)i * nw + w] = bits;
-        }
-        __syncthreads();
-        // D2: greedy scan by one wave; lane w keeps word w of the removed set; mask rows are fetched 8 at a time
-        if (tid < 64) {
-            unsigned long long removed = 0ull;
-            int kept = 0;
-            bool done = false;
-            for (int i0 = 0; i0 < n && !done; i0 += 8) {
-                unsigned long long row[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    row[r] = (i0 + r < n && tid < nw) ? mask[(long long)(i0 + r) * nw + tid] : 0ull;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int i = i0 + r;
-                    if (i < n && !done) {
-                        const unsigned long long cur = readlane64(removed, i >> 6);
-                        if (!((cur >> (i & 63)) & 1ull)) {
-                            if (tid == 0) skept[kept] = (unsigned short)i;
-                            ++kept;
-                            removed |= row[r];
-                            if (kept >= p.max_det) done = true;
-                        }
+            __syncthreads();
+            stamp(3);
+            // D2: greedy scan by one wave, one 64-candidate word at a time.  Lane t keeps word t of the removed set.  For word w,
+            //   1. lane i loads the DIAGONAL word of candidate 64 w + i (which later candidates of the same word it suppresses);
+            //   2. the intra-word greedy runs on scalar bit operations: take the lowest alive bit, keep it, clear the bits its
+            //      diagonal word (v_readlane) suppresses -- one iteration per KEPT candidate, no memory access in the chain;
+            //   3. the kept rows are OR-ed into the removed words of later blocks with independent (pipelined) loads.
+            if (tid < 64) {
+                unsigned long long removed = 0ull;
+                int kept = 0;
+                bool done = false;
+                for (int w = 0; w < nw && !done; ++w) {
+                    const int i_l = 64 * w + tid;
+                    const unsigned long long diag = i_l < n ? mask[(long long)i_l * nw + w] : 0ull;
+                    const int left = n - 64 * w;
+                    const unsigned long long valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+                    unsigned long long alive = valid & ~readlane64(removed, w);
+                    unsigned long long keptmask = 0ull;
+                    while (alive != 0ull) {
+                        const int bit = __builtin_ctzll(alive);
+                        keptmask |= 1ull << bit;
+                        alive &= ~(1ull << bit);
+                        alive &= ~readlane64(diag, bit);
+                        if (kept + __builtin_popcountll(keptmask) >= p.max_det) { done = true; break; }
                     }
+                    if ((keptmask >> tid) & 1ull)
+                        skept[kept + __builtin_popcountll(keptmask & ((1ull << tid) - 1ull))] = (unsigned short)(64 * w + tid);
+                    kept += __builtin_popcountll(keptmask);
+                    unsigned long long km = keptmask, acc = 0ull;
+                    const bool mine = tid > w && tid < nw;   // words of later blocks
+                    while (km != 0ull) {                     // four independent row loads per round
+                        int bits4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            bits4[u] = km != 0ull ? __builtin_ctzll(km) : -1;
+                            km &= km - 1ull;                 // 0 stays 0
+                        }
+                        unsigned long long r4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) r4[u] = (mine && bits4[u] >= 0) ? mask[(long long)(64 * w + bits4[u]) * nw + tid] : 0ull;
+                        acc |= (r4[0] | r4[1]) | (r4[2] | r4[3]);
+                    }
+                    removed |= acc;
                 }
+                if (tid == 0) { p.counts[b] = kept; s_kept = kept; }
             }
-            if (tid == 0) { p.counts[b] = kept; s_kept = kept; }
-        }
+        };
+        if ((size_t)n * nw * 8 <= kMaskLds) matrix_and_scan((unsigned long long*)(s_raw + kFastLds));
+        else matrix_and_scan(p.mask + (long long)b * kFast * kFastWords);
         __syncthreads();
+        stamp(4);
         // E: all threads write the kept rows (descending confidence = ascending rank)
         for (int k = tid; k < s_kept; k += kNmsThreads) emit(sslot[skept[k]], k);
+        __syncthreads();
+        stamp(5);
         return;
     }
 
@@ -394,6 +450,11 @@ extern "C" int aq_nms(const float* rows_dev, int rows_per_tile, int B, int N, in
     s += align_up((size_t)B * N * sizeof(float4), 256);
     p.mask = (unsigned long long*)s;
     p.dets = dets_dev; p.counts = counts_dev;
+    {   // diagnostics: an armed stamp buffer (aq_debug_conv_stamp) receives 8 phase timestamps per tile
+        size_t sbytes = 0;
+        unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
+        p.dbg = (sbuf && (size_t)B * 64 <= sbytes) ? sbuf : nullptr;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         AQ_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kNmsLds));

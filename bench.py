@@ -125,7 +125,7 @@ def main() -> int:
         # independent batches alternate over the streams: batch k+1's high-resolution layers fill the CUs that
         # batch k's low-resolution layers (200-400 tiles on 256 CUs) leave idle
         with torch.cuda.stream(streams[k % len(streams)]):
-            eng.infer(tiles_dev[k % a.pool], 0.25, 0.45, max_det, out=(dets[slot], counts[slot]), slot=k % len(streams))
+            eng.infer(tiles_dev[k % a.pool], float(os.environ.get("AQ_BENCH_CONF", 0.25)), 0.45, max_det, out=(dets[slot], counts[slot]), slot=k % len(streams))
 
     def join():
         for st in streams:
