@@ -52,44 +52,62 @@ __device__ __forceinline__ void decode_row(const DecodeParams& p, const float* s
 // Objectness is evaluated for every candidate; the other 9 sigmoids only where a row is actually written:
 // every row when the full pred tensor is requested (S1 alone), else only rows with obj > conf_thres, which go
 // to the compact candidate list that NMS reads.
+constexpr int kDecPerLane = 4;                               // candidates per lane: their head-map loads are issued together
+
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
-    // grid = (ceil(N / 256), B): one candidate per lane.  Passing candidates take a slot from an LDS counter; ONE global
-    // atomic per block reserves the block's range in the image's compact list (same-address global atomics serialise).
+    // grid = (ceil(N / (256 * kDecPerLane)), B).  Passing candidates take a slot from an LDS counter; ONE global atomic per block
+    // reserves the block's range in the image's compact list (same-address global atomics serialise).
     __shared__ int s_cnt, s_base;
     const int N = p.off[3];
     const int b = blockIdx.y;
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
-    bool pass = false;
-    int local = 0, n = 0, lvl = 0, a = 0, x = 0, y = 0;
-    const float* src = nullptr;
-    float obj = 0.f;
-    if (w < N) {
-        int m = w;                                         // position in the pixel-major walk of this image
-        const int na = p.na;
-        lvl = m >= p.off[2] ? 2 : (m >= p.off[1] ? 1 : 0);
-        m -= p.off[lvl];
-        const int ny = p.ny[lvl], nx = p.nx[lvl];
-        const int pix = (int)((unsigned)m / (unsigned)na);
-        a = m - pix * na;
-        y = (int)((unsigned)pix / (unsigned)nx);
-        x = pix - y * nx;
-        n = p.off[lvl] + a * ny * nx + pix;                // upstream candidate index: a * ny * nx + y * nx + x
-        src = p.head[lvl] + ((long long)(b * ny + y) * nx + x) * p.head_ld + a * p.no;
-        obj = sigmoidf_ref(src[4]);
-        if (p.pred) decode_row(p, src, lvl, a, x, y, obj, p.pred + ((long long)b * N + n) * p.no);
-        pass = p.cand && obj > p.conf_thres;
-        if (pass) local = atomicAdd(&s_cnt, 1);
+    bool pass[kDecPerLane];
+    int local[kDecPerLane], n[kDecPerLane], lvl[kDecPerLane], a[kDecPerLane], x[kDecPerLane], y[kDecPerLane];
+    const float* src[kDecPerLane];
+    float raw[kDecPerLane];
+#pragma unroll
+    for (int k = 0; k < kDecPerLane; ++k) {                  // index math + the objectness loads (independent: all in flight together)
+        const int w = (blockIdx.x * kDecPerLane + k) * blockDim.x + threadIdx.x;
+        pass[k] = false; local[k] = 0; n[k] = 0; lvl[k] = 0; a[k] = 0; x[k] = 0; y[k] = 0; src[k] = nullptr; raw[k] = 0.f;
+        if (w < N) {
+            int m = w;                                     // position in the pixel-major walk of this image
+            const int na = p.na;
+            lvl[k] = m >= p.off[2] ? 2 : (m >= p.off[1] ? 1 : 0);
+            m -= p.off[lvl[k]];
+            const int ny = p.ny[lvl[k]], nx = p.nx[lvl[k]];
+            const int pix = (int)((unsigned)m / (unsigned)na);
+            a[k] = m - pix * na;
+            y[k] = (int)((unsigned)pix / (unsigned)nx);
+            x[k] = pix - y[k] * nx;
+            n[k] = p.off[lvl[k]] + a[k] * ny * nx + pix;     // upstream candidate index: a * ny * nx + y * nx + x
+            src[k] = p.head[lvl[k]] + ((long long)(b * ny + y[k]) * nx + x[k]) * p.head_ld + a[k] * p.no;
+            raw[k] = src[k][4];
+        }
+    }
+    float obj[kDecPerLane];
+#pragma unroll
+    for (int k = 0; k < kDecPerLane; ++k) {
+        obj[k] = 0.f;
+        if (src[k]) {
+            obj[k] = sigmoidf_ref(raw[k]);
+            if (p.pred) decode_row(p, src[k], lvl[k], a[k], x[k], y[k], obj[k], p.pred + ((long long)b * N + n[k]) * p.no);
+            pass[k] = p.cand && obj[k] > p.conf_thres;
+            if (pass[k]) local[k] = atomicAdd(&s_cnt, 1);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_cnt > 0) s_base = atomicAdd(p.cand_count + b, s_cnt);
     __syncthreads();
-    if (pass) {
-        const int pos = s_base + local;
-        if (pos < p.cap) {
-            p.cand[(long long)b * p.cap + pos] = n;
-            if (p.cand_rows) decode_row(p, src, lvl, a, x, y, obj, p.cand_rows + ((long long)b * p.cap + pos) * p.no);
+#pragma unroll
+    for (int k = 0; k < kDecPerLane; ++k) {
+        if (pass[k]) {
+            const int pos = s_base + local[k];
+            if (pos < p.cap) {
+                p.cand[(long long)b * p.cap + pos] = n[k];
+                if (p.cand_rows)
+                    decode_row(p, src[k], lvl[k], a[k], x[k], y[k], obj[k], p.cand_rows + ((long long)b * p.cap + pos) * p.no);
+            }
         }
     }
 }
@@ -418,7 +436,8 @@ extern "C" int aq_detect_decode(const float* const head_dev[3], int head_ld, int
     p.cand_count = cand_count_dev; p.cap = cand_cap;
     if (cand_dev) AQ_CHECK_HIP(hipMemsetAsync(cand_count_dev, 0, sizeof(int32_t) * B, (hipStream_t)stream));
     AQ_REQUIRE(B <= 65535, "decode: batch too large for the grid");
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((off + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((off + 256 * kDecPerLane - 1) / (256 * kDecPerLane)), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, p);
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;
 }
