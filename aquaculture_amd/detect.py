@@ -82,6 +82,10 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
     p.add_argument("--precision", choices=("fp32", "bf16"), default=None, help="default fp32 (detect.py without --half)")
     p.add_argument("--workers", type=int, default=8, help="jpeg decode threads")
     p.add_argument("--quiet", action="store_true", help="no per-image log line (the summary lines are still printed)")
+    p.add_argument("--geocode-bboxes", default=None, metavar="CSV",
+                   help="reference data/wanted_bboxes.csv: after the sweep, geocode every detection (the arithmetic of the "
+                        "reference's src/process_yolo/geocode_results.py geocode_all_detections, as one batch op) -> --geocode-out")
+    p.add_argument("--geocode-out", default=None, metavar="GEOJSON", help="default <save_dir>/detections.geojson")
     opt = p.parse_args(argv)
     opt.imgsz *= 2 if len(opt.imgsz) == 1 else 1
     return opt
@@ -90,7 +94,7 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
 def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_det=1000, device="",
         save_txt=False, save_conf=False, nosave=False, classes=None, agnostic_nms=False,
         project="runs/detect", name="exp", exist_ok=False, half=False, batch_size=64, precision=None,
-        workers=8, quiet=False, log=print, **unsupported):
+        workers=8, quiet=False, geocode_bboxes=None, geocode_out=None, log=print, **unsupported):
     from .engine import Engine, format_label_rows, letterbox_device   # raises if the HIP library or the GPU is missing: there is no fallback
 
     for k in UNSUPPORTED:
@@ -269,6 +273,15 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         log(f"{seen_all} images, {dets_all} detections, {seen_all / max(elapsed, 1e-9):.1f} images/s on {world} GPU(s) [{precision}]")
         if save_txt:
             log(f"Results saved to {save_dir}\n{labels_all} labels saved to {save_dir / 'labels'}")
+        if geocode_bboxes:
+            # the consumer's next step (reference src/process_yolo/geocode_results.py:106-197) on the label files just written
+            if not save_txt or not save_conf:
+                raise ValueError("--geocode-bboxes reads the label files: it needs --save-txt --save-conf")
+            from . import geocode
+            t_g = time.perf_counter()
+            out = geocode_out or str(save_dir / "detections.geojson")
+            table = geocode.geocode_label_dir(labels_dir, geocode_bboxes, out)
+            log(f"{table['image'].shape[0]} detections geocoded to {out} in {time.perf_counter() - t_g:.2f}s")
     eng.close()
     return save_dir
 

@@ -1,0 +1,110 @@
+"""CPU oracle for the hot path's CONSUMER arithmetic: label rows -> pixel boxes -> geocoded boxes.
+
+TEST INFRASTRUCTURE ONLY (see oracle/yolov5_oracle.py): imported by tests/ and tools/bench_geocode.py's baseline leg, never by
+the product path (aquaculture_amd/geocode.py).
+
+Scalar, loop-per-detection restatement in Python floats (IEEE double, the reference's arithmetic type) of
+  * reference src/process_yolo/geocode_results.py:71-101   convert_pix_to_m_bboxes
+  * reference src/process_yolo/geocode_results.py:158-192  the per-label / per-box loop of geocode_all_detections
+  * reference src/utils.py:17-20                           LARGE_TIF_SIZE, IM_WIDTH, IM_HEIGHT, CRS_DICT
+  * reference src/process_yolo/geocode_results.py:24-30    REVERSE_CLASS_MAPPING
+
+PINNED against the reference's own output (tests/golden/g7_geocode.json, cut from reference output/humanlabels.geojson and
+data/wanted_bboxes.csv by tests/golden/make_geocode_golden.py): pixel -> EPSG:3857 reproduces 4139 of its 4142 polygons
+bit-exactly (the other three differ by one ulp, 1.2e-10 m) and EPSG:3857 -> EPSG:4326 reproduces its `im_center` values to
+3.5e-9 degrees.  NOT pinned by reference output: the EPSG:3035 columns (pyproj is absent here; the reference tree holds no
+value computed with them) -- they follow the published IOGP formulas (Guidance Note 7-2: method 9820 LAEA, method 1024
+pseudo-Mercator) and are checked against that note's two worked examples only.
+"""
+import math
+import os
+
+LARGE_TIF_SIZE = 1024 * 6          # reference src/utils.py:17
+IM_WIDTH = 1024                    # reference src/utils.py:18
+IM_HEIGHT = 1024                   # reference src/utils.py:19
+REVERSE_CLASS_MAPPING = {0: "circle_farm", 1: "square_farm", 2: "triangle_farm", 3: "other_farm", 4: "rectangle_farm"}
+
+WGS84_A = 6378137.0                # EPSG:3857 projects on the sphere of the WGS 84 semi-major axis
+# ETRS89 / LAEA Europe (EPSG:3035): GRS80 ellipsoid, origin 52 N 10 E, false easting 4 321 000, false northing 3 210 000
+GRS80_A = 6378137.0
+GRS80_F = 1.0 / 298.257222101
+LAEA_LAT0 = math.radians(52.0)
+LAEA_LON0 = math.radians(10.0)
+LAEA_FE = 4321000.0
+LAEA_FN = 3210000.0
+
+
+def parse_label_name(label_path):
+    """reference geocode_results.py:90: `_, bbox_ind, x_offset, y_offset = basename.replace('.txt', '').split('_')`."""
+    _, bbox_ind, x_offset, y_offset = os.path.basename(label_path).replace(".txt", "").split("_")
+    return int(bbox_ind), int(x_offset), int(y_offset)
+
+
+def convert_pix_to_m_bboxes(x, y, label, wanted_bboxes, large_tif_size=LARGE_TIF_SIZE):
+    """reference geocode_results.py:71-101.  wanted_bboxes: {bbox_ind: (xmin_m, ymin_m, xmax_m, ymax_m)} (EPSG:3857 bounds)."""
+    bbox_ind, x_offset, y_offset = parse_label_name(label)
+    xmin_m, ymin_m, xmax_m, ymax_m = wanted_bboxes[bbox_ind]
+    x_loc = x + x_offset
+    y_loc = y + y_offset
+    x_m = x_loc * ((xmax_m - xmin_m) / large_tif_size) + xmin_m
+    y_m = ymax_m - y_loc * ((ymax_m - ymin_m) / large_tif_size)
+    return x_m, y_m
+
+
+def mercator_to_lonlat(x, y):
+    """EPSG:3857 -> EPSG:4326 (IOGP GN7-2 method 1024, reverse): what `df.to_crs(4326)` does (reference geocode_results.py:195)."""
+    lon = math.degrees(x / WGS84_A)
+    lat = math.degrees(math.pi / 2.0 - 2.0 * math.atan(math.exp(-y / WGS84_A)))
+    return lon, lat
+
+
+def _laea_q(sin_phi, e):
+    return (1.0 - e * e) * (sin_phi / (1.0 - e * e * sin_phi * sin_phi) - (1.0 / (2.0 * e)) * math.log((1.0 - e * sin_phi) / (1.0 + e * sin_phi)))
+
+
+def lonlat_to_laea_europe(lon_deg, lat_deg):
+    """EPSG:4258/4326 -> EPSG:3035 easting, northing (IOGP GN7-2 method 9820, oblique aspect, forward)."""
+    e2 = GRS80_F * (2.0 - GRS80_F)
+    e = math.sqrt(e2)
+    phi, lam = math.radians(lat_deg), math.radians(lon_deg)
+    qp = _laea_q(1.0, e)
+    q0 = _laea_q(math.sin(LAEA_LAT0), e)
+    q = _laea_q(math.sin(phi), e)
+    beta0 = math.asin(q0 / qp)
+    beta = math.asin(q / qp)
+    rq = GRS80_A * math.sqrt(qp / 2.0)
+    d = GRS80_A * (math.cos(LAEA_LAT0) / math.sqrt(1.0 - e2 * math.sin(LAEA_LAT0) ** 2)) / (rq * math.cos(beta0))
+    b = rq * math.sqrt(2.0 / (1.0 + math.sin(beta0) * math.sin(beta) + math.cos(beta0) * math.cos(beta) * math.cos(lam - LAEA_LON0)))
+    east = LAEA_FE + b * d * (math.cos(beta) * math.sin(lam - LAEA_LON0))
+    north = LAEA_FN + (b / d) * (math.cos(beta0) * math.sin(beta) - math.sin(beta0) * math.cos(beta) * math.cos(lam - LAEA_LON0))
+    return east, north
+
+
+def mercator_to_laea_europe(x, y):
+    """EPSG:3857 -> EPSG:3035 (easting, northing): the role of `Transformer.from_crs(3857, 3035)` (reference geocode_results.py:31).
+    WGS 84 and ETRS89 are treated as coincident, as PROJ's default pipeline for this pair does."""
+    lon, lat = mercator_to_lonlat(x, y)
+    return lonlat_to_laea_europe(lon, lat)
+
+
+def geocode_label_rows(label_path, rows, wanted_bboxes):
+    """One label file's rows [[cls, xc, yc, w, h, conf], ...] (as np.loadtxt returns them: doubles parsed from the text) ->
+    list of dicts with the columns reference geocode_results.py:139-192 appends, one per detection, in file order.
+    `geometry` = EPSG:3857 bounds (xmin_m, ymin_m, xmax_m, ymax_m) of shapely's box(); the 3035 values are (easting, northing)."""
+    im_name = os.path.basename(label_path).replace(".txt", ".jpeg")
+    year = int(im_name.split("_")[0][-4:])                   # reference geocode_results.py:143
+    out = []
+    for bbox in rows:
+        xmin = int(IM_WIDTH * (bbox[1] - bbox[3] / 2))       # reference geocode_results.py:160-163: int() truncates toward zero
+        ymin = int(IM_HEIGHT * (bbox[2] - bbox[4] / 2))
+        xmax = int(IM_WIDTH * (bbox[1] + bbox[3] / 2))
+        ymax = int(IM_HEIGHT * (bbox[2] + bbox[4] / 2))
+        xmin_m, ymax_m = convert_pix_to_m_bboxes(xmin, ymin, label_path, wanted_bboxes)
+        xmax_m, ymin_m = convert_pix_to_m_bboxes(xmax, ymax, label_path, wanted_bboxes)
+        e_min, n_max = mercator_to_laea_europe(xmin_m, ymax_m)
+        e_max, n_min = mercator_to_laea_europe(xmax_m, ymin_m)
+        out.append({"image": im_name, "xmin": xmin, "xmax": xmax, "ymin": ymin, "ymax": ymax,
+                    "e_min_3035": e_min, "e_max_3035": e_max, "n_min_3035": n_min, "n_max_3035": n_max,
+                    "type": REVERSE_CLASS_MAPPING[int(bbox[0])], "year": year, "det_conf": float(bbox[5]),
+                    "geometry": (xmin_m, ymin_m, xmax_m, ymax_m)})
+    return out

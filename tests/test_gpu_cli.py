@@ -110,3 +110,35 @@ def test_cli_on_real_size_1024_tiles(tmp_path, lib):
         assert same >= 0.99 * len(want)
         arr = np.loadtxt(labels / (stem + ".txt"))
         assert int(1024 * (arr[:, 1] + arr[:, 3] / 2).max()) <= 1024
+
+
+def test_cli_geocodes_its_own_labels(workdir, lib, tmp_path):
+    """--geocode-bboxes: the consumer's arithmetic (reference src/process_yolo/geocode_results.py:106-197) run as a batch op on the
+    label files the sweep just wrote; checked against the scalar oracle on those same files."""
+    import json
+    from aquaculture_amd import tiles
+    from oracle import geocode_oracle as GO
+    inds = sorted({int(tiles.tile_name(i)[:-5].split("_")[1]) for i in TILES})
+    csv_path = tmp_path / "wanted_bboxes.csv"
+    with open(csv_path, "w") as f:                          # 1200 m squares like the reference's table
+        f.write(",geometry\n")
+        for k in inds:
+            x0, y0 = 300000.0 + 1200.0 * k, 5200000.0 + 1200.0 * (k % 7)
+            f.write(f'{k},"POLYGON (({x0 + 1200} {y0}, {x0 + 1200} {y0 + 1200}, {x0} {y0 + 1200}, {x0} {y0}, {x0 + 1200} {y0}))"\n')
+    out, labels = _run(workdir, "geo", extra=("--geocode-bboxes", str(csv_path)))
+    gj = labels.parent / "detections.geojson"
+    assert "detections geocoded to" in out and gj.exists()
+    d = json.load(open(gj))
+    bboxes = {k: (300000.0 + 1200.0 * k, 5200000.0 + 1200.0 * (k % 7), 300000.0 + 1200.0 * k + 1200, 5200000.0 + 1200.0 * (k % 7) + 1200) for k in inds}
+    want = []
+    for fn in sorted(os.listdir(labels)):
+        rows = np.loadtxt(labels / fn, ndmin=2)
+        want += GO.geocode_label_rows(fn, rows, bboxes)
+    assert len(d["features"]) == len(want) > 0
+    for ft, w in zip(d["features"], want):
+        p = ft["properties"]
+        assert (p["image"], p["xmin"], p["xmax"], p["ymin"], p["ymax"], p["type"], p["year"]) == \
+               (w["image"], w["xmin"], w["xmax"], w["ymin"], w["ymax"], w["type"], w["year"])
+        assert p["det_conf"] == w["det_conf"] and abs(p["e_min_3035"] - w["e_min_3035"]) < 1e-6
+        lon, lat = GO.mercator_to_lonlat(w["geometry"][2], w["geometry"][1])      # ring starts at (maxx, miny)
+        assert abs(ft["geometry"]["coordinates"][0][0][0] - lon) < 1e-12 and abs(ft["geometry"]["coordinates"][0][0][1] - lat) < 1e-12
