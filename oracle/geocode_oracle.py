@@ -1,7 +1,7 @@
 """CPU oracle for the hot path's CONSUMER arithmetic: label rows -> pixel boxes -> geocoded boxes.
 
-TEST INFRASTRUCTURE ONLY (see oracle/yolov5_oracle.py): imported by tests/ and tools/bench_geocode.py's baseline leg, never by
-the product path (aquaculture_amd/geocode.py).
+TEST INFRASTRUCTURE ONLY (see oracle/yolov5_oracle.py): imported by tests/ only, never by the product path
+(aquaculture_amd/geocode.py) or by tools/.
 
 Scalar, loop-per-detection restatement in Python floats (IEEE double, the reference's arithmetic type) of
   * reference src/process_yolo/geocode_results.py:71-101   convert_pix_to_m_bboxes

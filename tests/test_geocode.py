@@ -139,3 +139,23 @@ def test_wanted_bboxes_csv_loader(tmp_path, golden):
         for k, (x0, y0, x1, y1) in golden["bboxes"].items():
             f.write(f'{k},"POLYGON (({x1!r} {y0!r}, {x1!r} {y1!r}, {x0!r} {y1!r}, {x0!r} {y0!r}, {x1!r} {y0!r}))"\n')
     assert geocode.load_wanted_bboxes(str(p)) == golden["bboxes"]
+
+
+def test_batch_throughput_vs_scalar_loop(golden, capsys):
+    """Measurement beside parity: the batch op against the per-detection loop (the oracle's form = the reference's), same rows."""
+    import time
+    stems, counts, rows32 = _random_labels(golden, 400, 5)
+    rows = rows32.astype(np.float64)
+    t0 = time.perf_counter()
+    geocode.geocode_detections(stems, counts, rows, golden["bboxes"])
+    dt_batch = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    k = 0
+    for s, c in zip(stems, counts):
+        GO.geocode_label_rows(s + ".txt", rows[k:k + c], golden["bboxes"])
+        k += c
+    dt_loop = time.perf_counter() - t0
+    with capsys.disabled():
+        print(f"\n[geocode] {rows.shape[0]} detections: batch {rows.shape[0] / dt_batch:,.0f}/s, scalar loop {rows.shape[0] / dt_loop:,.0f}/s "
+              f"({dt_loop / dt_batch:.1f}x)")
+    assert dt_batch * 2 < dt_loop

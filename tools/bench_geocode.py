@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Throughput of the geocoding batch op (aquaculture_amd/geocode.py) beside the scalar oracle (oracle/geocode_oracle.py, the
-per-detection Python loop of reference src/process_yolo/geocode_results.py:158-192).  CPU only; prints one JSON line.
+"""Throughput of the geocoding batch op (aquaculture_amd/geocode.py).  CPU only; prints one JSON line.  The comparison with the
+per-detection loop of reference src/process_yolo/geocode_results.py:158-192 (the oracle's form) lives in
+tests/test_geocode.py::test_batch_throughput_vs_scalar_loop -- nothing outside tests/ may touch oracle/.
 Sample: N synthetic label rows spread over the tile names of tests/golden/g7_geocode.json (the reference's own scene table)."""
 import argparse
 import json
@@ -13,13 +14,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from aquaculture_amd import geocode  # noqa: E402
-from oracle import geocode_oracle as GO  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1_000_000)
-    ap.add_argument("--oracle-rows", type=int, default=100_000)
     a = ap.parse_args()
     with open(os.path.join(ROOT, "tests", "golden", "g7_geocode.json")) as f:
         g = json.load(f)
@@ -36,15 +35,7 @@ def main():
     t0 = time.perf_counter()
     t = geocode.geocode_detections(stems, counts, rows, bboxes)
     dt = time.perf_counter() - t0
-    no = min(a.oracle_rows // per, n_img)
-    t1 = time.perf_counter()
-    k = 0
-    for i in range(no):
-        GO.geocode_label_rows(stems[i] + ".txt", rows[k:k + per], bboxes)
-        k += per
-    do = time.perf_counter() - t1
     print(json.dumps({"op": "geocode_detections", "rows": int(rows.shape[0]), "seconds": round(dt, 4), "rows_per_s": round(rows.shape[0] / dt),
-                      "oracle_rows": k, "oracle_rows_per_s": round(k / do), "speedup": round(rows.shape[0] / dt / (k / do), 1),
                       "checksum_xmin": int(t["xmin"].sum())}))
 
 
