@@ -159,3 +159,21 @@ def test_batch_throughput_vs_scalar_loop(golden, capsys):
         print(f"\n[geocode] {rows.shape[0]} detections: batch {rows.shape[0] / dt_batch:,.0f}/s, scalar loop {rows.shape[0] / dt_loop:,.0f}/s "
               f"({dt_loop / dt_batch:.1f}x)")
     assert dt_batch * 2 < dt_loop
+
+
+def test_tile_name_conventions_match_reference_names():
+    """Real tile names from the reference's data files (tests/golden/g8_tile_names.json, cut from reference output/cf_images.csv and
+    output/humanlabels.geojson): our parser reads them, our generator writes the same form, offsets are multiples of 1024 below 6144
+    (reference src/utils.py:372-389; src/load_data/tile_tifs.py:13-47)."""
+    from aquaculture_amd import tiles
+    with open(os.path.join(HERE, "golden", "g8_tile_names.json")) as f:
+        names = json.load(f)["names"]
+    assert len(names) > 100
+    ind, xo, yo, yr = geocode.parse_stems([n[:-5] for n in names])
+    for n, i, x, y, year in zip(names, ind, xo, yo, yr):
+        spec = tiles.parse_tile_name(n)
+        assert (int(spec["bbox_ind"]), int(spec["x_offset"]), int(spec["y_offset"]), int(spec["year"])) == (i, x, y, year)
+        assert 2000 <= year <= 2021 and x % 1024 == 0 and y % 1024 == 0 and 0 <= x < 6144 and 0 <= y < 6144
+        # our synthetic-name generator produces the reference's form for the same (year, scene, offsets)
+        k = int(i) * 36 + (y // 1024) * 6 + (x // 1024)
+        assert tiles.tile_name(k, year=year) == n
