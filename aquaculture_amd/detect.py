@@ -80,7 +80,8 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
     p.add_argument("--vid-stride", type=int, default=1)
     p.add_argument("--batch-size", type=int, default=64, help="tiles per engine call")
     p.add_argument("--precision", choices=("fp32", "bf16"), default=None, help="default fp32 (detect.py without --half)")
-    p.add_argument("--workers", type=int, default=8, help="jpeg decode threads")
+    p.add_argument("--workers", type=int, default=8, help="jpeg decoders (worker processes for uniform tile directories, threads otherwise)")
+    p.add_argument("--decode-threads", action="store_true", help="decode in threads of this process instead of worker processes")
     p.add_argument("--quiet", action="store_true", help="no per-image log line (the summary lines are still printed)")
     p.add_argument("--geocode-bboxes", default=None, metavar="CSV",
                    help="reference data/wanted_bboxes.csv: after the sweep, geocode every detection (the arithmetic of the "
@@ -94,7 +95,7 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
 def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_det=1000, device="",
         save_txt=False, save_conf=False, nosave=False, classes=None, agnostic_nms=False,
         project="runs/detect", name="exp", exist_ok=False, half=False, batch_size=64, precision=None,
-        workers=8, quiet=False, geocode_bboxes=None, geocode_out=None, log=print, **unsupported):
+        workers=8, decode_threads=False, quiet=False, geocode_bboxes=None, geocode_out=None, log=print, **unsupported):
     from .engine import Engine, format_label_rows, letterbox_device   # raises if the HIP library or the GPU is missing: there is no fallback
 
     for k in UNSUPPORTED:
@@ -196,7 +197,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     def batch_source():
         """Uniform tile directories (the reference's case): zero-copy pinned batches; mixed sizes: the generic path."""
         try:
-            for item in dataset.pinned_batches(batch_size, depth + 1):
+            for item in dataset.pinned_batches(batch_size, depth + 1, processes=0 if decode_threads else None):
                 yield item
         except ValueError as e:
             log(f"note: {e}")

@@ -142,3 +142,13 @@ def test_cli_geocodes_its_own_labels(workdir, lib, tmp_path):
         assert p["det_conf"] == w["det_conf"] and abs(p["e_min_3035"] - w["e_min_3035"]) < 1e-6
         lon, lat = GO.mercator_to_lonlat(w["geometry"][2], w["geometry"][1])      # ring starts at (maxx, miny)
         assert abs(ft["geometry"]["coordinates"][0][0][0] - lon) < 1e-12 and abs(ft["geometry"]["coordinates"][0][0][1] - lat) < 1e-12
+
+
+def test_decode_processes_and_threads_give_identical_labels(workdir, lib):
+    """The jpeg decode worker processes (shared-memory pinned ring) and the in-process decode threads feed the engine the same pixels."""
+    _, la = _run(workdir, "dec_procs", extra=("--half", "--workers", "3"))
+    _, lb = _run(workdir, "dec_threads", extra=("--half", "--workers", "3", "--decode-threads"))
+    fa, fb = sorted(os.listdir(la)), sorted(os.listdir(lb))
+    assert fa == fb and fa
+    for f in fa:
+        assert open(la / f).read() == open(lb / f).read()

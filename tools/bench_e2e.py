@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--batch-size", type=int, default=64)
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--decode-threads", action="store_true", help="in-process decode threads instead of worker processes (A/B)")
     a = ap.parse_args()
     from aquaculture_amd import checkpoint, tiles
     jp = os.path.join(a.dir, f"jpegs_{a.size}")
@@ -39,7 +40,7 @@ def main():
         checkpoint.write_synthetic_checkpoint(w, "yolov5m", 5)
     cmd = [sys.executable, os.path.join(ROOT, "yolov5", "detect.py"), "--weights", w, "--source", jp, "--nosave", "--save-txt", "--save-conf",
            "--project", os.path.join(a.dir, "runs"), "--name", "e2e", "--batch-size", str(a.batch_size), "--workers", str(a.workers),
-           "--precision", a.precision, "--quiet"]
+           "--precision", a.precision, "--quiet"] + (["--decode-threads"] if a.decode_threads else [])
     t0 = time.perf_counter()
     r = subprocess.run(cmd, capture_output=True, text=True)
     dt = time.perf_counter() - t0
