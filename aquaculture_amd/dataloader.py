@@ -216,14 +216,18 @@ class LoadImages:
         shm = shared_memory.SharedMemory(create=True, size=nbytes)
         ring = np.ndarray((n_buffers, batch_size, H0, W0, 3), dtype=np.uint8, buffer=shm.buf)
         ring_t = torch.from_numpy(ring)
-        # page-lock the ring in place so that H2D copies from it are asynchronous DMA (cudaHostRegister = hipHostRegister on ROCm);
-        # if the runtime refuses, batches go through one pinned staging copy instead
+        # Page-lock the ring in place (cudaHostRegister = hipHostRegister on ROCm) so that H2D copies from it are asynchronous DMA.
+        # Measured on the MI355X box: DMA reads from a registered shm mapping run at only ~4 GB/s (hipHostMalloc memory: ~55 GB/s),
+        # yet that still beats the alternative -- one ~200 MB memcpy per batch from the ring into a hipHostMalloc staging buffer in
+        # the main loop (1,450 vs 755 images/s for 1024-px jpegs).  The staging copy remains as the fallback if registration fails
+        # (AQ_DECODE_REGISTER=0 forces it).
         registered = False
-        try:
-            rc = torch.cuda.cudart().cudaHostRegister(ring_t.data_ptr(), nbytes, 0)
-            registered = int(rc) == 0
-        except Exception:
-            registered = False
+        if os.environ.get("AQ_DECODE_REGISTER", "1") != "0":
+            try:
+                rc = torch.cuda.cudart().cudaHostRegister(ring_t.data_ptr(), nbytes, 0)
+                registered = int(rc) == 0
+            except Exception:
+                registered = False
         stage = None if registered else [torch.empty((batch_size, H0, W0, 3), dtype=torch.uint8).pin_memory() for _ in range(n_buffers)]
         nproc = max(1, min(nproc, batch_size))
         env = dict(os.environ)
