@@ -174,8 +174,10 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const char* __restrict_
 // OpenCV's 8-bit bilinear kernel in fixed point (11-bit coefficients): horizontal pass in int (scale 2^11), vertical pass
 // ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.  The coefficient tables (source index pair + weights per
 // destination column / row) are built on the host exactly as resize.cpp does (float32 fractions, cvRound) and passed in.
-__global__ __launch_bounds__(256) void letterbox_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                          const int4* __restrict__ xtab, const int4* __restrict__ ytab,
+// Tile b starts at src + tile_off[b] (tile_off == nullptr: b * H0 * row_b, tiles stored one after the other) and its rows are row_b
+// bytes apart: with offsets into one big scene raster the crop of reference src/load_data/tile_tifs.py:33-47 costs no pass of its own.
+__global__ __launch_bounds__(256) void letterbox_u8_kernel(const uint8_t* __restrict__ src, long long row_b, const long long* __restrict__ tile_off,
+                                                          uint8_t* __restrict__ dst, const int4* __restrict__ xtab, const int4* __restrict__ ytab,
                                                           int B, int H0, int W0, int H, int W, int new_w, int new_h, int top, int left) {
     const unsigned n = (unsigned)B * H * W;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -186,8 +188,9 @@ __global__ __launch_bounds__(256) void letterbox_u8_kernel(const uint8_t* __rest
         const int yy = y - top, xx = x - left;
         if (yy < 0 || yy >= new_h || xx < 0 || xx >= new_w) { o[0] = o[1] = o[2] = 114; continue; }
         const int4 xt = xtab[xx], yt = ytab[yy];        // (i0, i1, w0, w1)
-        const uint8_t* r0 = src + ((size_t)b * H0 + yt.x) * W0 * 3;
-        const uint8_t* r1 = src + ((size_t)b * H0 + yt.y) * W0 * 3;
+        const uint8_t* tile = src + (tile_off ? tile_off[b] : (long long)b * H0 * row_b);
+        const uint8_t* r0 = tile + yt.x * row_b;
+        const uint8_t* r1 = tile + yt.y * row_b;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int h0 = r0[xt.x * 3 + c] * xt.z + r0[xt.y * 3 + c] * xt.w;
@@ -275,7 +278,25 @@ extern "C" int aq_letterbox_u8(const uint8_t* src_dev, int B, int H0, int W0, ui
                top + new_h <= H && left + new_w <= W, "letterbox: bad geometry");
     const long long n = (long long)B * H * W;
     AQ_REQUIRE(n < (1LL << 31), "letterbox: batch too large");
-    hipLaunchKernelGGL(letterbox_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, src_dev, dst_dev,
+    hipLaunchKernelGGL(letterbox_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, src_dev, (long long)W0 * 3, nullptr, dst_dev,
+                       (const int4*)xtab_dev, (const int4*)ytab_dev, B, H0, W0, H, W, new_w, new_h, top, left);
+    AQ_CHECK_HIP(hipGetLastError());
+    return AQ_OK;
+}
+
+extern "C" int aq_letterbox_tiles_u8(const uint8_t* scene_dev, long long scene_bytes, long long row_bytes, const long long* tile_off_dev,
+                                     const long long* tile_off_host, int B, int H0, int W0, uint8_t* dst_dev, int H, int W, int new_w, int new_h,
+                                     int top, int left, const int32_t* xtab_dev, const int32_t* ytab_dev, void* stream) {
+    AQ_REQUIRE(scene_dev && tile_off_dev && tile_off_host && dst_dev && xtab_dev && ytab_dev, "letterbox_tiles: null pointer");
+    AQ_REQUIRE(B > 0 && H0 > 0 && W0 > 0 && H > 0 && W > 0 && new_w > 0 && new_h > 0 && top >= 0 && left >= 0 &&
+               top + new_h <= H && left + new_w <= W && row_bytes >= (long long)W0 * 3, "letterbox_tiles: bad geometry");
+    for (int b = 0; b < B; ++b)      // every tile must lie inside the raster: the kernel trusts the offsets
+        AQ_REQUIRE(tile_off_host[b] >= 0 && tile_off_host[b] + (long long)(H0 - 1) * row_bytes + (long long)W0 * 3 <= scene_bytes &&
+                       tile_off_host[b] % row_bytes + (long long)W0 * 3 <= row_bytes,     /* no wrap into the next raster row */
+                   "letterbox_tiles: tile %d (offset %lld) leaves the raster of %lld bytes", b, tile_off_host[b], scene_bytes);
+    const long long n = (long long)B * H * W;
+    AQ_REQUIRE(n < (1LL << 31), "letterbox_tiles: batch too large");
+    hipLaunchKernelGGL(letterbox_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, scene_dev, row_bytes, tile_off_dev, dst_dev,
                        (const int4*)xtab_dev, (const int4*)ytab_dev, B, H0, W0, H, W, new_w, new_h, top, left);
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;

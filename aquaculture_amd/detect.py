@@ -87,6 +87,9 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
                    help="reference data/wanted_bboxes.csv: after the sweep, geocode every detection (the arithmetic of the "
                         "reference's src/process_yolo/geocode_results.py geocode_all_detections, as one batch op) -> --geocode-out")
     p.add_argument("--geocode-out", default=None, metavar="GEOJSON", help="default <save_dir>/detections.geojson")
+    p.add_argument("--tile-scenes", nargs="?", type=int, const=1024, default=0, metavar="TILESIZE",
+                   help="opt-in scene mode: --source holds whole scene rasters (*.tif); they are cut into TILESIZE (default 1024) tiles "
+                        "on the GPU, in the order and with the names of reference src/load_data/tile_tifs.py, skipping its jpeg step")
     opt = p.parse_args(argv)
     opt.imgsz *= 2 if len(opt.imgsz) == 1 else 1
     return opt
@@ -95,8 +98,8 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
 def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_det=1000, device="",
         save_txt=False, save_conf=False, nosave=False, classes=None, agnostic_nms=False,
         project="runs/detect", name="exp", exist_ok=False, half=False, batch_size=64, precision=None,
-        workers=8, decode_threads=False, quiet=False, geocode_bboxes=None, geocode_out=None, log=print, **unsupported):
-    from .engine import Engine, format_label_rows, letterbox_device   # raises if the HIP library or the GPU is missing: there is no fallback
+        workers=8, decode_threads=False, quiet=False, geocode_bboxes=None, geocode_out=None, tile_scenes=0, log=print, **unsupported):
+    from .engine import Engine, format_label_rows, letterbox_device, letterbox_scene_tiles   # raises if the HIP library or the GPU is missing: there is no fallback
 
     for k in UNSUPPORTED:
         if unsupported.get(k):
@@ -126,7 +129,11 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     eng = Engine(ck, precision, dev)
     imgsz = check_img_size(list(imgsz), s=int(max(ck.stride)))
     # decoded images go to the GPU as they are; the letterbox (resize INTER_LINEAR + pad 114) runs on the device
-    dataset = LoadImages(source, img_size=imgsz, stride=int(max(ck.stride)), auto=True, shard=(rank, world), workers=workers, raw=True)
+    if tile_scenes:
+        from .scenes import SceneTiles
+        dataset = SceneTiles(source, tilesize=int(tile_scenes), shard=(rank, world), workers=workers, batch_size=batch_size, pinned=True)
+    else:
+        dataset = LoadImages(source, img_size=imgsz, stride=int(max(ck.stride)), auto=True, shard=(rank, world), workers=workers, raw=True)
 
     # Pipeline: decode threads -> [main thread: H2D, letterbox, engine, async D2H] -> [writer thread: rescale, format, files].
     # Up to `depth` batches are in flight, each with its own workspace slot, pinned result buffers and stream.
@@ -146,7 +153,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                 item = q.get()
                 if item is None:
                     return
-                ev, counts_h, dets_h, paths, shapes0, hw, first, t_inf, slot_id = item
+                ev, counts_h, dets_h, paths, shapes0, hw, gidx, t_inf, slot_id = item
                 ev.synchronize()
                 t0 = time.perf_counter()
                 nlab = ndet = 0
@@ -162,11 +169,11 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                             f.write(format_label_rows(rows, save_conf))
                         nlab += 1
                     if not quiet:
-                        s = f"image {dataset.indices[first + b] + 1}/{dataset.total} {p}: {H}x{W} "
+                        s = f"image {gidx[b] + 1}/{dataset.total} {p}: {H}x{W} "
                         s += postprocess.class_summary(det[:, 5], ck.names) if det.shape[0] else "(no detections), "
                         log(f"{s}{t_inf * 1e3 / len(paths):.1f}ms")
                     if world > 1 and det.shape[0]:
-                        idx = torch.full((det.shape[0],), dataset.indices[first + b], dtype=torch.float32)
+                        idx = torch.full((det.shape[0],), gidx[b], dtype=torch.float32)
                         gathered.append(aqdist.pack_rows(idx, torch.from_numpy(det.copy())))
                 slot_free[slot_id].release()
                 with lock:
@@ -203,17 +210,31 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
             log(f"note: {e}")
             raise
 
-    try:
-        from PIL import Image
-        with Image.open(dataset.files[0]) as _im0:
-            _size0 = _im0.size
-        uniform = all(Image.open(f).size == _size0 for f in dataset.files[:: max(1, len(dataset.files) // 16)])
-    except Exception:
-        uniform = False
-    source_iter = batch_source() if uniform and len(dataset) else ((p_, torch.from_numpy(b_).pin_memory(), s_, None)
-                                                                  for p_, b_, s_ in dataset.batches(batch_size))
+    def scene_source():
+        """Scene mode: (tile names, ("scene", path, raster, origins, (h, w)), shapes, None, global tile indices) per batch."""
+        for path, arr, stems, origins, hw, gids in dataset.batches():
+            names = [os.path.join(os.path.dirname(path), st_ + ".tif") for st_ in stems]     # label file = <tile stem>.txt
+            yield names, ("scene", path, arr, origins, hw), [hw] * len(stems), None, gids
+
+    def image_source():
+        try:
+            from PIL import Image
+            with Image.open(dataset.files[0]) as _im0:
+                _size0 = _im0.size
+            uniform = all(Image.open(f).size == _size0 for f in dataset.files[:: max(1, len(dataset.files) // 16)])
+        except Exception:
+            uniform = False
+        it = batch_source() if uniform and len(dataset) else ((p_, torch.from_numpy(b_).pin_memory(), s_, None)
+                                                              for p_, b_, s_ in dataset.batches(batch_size))
+        n_ = 0
+        for p_, h_, s_, bi_ in it:
+            yield p_, h_, s_, bi_, dataset.indices[n_: n_ + len(p_)]
+            n_ += len(p_)
+
+    source_iter = scene_source() if tile_scenes else image_source()
+    scene_dev, scene_path, scene_ev = None, None, None
     copy_done = []
-    for paths, host, shapes0, buf_i in source_iter:
+    for paths, host, shapes0, buf_i, gidx in source_iter:
         if err:
             break
         t0 = time.perf_counter()
@@ -221,12 +242,24 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         slot_free[slot].acquire()
         st = streams[slot]
         with torch.cuda.stream(st):
-            tiles = host.to(dev, non_blocking=True)
-            if buf_i is not None:                      # hand the pinned buffer back once its H2D copy has completed
-                h2d = torch.cuda.Event()
-                h2d.record(st)
-                copy_done.append((h2d, buf_i))
-            tiles = letterbox_device(tiles, tuple(imgsz), int(max(ck.stride)), True)
+            if isinstance(host, tuple):                # scene mode: one upload per scene, tiles cut by the letterbox kernel
+                _, spath, sarr, origins, thw = host
+                if spath != scene_path:                # page-locked source: async copy, its buffer goes back once the copy is done
+                    scene_dev, scene_path = torch.from_numpy(sarr).to(dev, non_blocking=True), spath
+                    scene_ev = torch.cuda.Event()
+                    scene_ev.record(st)
+                    dataset.uploaded(dataset.slot_of[spath], scene_ev)
+                else:
+                    st.wait_event(scene_ev)            # another stream uploaded this scene
+                scene_dev.record_stream(st)
+                tiles = letterbox_scene_tiles(scene_dev, origins, thw, tuple(imgsz), int(max(ck.stride)), True)
+            else:
+                tiles = host.to(dev, non_blocking=True)
+                if buf_i is not None:                  # hand the pinned buffer back once its H2D copy has completed
+                    h2d = torch.cuda.Event()
+                    h2d.record(st)
+                    copy_done.append((h2d, buf_i))
+                tiles = letterbox_device(tiles, tuple(imgsz), int(max(ck.stride)), True)
             t1 = time.perf_counter()
             dets, counts = eng.infer(tiles, conf_thres, iou_thres, max_det, slot=slot)
             B = tiles.shape[0]
@@ -241,7 +274,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         H, W = int(tiles.shape[1]), int(tiles.shape[2])
         shape_str = f"(1, 3, {H}, {W})"
         t2 = time.perf_counter()
-        q.put((ev, counts_h, dets_h, paths, shapes0, (H, W), issued, t2 - t1, slot))
+        q.put((ev, counts_h, dets_h, paths, shapes0, (H, W), list(gidx), t2 - t1, slot))
         issued += len(paths)
         while copy_done and (copy_done[0][0].query() or len(copy_done) > depth):
             ev_, bi_ = copy_done.pop(0)

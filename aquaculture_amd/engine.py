@@ -65,7 +65,7 @@ EXPORTS = (
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
     "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
     "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct", "aq_preprocess_s2d", "aq_sppf_pool",
-    "aq_upsample2x", "aq_letterbox_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
+    "aq_upsample2x", "aq_letterbox_u8", "aq_letterbox_tiles_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
 
 _lib = None
@@ -117,6 +117,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_sppf_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.aq_upsample2x.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.aq_letterbox_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.aq_letterbox_tiles_u8.argtypes = [vp, C.c_longlong, C.c_longlong, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.aq_format_label_rows.argtypes = [C.POINTER(f32), i32, i32, C.c_char_p, sz]
     lib.aq_format_label_rows.restype = C.c_long
     lib.aq_detect_decode.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32),
@@ -423,6 +424,37 @@ def letterbox_device(tiles0: torch.Tensor, new_shape=(640, 640), stride: int = 3
     out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=tiles0.device)
     _check(lib.aq_letterbox_u8(tiles0.data_ptr(), B, H0, W0, out.data_ptr(), H, W, nw, nh, top, left,
                                xt.data_ptr(), yt.data_ptr(), _stream_ptr()))
+    return out
+
+
+def _letterbox_tables(H0: int, W0: int, new_shape, stride: int, auto: bool, device):
+    from . import dataloader
+    key = (H0, W0, tuple(new_shape), stride, auto, device.index)
+    if key not in _lb_tables:
+        (nw, nh), (top, bottom, left, right) = dataloader.letterbox_geometry((H0, W0), new_shape, auto, True, stride)
+        xt = np.stack(dataloader._axis_coeffs(W0, nw), 1).astype(np.int32)
+        yt = np.stack(dataloader._axis_coeffs(H0, nh), 1).astype(np.int32)
+        _lb_tables[key] = (torch.from_numpy(xt).to(device), torch.from_numpy(yt).to(device),
+                           (nw, nh, top, left, nh + top + bottom, nw + left + right))
+    return _lb_tables[key]
+
+
+def letterbox_scene_tiles(scene: torch.Tensor, origins, tile_hw, new_shape=(640, 640), stride: int = 32, auto: bool = True) -> torch.Tensor:
+    """uint8 CUDA scene raster [Hs,Ws,3] + tile origins [(x0, y0), ...] of equal size tile_hw=(H0,W0) -> letterboxed uint8 [B,H,W,3]
+    (aq_letterbox_tiles_u8): crop (reference src/load_data/tile_tifs.py:33-47) and letterbox in one pass, no tile copies."""
+    _require_gpu()
+    lib = load_library()
+    assert scene.is_cuda and scene.dtype == torch.uint8 and scene.dim() == 3 and scene.shape[2] == 3 and scene.is_contiguous()
+    Hs, Ws, _ = scene.shape
+    H0, W0 = tile_hw
+    row_b = Ws * 3
+    offs = np.asarray([y0 * row_b + x0 * 3 for x0, y0 in origins], dtype=np.int64)
+    B = int(offs.shape[0])
+    xt, yt, (nw, nh, top, left, H, W) = _letterbox_tables(H0, W0, new_shape, stride, auto, scene.device)
+    offs_dev = torch.from_numpy(offs).to(scene.device)
+    out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=scene.device)
+    _check(lib.aq_letterbox_tiles_u8(scene.data_ptr(), Hs * row_b, row_b, offs_dev.data_ptr(), offs.ctypes.data, B, H0, W0, out.data_ptr(),
+                                     H, W, nw, nh, top, left, xt.data_ptr(), yt.data_ptr(), _stream_ptr()))
     return out
 
 

@@ -194,6 +194,13 @@ int aq_preprocess_s2d(const uint8_t* tiles_dev, void* out_dev, int B, int H, int
  * on the host (aquaculture_amd/dataloader.py resize tables).  UNPINNED: no OpenCV is available to check against. */
 int aq_letterbox_u8(const uint8_t* src_dev, int B, int H0, int W0, uint8_t* dst_dev, int H, int W, int new_w, int new_h,
                     int top, int left, const int32_t* xtab_dev, const int32_t* ytab_dev, void* stream);
+/* The same letterbox reading its B tiles (H0 x W0) out of ONE uint8 RGB raster in device memory: tile b starts tile_off[b] bytes into
+ * the raster, rows are row_bytes apart.  Replaces the crop + re-encode of reference src/load_data/tile_tifs.py:13-47 (gdal.Translate
+ * srcWin per tile) + :50-74 (JPEG) for the opt-in scene mode: the scene is uploaded once and never written back as tiles.  The offsets
+ * are passed twice: tile_off_dev for the kernel, tile_off_host so that the call can refuse tiles that leave the raster. */
+int aq_letterbox_tiles_u8(const uint8_t* scene_dev, long long scene_bytes, long long row_bytes, const long long* tile_off_dev,
+                          const long long* tile_off_host, int B, int H0, int W0, uint8_t* dst_dev, int H, int W, int new_w, int new_h,
+                          int top, int left, const int32_t* xtab_dev, const int32_t* ytab_dev, void* stream);
 /* SPPF pools: y1 = mp5(x), y2 = mp5(y1), y3 = mp5(y2) written to channel slices c, 2c, 3c of the same buffer. */
 int aq_sppf_pool(void* buf_dev, int ld, int ch_off, int c, int B, int H, int W, int precision, void* stream);
 /* nearest 2x upsample of a channel slice into a channel slice. */

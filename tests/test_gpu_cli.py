@@ -152,3 +152,36 @@ def test_decode_processes_and_threads_give_identical_labels(workdir, lib):
     assert fa == fb and fa
     for f in fa:
         assert open(la / f).read() == open(lb / f).read()
+
+
+def test_scene_mode_equals_the_sweep_over_lossless_tiles(tmp_path, lib):
+    """--tile-scenes: a scene raster cut into tiles on the device (order, sizes and names of reference src/load_data/tile_tifs.py:33-47,
+    edge tiles included) gives byte-identical label files to the ordinary sweep over the same tiles stored losslessly."""
+    from PIL import Image
+    from aquaculture_amd import checkpoint, scenes, tiles
+    checkpoint.write_synthetic_checkpoint(str(tmp_path / "multilabel_farms_synth.pt"), "yolov5m", 5)
+    ids = {(0, 0): 19, (1024, 0): 3, (0, 1024): 20, (1024, 1024): 19}
+    scene = np.zeros((1500, 2048, 3), np.uint8)
+    for (x0, y0), i in ids.items():
+        t = tiles.synthetic_tile(i, 1024)
+        scene[y0:y0 + 1024, x0:x0 + 1024] = t[: min(1024, 1500 - y0)]
+    (tmp_path / "scenes").mkdir()
+    (tmp_path / "jpegs").mkdir()
+    spath = tmp_path / "scenes" / "ORTHOIMAGERY.ORTHOPHOTOS2015_7.tif"
+    Image.fromarray(scene).save(spath)
+    grid = scenes.tile_grid(2048, 1500)
+    assert [g[2:] for g in grid] == [(1024, 1024), (1024, 476), (1024, 1024), (1024, 476)]
+    for x0, y0, w, h in grid:
+        Image.fromarray(scene[y0:y0 + h, x0:x0 + w]).save(tmp_path / "jpegs" / (scenes.tile_stem(str(spath), x0, y0) + ".png"))
+    _, ref = _run(tmp_path, "tiles")
+    cmd = [sys.executable, os.path.join(ROOT, "yolov5", "detect.py"), "--weights", str(tmp_path / "multilabel_farms_synth.pt"), "--source",
+           str(tmp_path / "scenes"), "--tile-scenes", "--nosave", "--save-txt", "--save-conf", "--project", str(tmp_path / "runs"), "--name",
+           "scene", "--batch-size", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "image 4/4" in r.stdout and "4 images" in r.stdout
+    lab = tmp_path / "runs" / "scene" / "labels"
+    fr, fs = sorted(os.listdir(ref)), sorted(os.listdir(lab))
+    assert fr == fs and len(fr) >= 3 and all(f.count("_") == 3 for f in fs)
+    for f in fr:
+        assert open(ref / f).read() == open(lab / f).read(), f

@@ -251,3 +251,33 @@ def test_engine_rejects_bad_input(lib, synth_ck):
         eng.infer(torch.zeros(1, 100, 100, 3, dtype=torch.uint8, device="cuda"))
     with pytest.raises(RuntimeError, match="bad thresholds"):
         eng.infer(torch.zeros(1, 64, 64, 3, dtype=torch.uint8, device="cuda"), conf_thres=1.5)
+
+
+@pytest.mark.parametrize("scene_hw,tile_hw", [((2048, 3072), (1024, 1024)), ((1500, 2500), (476, 1024)), ((1500, 2500), (1024, 452)),
+                                              ((700, 900), (640, 640))])
+def test_scene_tiles_letterbox_equals_letterbox_of_explicit_crops(lib, scene_hw, tile_hw):
+    """aq_letterbox_tiles_u8 (tiles cut out of one scene raster by the letterbox kernel, reference src/load_data/tile_tifs.py:33-47)
+    == aq_letterbox_u8 on the same tiles copied out first == the host restatement: identical bytes."""
+    from aquaculture_amd import dataloader, engine, scenes
+    rng = np.random.default_rng(scene_hw[0] + tile_hw[1])
+    scene = rng.integers(0, 256, scene_hw + (3,), dtype=np.uint8)
+    h, w = tile_hw
+    origins = [(x0, y0) for x0, y0, tw, th in scenes.tile_grid(scene_hw[1], scene_hw[0], max(h, w) if (h, w) != (640, 640) else 640)
+               if (th, tw) == (h, w)]
+    if (h, w) == (640, 640):
+        origins = [(0, 0), (260, 60), (17, 33)]                 # any in-raster origin works, not only grid points
+    assert origins
+    crops = np.stack([scene[y0:y0 + h, x0:x0 + w] for x0, y0 in origins], 0)
+    dev = torch.from_numpy(scene).cuda()
+    got = engine.letterbox_scene_tiles(dev, origins, (h, w)).cpu().numpy()
+    ref = engine.letterbox_device(torch.from_numpy(np.ascontiguousarray(crops)).cuda()).cpu().numpy()
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    assert np.array_equal(got[0], dataloader.letterbox(crops[0]))
+
+
+def test_scene_tiles_outside_the_raster_are_refused(lib):
+    from aquaculture_amd import engine
+    dev = torch.zeros((1100, 1100, 3), dtype=torch.uint8, device="cuda")
+    for origin in [(100, 0), (0, 77), (-1, 0)]:
+        with pytest.raises(RuntimeError, match="leaves the raster"):
+            engine.letterbox_scene_tiles(dev, [(0, 0), origin], (1024, 1024))

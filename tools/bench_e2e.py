@@ -24,10 +24,27 @@ def main():
     ap.add_argument("--batch-size", type=int, default=64)
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--decode-threads", action="store_true", help="in-process decode threads instead of worker processes (A/B)")
+    ap.add_argument("--scenes", type=int, default=0, help="scene mode: write this many 6144x6144 scene rasters (36 tiles each) and sweep them "
+                                                          "with --tile-scenes instead of a jpeg directory")
     a = ap.parse_args()
     from aquaculture_amd import checkpoint, tiles
     jp = os.path.join(a.dir, f"jpegs_{a.size}")
-    if not os.path.isdir(jp) or len(os.listdir(jp)) < a.n:
+    if a.scenes:
+        import numpy as np
+        from PIL import Image
+        jp = os.path.join(a.dir, "scenes")
+        a.n = 36 * a.scenes
+        if not os.path.isdir(jp) or len(os.listdir(jp)) < a.scenes:
+            os.makedirs(jp, exist_ok=True)
+            base = [tiles.synthetic_tile(i, 1024) for i in range(36)]
+            mosaic = np.concatenate([np.concatenate(base[6 * c:6 * c + 6], 0) for c in range(6)], 1)     # [6144, 6144, 3]
+            for k in range(a.scenes):                           # uncompressed baseline TIFF, as an ortho-photo download would be
+                dst = os.path.join(jp, f"ORTHOIMAGERY.ORTHOPHOTOS2015_{k}.tif")
+                if k < 8:
+                    Image.fromarray(np.roll(mosaic, 1024 * k, 0)).save(dst)
+                else:                                           # 8 distinct rasters (0.9 GB), the rest are links to them
+                    os.symlink(os.path.join(jp, f"ORTHOIMAGERY.ORTHOPHOTOS2015_{k % 8}.tif"), dst)
+    elif not os.path.isdir(jp) or len(os.listdir(jp)) < a.n:
         os.makedirs(jp, exist_ok=True)
         base = [tiles.synthetic_tile(i, a.size) for i in range(64)]      # 64 distinct tiles, re-encoded under N names
         from PIL import Image
@@ -40,7 +57,7 @@ def main():
         checkpoint.write_synthetic_checkpoint(w, "yolov5m", 5)
     cmd = [sys.executable, os.path.join(ROOT, "yolov5", "detect.py"), "--weights", w, "--source", jp, "--nosave", "--save-txt", "--save-conf",
            "--project", os.path.join(a.dir, "runs"), "--name", "e2e", "--batch-size", str(a.batch_size), "--workers", str(a.workers),
-           "--precision", a.precision, "--quiet"] + (["--decode-threads"] if a.decode_threads else [])
+           "--precision", a.precision, "--quiet"] + (["--decode-threads"] if a.decode_threads else []) + (["--tile-scenes"] if a.scenes else [])
     t0 = time.perf_counter()
     r = subprocess.run(cmd, capture_output=True, text=True)
     dt = time.perf_counter() - t0
@@ -48,7 +65,8 @@ def main():
     print("\n".join(tail[-5:]))
     if r.returncode != 0:
         print(r.stderr[-2000:])
-    print(f"wall {dt:.1f} s for {a.n} {a.size}px jpegs -> {a.n / dt:.0f} images/s including process start, checkpoint load and autotune")
+    what = f"{a.scenes} scenes ({a.n} 1024px tiles)" if a.scenes else f"{a.n} {a.size}px jpegs"
+    print(f"wall {dt:.1f} s for {what} -> {a.n / dt:.0f} images/s including process start, checkpoint load and autotune")
 
 
 if __name__ == "__main__":
