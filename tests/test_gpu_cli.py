@@ -185,3 +185,31 @@ def test_scene_mode_equals_the_sweep_over_lossless_tiles(tmp_path, lib):
     assert fr == fs and len(fr) >= 3 and all(f.count("_") == 3 for f in fs)
     for f in fr:
         assert open(ref / f).read() == open(lab / f).read(), f
+
+
+def test_scene_mode_two_ranks(tmp_path, lib):
+    """Scenes are sharded i % world; the union of the ranks' label files equals the single-process scene sweep and the final gather
+    accounts for every detection (gloo rehearsal of the RCCL path, both ranks on the one GPU)."""
+    from PIL import Image
+    from aquaculture_amd import checkpoint, tiles
+    checkpoint.write_synthetic_checkpoint(str(tmp_path / "multilabel_farms_synth.pt"), "yolov5m", 5)
+    (tmp_path / "scenes").mkdir()
+    t19, t20 = tiles.synthetic_tile(19, 1024), tiles.synthetic_tile(20, 1024)
+    Image.fromarray(t19).save(tmp_path / "scenes" / "ORTHOIMAGERY.ORTHOPHOTOS2015_1.tif")
+    Image.fromarray(np.concatenate([t20, t19], 0)).save(tmp_path / "scenes" / "ORTHOIMAGERY.ORTHOPHOTOS2015_2.tif", compression="tiff_lzw")
+    base = [os.path.join(ROOT, "yolov5", "detect.py"), "--weights", str(tmp_path / "multilabel_farms_synth.pt"), "--source",
+            str(tmp_path / "scenes"), "--tile-scenes", "--nosave", "--save-txt", "--save-conf", "--half", "--project", str(tmp_path / "runs")]
+    r1 = subprocess.run([sys.executable, *base, "--name", "one"], capture_output=True, text=True, timeout=420)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), *base, "--name", "two"], capture_output=True, text=True, timeout=420,
+                        env=dict(os.environ, AQ_DIST_BACKEND="gloo"))
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    assert "3 images" in r1.stdout and "3 images" in r2.stdout and "on 2 GPU(s)" in r2.stdout
+    a, b = tmp_path / "runs" / "one" / "labels", tmp_path / "runs" / "two" / "labels"
+    assert sorted(os.listdir(a)) == sorted(os.listdir(b)) and len(os.listdir(a)) == 3
+    for f in os.listdir(a):
+        assert open(a / f).read() == open(b / f).read(), f
