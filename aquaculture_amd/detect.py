@@ -199,7 +199,6 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     t_start = time.perf_counter()
     shape_str = ""
     pinned = [None] * depth
-    issued = 0
     k = 0
     def batch_source():
         """Uniform tile directories (the reference's case): zero-copy pinned batches; mixed sizes: the generic path."""
@@ -275,7 +274,6 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         shape_str = f"(1, 3, {H}, {W})"
         t2 = time.perf_counter()
         q.put((ev, counts_h, dets_h, paths, shapes0, (H, W), list(gidx), t2 - t1, slot))
-        issued += len(paths)
         while copy_done and (copy_done[0][0].query() or len(copy_done) > depth):
             ev_, bi_ = copy_done.pop(0)
             ev_.synchronize()

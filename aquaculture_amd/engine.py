@@ -295,8 +295,11 @@ class Engine:
                f":v{self.lib.aq_version()}:ops{len(self.plan.ops)}")   # library version + plan shape: new kernels invalidate old tables
         table = {}
         if cache and os.path.exists(cache):
-            with open(cache) as f:
-                table = json.load(f)
+            try:
+                with open(cache) as f:
+                    table = json.load(f)
+            except (OSError, ValueError):      # unreadable or half-written by another rank: tune again
+                table = {}
             if key in table and len(table[key]) == len(self.plan.ops):
                 for i, c in enumerate(table[key]):
                     if self.plan.ops[i].kind == _spec.OP_CONV:
@@ -308,8 +311,10 @@ class Engine:
         if cache:
             table[key] = cfgs
             os.makedirs(os.path.dirname(os.path.abspath(cache)), exist_ok=True)
-            with open(cache, "w") as f:
+            tmp = f"{cache}.{os.getpid()}.tmp"     # ranks of one job may share the file: replace it atomically
+            with open(tmp, "w") as f:
                 json.dump(table, f)
+            os.replace(tmp, cache)
         return cfgs
 
     def profile(self, enable: bool, ring: int = 32) -> None:
