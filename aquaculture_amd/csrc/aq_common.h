@@ -67,7 +67,7 @@ struct ConvParams {
 
 int aq_launch_conv(const ConvParams& p, int precision, int out_f32, int cfg, hipStream_t stream);
 int aq_conv_pick_config(int cout, int npix, int precision);
-int aq_launch_conv_halo(const ConvParams& p, int precision, int out_f32, int hcfg, hipStream_t stream);
+int aq_launch_conv_halo(const ConvParams& p, int precision, int out_f32, int hcfg, bool one_tile_per_wg, hipStream_t stream);
 int aq_conv_halo_num_configs();
 unsigned long long* aq_stamp_buffer(size_t* bytes);
 // 256 zero bytes on the CURRENT device (allocated on first use, one per device, never freed): the LDS-DMA source for pixels

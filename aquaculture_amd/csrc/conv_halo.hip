@@ -326,7 +326,7 @@ int aq_conv_halo_tiles(int hcfg, int* bm, int* bn) {
     return AQ_OK;
 }
 
-int aq_launch_conv_halo(const ConvParams& p_in, int precision, int out_f32, int hcfg, hipStream_t stream) {
+int aq_launch_conv_halo(const ConvParams& p_in, int precision, int out_f32, int hcfg, bool one_tile_per_wg, hipStream_t stream) {
     if (hcfg < 0 || hcfg >= kNumHalo) { aq_set_error("halo conv: bad config %d", hcfg); return AQ_ERR_INVALID; }
     const HaloConfig& k = kHalo[hcfg];
     ConvParams p = p_in;
@@ -368,6 +368,7 @@ int aq_launch_conv_halo(const ConvParams& p_in, int precision, int out_f32, int 
     long long grid = g_halo_cus;          // > 80 KiB of LDS per workgroup: one resident workgroup per CU
     if (lds <= 80 * 1024) grid *= 2;
     if (grid > ntiles) grid = ntiles;
+    if (one_tile_per_wg) grid = ntiles;     // see aq_launch_conv
     size_t sbytes = 0;
     unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
     if (sbuf && variant == 0 && hcfg == 0 && (size_t)grid * nw * 64 <= sbytes) {

@@ -536,6 +536,7 @@ extern "C" int aq_debug_conv_stamp(void* buf_dev, size_t bytes) {
 extern "C" int aq_conv_num_configs(void) { return kNumConfigs + aq_conv_halo_num_configs(); }
 
 extern "C" int aq_conv_config_tiles(int cfg, int* bm, int* bn) {
+    if (cfg >= 0) cfg &= ~AQ_CONV_CFG_ONE_TILE_PER_WG;
     if (cfg >= kNumConfigs) return aq_conv_halo_tiles(cfg - kNumConfigs, bm, bn);
     if (cfg < 0) return AQ_ERR_INVALID;
     *bm = kConfigs[cfg].bm;
@@ -567,8 +568,14 @@ int aq_conv_pick_config(int cout, int npix, int precision) {
     return best;
 }
 
-int aq_launch_conv(const ConvParams& p_in, int precision, int out_f32, int cfg, hipStream_t stream) {
-    if (cfg >= kNumConfigs) return aq_launch_conv_halo(p_in, precision, out_f32, cfg - kNumConfigs, stream);
+int aq_launch_conv(const ConvParams& p_in, int precision, int out_f32, int cfg_in, hipStream_t stream) {
+    // AQ_CONV_CFG_ONE_TILE_PER_WG: grid = tile count, every workgroup computes one tile and exits, so tiles go to CUs in the order
+    // CUs become free (within the launch and, with several batches in flight, across launches of different streams).  The
+    // default grid is persistent: one or two resident workgroups per CU walk a static stride of tiles and prefetch the next tile
+    // under the current epilogue -- better alone when the tile count divides evenly, worse when it leaves a ragged last round.
+    const bool one_tile_per_wg = cfg_in >= 0 && (cfg_in & AQ_CONV_CFG_ONE_TILE_PER_WG) != 0;
+    const int cfg = cfg_in >= 0 ? (cfg_in & ~AQ_CONV_CFG_ONE_TILE_PER_WG) : cfg_in;
+    if (cfg >= kNumConfigs) return aq_launch_conv_halo(p_in, precision, out_f32, cfg - kNumConfigs, one_tile_per_wg, stream);
     if (cfg < 0) { aq_set_error("conv: bad config %d", cfg); return AQ_ERR_INVALID; }
     const ConvConfig& k = kConfigs[cfg];
     ConvParams p = p_in;
@@ -615,6 +622,7 @@ int aq_launch_conv(const ConvParams& p_in, int precision, int out_f32, int cfg, 
     }
     long long grid = (long long)g_num_cus * blocks;
     if (grid > ntiles) grid = ntiles;
+    if (one_tile_per_wg) grid = ntiles;     // hardware dispatch order instead of the static persistent split
     if (g_stamp_buf && variant == 0) {
         for (const StampedKernel& sk : kStamped)
             if (sk.cfg == cfg && (size_t)grid * (k.threads / 64) * 64 <= g_stamp_bytes) {

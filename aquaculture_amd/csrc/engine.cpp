@@ -22,7 +22,7 @@ void aq_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* aq_last_error(void) { return g_err; }
-extern "C" int aq_version(void) { return 2; }   // 2: fused stem / Bottleneck / down-block ops, direct 1x1 and 3x3/s2 autotuner candidates
+extern "C" int aq_version(void) { return 3; }   // 2: fused stem / Bottleneck / down-block ops, direct 1x1 and 3x3/s2 candidates; 3: one-tile-per-workgroup grids
 
 namespace {
 
@@ -503,7 +503,8 @@ extern "C" int aq_engine_num_ops(aq_engine* e) { return e ? (int)e->ops.size() :
 
 extern "C" int aq_engine_set_conv_config(aq_engine* e, int op, int cfg) {
     AQ_REQUIRE(e && op >= 0 && op < (int)e->ops.size() && e->ops[op].kind == AQ_OP_CONV, "set_conv_config: op %d is not a conv", op);
-    AQ_REQUIRE((cfg >= -1 && cfg < aq_conv_num_configs()) || (cfg >= AQ_CONV_CFG_DIRECT1X1 && cfg == e->packed[op].direct_cfg),
+    AQ_REQUIRE((cfg >= -1 && (cfg < 0 || (cfg & ~AQ_CONV_CFG_ONE_TILE_PER_WG) < aq_conv_num_configs())) ||
+                   (cfg >= AQ_CONV_CFG_DIRECT1X1 && cfg == e->packed[op].direct_cfg),
                "set_conv_config: bad config %d for op %d", cfg, op);
     e->conv_cfg[op] = cfg;
     return AQ_OK;
@@ -533,8 +534,9 @@ extern "C" int aq_engine_autotune(aq_engine* e, const uint8_t* tiles_dev, int B,
         if (e->ops[oi].kind != AQ_OP_CONV) continue;
         float best = 1e30f;
         int best_cfg = -1;
-        for (int ci = 0; ci <= ncfg && rc == AQ_OK; ++ci) {
-            const int c = ci < ncfg ? ci : e->packed[oi].direct_cfg;  // last candidate: the direct kernel, where one applies
+        // candidates: every tile shape as a persistent grid and as one workgroup per tile, then the direct kernel where one applies
+        for (int ci = 0; ci <= 2 * ncfg && rc == AQ_OK; ++ci) {
+            const int c = ci < ncfg ? ci : (ci < 2 * ncfg ? ((ci - ncfg) | AQ_CONV_CFG_ONE_TILE_PER_WG) : e->packed[oi].direct_cfg);
             if (c < 0) continue;
             rc = run_conv(e, (int)oi, ws, tiles_dev, B, stream, c);   // warm-up (also sets the LDS attribute)
             if (rc == AQ_ERR_INVALID) { rc = AQ_OK; continue; }       // this tile shape does not apply to this layer

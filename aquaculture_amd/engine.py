@@ -554,6 +554,7 @@ def downblock_nhwc(x: torch.Tensor, wa_oihw: torch.Tensor, ba: torch.Tensor, wb_
 
 CONV_CFG_DIRECT1X1 = 1000   # AQ_CONV_CFG_DIRECT1X1
 CONV_CFG_DIRECT3X3S2 = 1001  # AQ_CONV_CFG_DIRECT3X3S2
+CONV_CFG_ONE_TILE_PER_WG = 4096  # AQ_CONV_CFG_ONE_TILE_PER_WG (OR-ed into a tile configuration id)
 
 
 def conv1x1_direct_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, act: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -173,6 +173,10 @@ int aq_downblock(const void* in_dev, int in_ld, int in_choff, void* out_dev, int
  * in registers.  Same operation as aq_conv2d with k = 1; the engine's autotuner times it per layer against the implicit-GEMM tile
  * shapes under the config id AQ_CONV_CFG_DIRECT1X1. */
 #define AQ_CONV_CFG_DIRECT1X1 1000
+/* OR-ed into a tile configuration id (aq_conv2d, aq_engine_set_conv_config): launch one workgroup per output tile instead of the
+ * persistent grid (one or two resident workgroups per CU striding over the tiles).  Tiles then reach CUs in the order CUs become
+ * free; the autotuner times both forms per layer. */
+#define AQ_CONV_CFG_ONE_TILE_PER_WG 4096
 int aq_conv1x1_direct_supported(int cin, int cout);
 int aq_pack_conv1x1_direct(const float* w_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream);
 int aq_conv1x1_direct(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff, int cin, int cout,

@@ -69,6 +69,10 @@ def test_conv_matches_reference(lib, case, precision):
         else:
             # within one bf16 ulp (2^-8 relative) of the exactly-rounded reference
             torch.testing.assert_close(out, ref.bfloat16().float(), rtol=2 ** -7, atol=1e-3)
+        # the same tile shape launched as one workgroup per tile: scheduling only, so the bytes are the same
+        out1 = engine.conv2d_nhwc(xd, w, b, stride=stride, act=act, residual=rd, precision=precision,
+                                  cfg=cfg | engine.CONV_CFG_ONE_TILE_PER_WG).cpu().float()
+        assert torch.equal(out1, out), cfg
     assert ran >= 10
 
 

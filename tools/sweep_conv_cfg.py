@@ -36,7 +36,7 @@ def main():
         oi = names.index(name)
         tuned = lib.aq_engine_get_conv_config(eng.handle, oi)
         rows = []
-        for cfg in list(range(ncfg)) + [engine.CONV_CFG_DIRECT1X1, engine.CONV_CFG_DIRECT3X3S2]:
+        for cfg in list(range(ncfg)) + [c | engine.CONV_CFG_ONE_TILE_PER_WG for c in range(ncfg)] + [engine.CONV_CFG_DIRECT1X1, engine.CONV_CFG_DIRECT3X3S2]:
             try:
                 eng.set_conv_config(oi, cfg)
             except RuntimeError:
@@ -52,14 +52,14 @@ def main():
             ms, calls = eng.op_times_ms()
             eng.profile(False)
             bm, bn = C.c_int(), C.c_int()
-            if cfg < ncfg:
+            if (cfg & 4095) < ncfg:
                 lib.aq_conv_config_tiles(cfg, C.byref(bm), C.byref(bn))
             rows.append((float(ms[oi]) * 1e3, cfg, bm.value, bn.value))
         eng.set_conv_config(oi, -1)
         rows.sort()
         print(f"{name} (op {oi}, tuned cfg {tuned}):")
         for us, cfg, bm, bn in rows[:a.top]:
-            print(f"   cfg {cfg:4d}  {bm:3d}x{bn:3d}  {us:8.1f} us")
+            print(f"   cfg {cfg & 4095:4d}{'+1/wg' if cfg >= 4096 else '     '}  {bm:3d}x{bn:3d}  {us:8.1f} us")
         sys.stdout.flush()
 
 
