@@ -559,6 +559,24 @@ extern "C" int aq_engine_autotune(aq_engine* e, const uint8_t* tiles_dev, int B,
     return AQ_OK;
 }
 
+extern "C" int aq_engine_set_tuned_table(aq_engine* e, int B, int H, int W, const int* cfgs, int n_ops) {
+    AQ_REQUIRE(e && cfgs && n_ops == (int)e->ops.size() && B > 0 && H > 0 && W > 0, "set_tuned_table: expected %d entries", e ? (int)e->ops.size() : 0);
+    for (int i = 0; i < n_ops; ++i) {
+        const int c = cfgs[i];
+        if (e->ops[i].kind != AQ_OP_CONV) continue;
+        AQ_REQUIRE(c == -1 || (c >= 0 && (c & ~AQ_CONV_CFG_ONE_TILE_PER_WG) < aq_conv_num_configs()) ||
+                       (c >= AQ_CONV_CFG_DIRECT1X1 && c < AQ_CONV_CFG_ONE_TILE_PER_WG && c == e->packed[i].direct_cfg),
+                   "set_tuned_table: bad config %d for op %d", c, i);
+    }
+    int rc = layout(e, B, H, W);      // (H, W) as the engine lays them out: the table is matched against those
+    if (rc) return rc;
+    e->tuned_cfg.assign(cfgs, cfgs + n_ops);
+    for (int i = 0; i < n_ops; ++i)
+        if (e->ops[i].kind != AQ_OP_CONV) e->tuned_cfg[i] = -1;
+    e->tuned_B = B; e->tuned_H = e->lay_H; e->tuned_W = e->lay_W;
+    return AQ_OK;
+}
+
 extern "C" int aq_engine_get_conv_config(aq_engine* e, int op) {
     if (!e || op < 0 || op >= (int)e->ops.size()) return -1;
     if (e->conv_cfg[op] >= 0) return e->conv_cfg[op];

@@ -87,6 +87,9 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
                    help="reference data/wanted_bboxes.csv: after the sweep, geocode every detection (the arithmetic of the "
                         "reference's src/process_yolo/geocode_results.py geocode_all_detections, as one batch op) -> --geocode-out")
     p.add_argument("--geocode-out", default=None, metavar="GEOJSON", help="default <save_dir>/detections.geojson")
+    p.add_argument("--autotune", choices=("auto", "on", "off"), default="auto",
+                   help="time the conv kernels' tile configurations on the first full batch and keep the fastest per layer "
+                        "(cached in $AQ_TUNE_CACHE or ~/.cache/aquaculture_amd/); auto = only for sweeps of >= 8 batches per GPU")
     p.add_argument("--tile-scenes", nargs="?", type=int, const=1024, default=0, metavar="TILESIZE",
                    help="opt-in scene mode: --source holds whole scene rasters (*.tif); they are cut into TILESIZE (default 1024) tiles "
                         "on the GPU, in the order and with the names of reference src/load_data/tile_tifs.py, skipping its jpeg step")
@@ -98,7 +101,7 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
 def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_det=1000, device="",
         save_txt=False, save_conf=False, nosave=False, classes=None, agnostic_nms=False,
         project="runs/detect", name="exp", exist_ok=False, half=False, batch_size=64, precision=None,
-        workers=8, decode_threads=False, quiet=False, geocode_bboxes=None, geocode_out=None, tile_scenes=0, log=print, **unsupported):
+        workers=8, decode_threads=False, quiet=False, geocode_bboxes=None, geocode_out=None, tile_scenes=0, autotune="auto", log=print, **unsupported):
     from .engine import Engine, format_label_rows, letterbox_device, letterbox_scene_tiles   # raises if the HIP library or the GPU is missing: there is no fallback
 
     for k in UNSUPPORTED:
@@ -232,6 +235,12 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
 
     source_iter = scene_source() if tile_scenes else image_source()
     scene_dev, scene_path, scene_ev = None, None, None
+    # Autotune on the first full batch (rank 0 times, every rank installs the same table: identical kernels on all GPUs of a run).
+    per_rank = dataset.total // max(world, 1)
+    tune = autotune == "on" or (autotune == "auto" and per_rank >= 8 * batch_size)
+    if tune and world > 1 and (dataset.n_scenes_total if tile_scenes else dataset.total) < world:
+        tune = False                                   # some rank has no batch to meet the broadcast with
+    tune_cache = os.environ.get("AQ_TUNE_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "aquaculture_amd", "tune.json")
     copy_done = []
     for paths, host, shapes0, buf_i, gidx in source_iter:
         if err:
@@ -259,6 +268,18 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                     h2d.record(st)
                     copy_done.append((h2d, buf_i))
                 tiles = letterbox_device(tiles, tuple(imgsz), int(max(ck.stride)), True)
+            if tune:                                   # once, before the pipeline fills
+                tune = False
+                geom = [int(tiles.shape[0]), int(tiles.shape[1]), int(tiles.shape[2])]
+                t_tune = time.perf_counter()
+                box = [geom, eng.autotune(tiles, cache=tune_cache) if rank == 0 else None]
+                if world > 1:
+                    torch.distributed.broadcast_object_list(box, src=0)
+                    if rank != 0 and box[0] == geom:
+                        eng.set_tuned_table(*geom, box[1])
+                if rank == 0:
+                    log(f"autotuned {sum(1 for c in box[1] if c >= 0)} conv layers for batch {geom[0]} x {geom[1]}x{geom[2]} in "
+                        f"{time.perf_counter() - t_tune:.1f}s (table: {tune_cache})")
             t1 = time.perf_counter()
             dets, counts = eng.infer(tiles, conf_thres, iou_thres, max_det, slot=slot)
             B = tiles.shape[0]

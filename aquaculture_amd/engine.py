@@ -61,7 +61,7 @@ class aq_det(C.Structure):
 EXPORTS = (
     "aq_last_error", "aq_version", "aq_engine_create", "aq_engine_destroy", "aq_engine_workspace_bytes",
     "aq_engine_infer", "aq_engine_forward_raw", "aq_engine_tensor_ptr", "aq_engine_profile",
-    "aq_engine_op_times", "aq_engine_num_ops", "aq_engine_set_conv_config", "aq_engine_autotune",
+    "aq_engine_op_times", "aq_engine_num_ops", "aq_engine_set_conv_config", "aq_engine_autotune", "aq_engine_set_tuned_table",
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
     "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
     "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct", "aq_preprocess_s2d", "aq_sppf_pool",
@@ -95,6 +95,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_engine_set_conv_config.argtypes = [vp, i32, i32]
     lib.aq_engine_autotune.argtypes = [vp, vp, i32, i32, i32, vp, sz, i32, vp]
     lib.aq_engine_get_conv_config.argtypes = [vp, i32]
+    lib.aq_engine_set_tuned_table.argtypes = [vp, i32, i32, i32, C.POINTER(i32), i32]
     lib.aq_debug_conv_stamp.argtypes = [vp, sz]
     lib.aq_debug_mfma_peak.argtypes = [i32, i32, vp, vp]
     lib.aq_conv_config_tiles.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
@@ -285,6 +286,11 @@ class Engine:
     def set_conv_config(self, op: int, cfg: int) -> None:
         _check(self.lib.aq_engine_set_conv_config(self.handle, op, cfg))
 
+    def set_tuned_table(self, B: int, H: int, W: int, cfgs) -> None:
+        """Install an autotune result (from a cache file or another rank) for batches of exactly this geometry."""
+        arr = (C.c_int * len(cfgs))(*[int(c) for c in cfgs])
+        _check(self.lib.aq_engine_set_tuned_table(self.handle, B, H, W, arr, len(cfgs)))
+
     def autotune(self, tiles: torch.Tensor, reps: int = 3, cache: Optional[str] = None) -> List[int]:
         """Pick the fastest tile configuration per conv op for this batch geometry (synchronises).
         ``cache``: optional JSON file; a stored table for the same model/precision/geometry is applied
@@ -301,9 +307,7 @@ class Engine:
             except (OSError, ValueError):      # unreadable or half-written by another rank: tune again
                 table = {}
             if key in table and len(table[key]) == len(self.plan.ops):
-                for i, c in enumerate(table[key]):
-                    if self.plan.ops[i].kind == _spec.OP_CONV:
-                        self.set_conv_config(i, c)
+                self.set_tuned_table(B, H, W, table[key])
                 return list(table[key])
         ws = self.workspace(B, H, W)
         _check(self.lib.aq_engine_autotune(self.handle, tiles.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(), reps, _stream_ptr()))

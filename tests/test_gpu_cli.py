@@ -213,3 +213,25 @@ def test_scene_mode_two_ranks(tmp_path, lib):
     assert sorted(os.listdir(a)) == sorted(os.listdir(b)) and len(os.listdir(a)) == 3
     for f in os.listdir(a):
         assert open(a / f).read() == open(b / f).read(), f
+
+
+def test_cli_autotune_keeps_the_labels(workdir, lib, tmp_path):
+    """--autotune on: the first batch is used to time every tile configuration per conv layer; the table is cached and the second
+    run installs it without timing.  fp32 results may move by accumulation order only (halo vs implicit-GEMM K order): same boxes
+    within 1e-4 (a handful of box edges one pixel off after rounding), same counts."""
+    env = {"AQ_TUNE_CACHE": str(tmp_path / "tune.json")}
+    _, off = _run(workdir, "tune_off", extra=("--autotune", "off"))
+    out1, on1 = _run(workdir, "tune_on", extra=("--autotune", "on"), env=env)
+    assert "autotuned" in out1 and os.path.exists(env["AQ_TUNE_CACHE"])
+    out2, on2 = _run(workdir, "tune_on2", extra=("--autotune", "on"), env=env)
+    assert "autotuned" in out2
+    fa = sorted(os.listdir(off))
+    assert fa == sorted(os.listdir(on1)) == sorted(os.listdir(on2)) and fa
+    for f in fa:
+        a, b = np.loadtxt(off / f, ndmin=2), np.loadtxt(on1 / f, ndmin=2)
+        assert a.shape == b.shape and np.array_equal(np.sort(a[:, 0]), np.sort(b[:, 0]))      # near-ties in conf may swap lines
+        # nearest row of the same class: a 1e-6 change before `.round()` can move a box edge by one pixel (1/640), nothing more
+        d = np.abs(a[:, None, 1:] - b[None, :, 1:]).max(-1) + 10.0 * (a[:, None, 0] != b[None, :, 0])
+        near = d.min(1)
+        assert near.max() <= 2.0 / 640 + 1e-4 and (near <= 1e-4).mean() >= 0.99, (f, near.max(), (near <= 1e-4).mean())
+        assert open(on1 / f).read() == open(on2 / f).read()          # cached table = the same kernels again
