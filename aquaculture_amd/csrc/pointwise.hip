@@ -324,8 +324,32 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, u
     if (s == 123.456f) out[0] = s;   // keep the loop alive without a store in practice
 }
 
+// the same with v_mfma_f32_16x16x32_bf16 (the instruction of the fused / direct kernels): 16 independent accumulators per wave
+__global__ __launch_bounds__(256) void mfma_peak16_kernel(float* out, int iters, unsigned seed) {
+    f32x4 acc[16];
+    bf16x8 a, b;
+    const unsigned t = threadIdx.x * 2654435761u + seed;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (short)(0x3f80 + ((t >> i) & 0x3f)); b[i] = (short)(0xbf80 + ((t >> (i + 3)) & 0x3f)); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[k], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += acc[k][threadIdx.x & 3];
+    if (s == 123.456f) out[0] = s;
+}
+
 extern "C" int aq_debug_mfma_peak(int blocks, int iters, void* out_dev, void* stream) {
-    AQ_REQUIRE(blocks > 0 && iters > 0 && out_dev, "mfma_peak: bad argument");
+    AQ_REQUIRE(blocks > 0 && iters != 0 && out_dev, "mfma_peak: bad argument");
+    if (iters < 0) {       // negative count: the 16x16x32 form, 16 MFMAs (the same FLOPs as 8 of the 32x32x16 form) per iteration
+        hipLaunchKernelGGL(mfma_peak16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float*)out_dev, -iters, 12345u);
+        AQ_CHECK_HIP(hipGetLastError());
+        return AQ_OK;
+    }
     hipLaunchKernelGGL(mfma_peak_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float*)out_dev, iters, 12345u);
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;
