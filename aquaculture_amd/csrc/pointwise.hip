@@ -118,36 +118,51 @@ __device__ __forceinline__ uint4 max16(uint4 a, uint4 v) {
 
 template <bool F32, int GPB>   // GPB = adjacent 16-byte channel groups per workgroup (GPB * 16 B contiguous per pixel)
 __global__ __launch_bounds__(256) void sppf_pool3_kernel(char* __restrict__ base, int ld_b, int slice_b, int groups, int H, int W) {
+    // Three chained 5x5 / stride 1 / pad 2 max pools of one image plane, kept in LDS.  Each pool is done separably -- a horizontal 5-tap
+    // pass into a temporary plane, then a vertical 5-tap pass (max is exact, so the result is the 5x5 window maximum bit for bit) --
+    // 10 LDS reads per output instead of 25: the kernel is bound by LDS bandwidth, not by HBM.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int hw = H * W, n = hw * GPB;
-    uint4* plane[2] = {(uint4*)smem, (uint4*)smem + n};
+    uint4* plane[3] = {(uint4*)smem, (uint4*)smem + n, (uint4*)smem + 2 * n};
     const int gblocks = groups / GPB;
     const int b = blockIdx.x / gblocks, g0 = (blockIdx.x - b * gblocks) * GPB;
     char* img = base + (long long)b * hw * ld_b + g0 * 16;
+    auto mx = [](uint4 m, uint4 v) -> uint4 {
+        if (F32) return max16<true>(m, v);
+        m.x = pk_max_i16(m.x, v.x); m.y = pk_max_i16(m.y, v.y); m.z = pk_max_i16(m.z, v.z); m.w = pk_max_i16(m.w, v.w);
+        return m;
+    };
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int pix = i / GPB, g = i - pix * GPB;
         const uint4 v = *(const uint4*)(img + (long long)pix * ld_b + g * 16);
         plane[0][i] = F32 ? v : key16(v);                  // bf16: keep the planes as order-preserving int16 keys
     }
     __syncthreads();
+    int cur = 0;                                           // plane[cur] = input of this stage, plane[2] = row maxima, plane[cur ^ 1] = output
     for (int s = 0; s < 3; ++s) {
-        const uint4* src = plane[s & 1];
-        uint4* dst = plane[(s & 1) ^ 1];
+        const uint4* src = plane[cur];
+        uint4* tmp = plane[2];
+        uint4* dst = plane[cur ^ 1];
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int pix = i / GPB, g = i - pix * GPB;
             const int y = pix / W, x = pix - y * W;
-            const int y0 = max(y - 2, 0), y1 = min(y + 2, H - 1), x0 = max(x - 2, 0), x1 = min(x + 2, W - 1);
+            const int x0 = max(x - 2, 0), x1 = min(x + 2, W - 1);
             uint4 m = src[i];
-            for (int yy = y0; yy <= y1; ++yy)
-                for (int xx = x0; xx <= x1; ++xx) {
-                    const uint4 v = src[(yy * W + xx) * GPB + g];
-                    if (F32) m = max16<true>(m, v);
-                    else { m.x = pk_max_i16(m.x, v.x); m.y = pk_max_i16(m.y, v.y); m.z = pk_max_i16(m.z, v.z); m.w = pk_max_i16(m.w, v.w); }
-                }
+            for (int xx = x0; xx <= x1; ++xx) m = mx(m, src[(y * W + xx) * GPB + g]);
+            tmp[i] = m;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int pix = i / GPB, g = i - pix * GPB;
+            const int y = pix / W, x = pix - y * W;
+            const int y0 = max(y - 2, 0), y1 = min(y + 2, H - 1);
+            uint4 m = tmp[i];
+            for (int yy = y0; yy <= y1; ++yy) m = mx(m, tmp[(yy * W + x) * GPB + g]);
             dst[i] = m;
             *(uint4*)(img + (long long)pix * ld_b + (long long)(s + 1) * slice_b + g * 16) = F32 ? m : key16(m);
         }
         __syncthreads();
+        cur ^= 1;
     }
 }
 
@@ -231,8 +246,8 @@ extern "C" int aq_sppf_pool(void* buf_dev, int ld, int ch_off, int c, int B, int
     const long long n = (long long)B * H * W * groups;
     AQ_REQUIRE(n < (1LL << 31), "sppf_pool: batch too large");
     char* base = (char*)buf_dev + (long long)ch_off * eb;
-    constexpr int GPB = 4;
-    const size_t plane_lds = (size_t)2 * H * W * 16 * GPB;
+    constexpr int GPB = 2;
+    const size_t plane_lds = (size_t)3 * H * W * 16 * GPB;
     if (plane_lds <= 64 * 1024 && groups % GPB == 0 && (long long)B * groups < (1LL << 31)) {   // plane fits LDS: one fused launch
         const unsigned grid = (unsigned)(B * (groups / GPB));
         if (precision == AQ_FP32)

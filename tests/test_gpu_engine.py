@@ -281,3 +281,29 @@ def test_scene_tiles_outside_the_raster_are_refused(lib):
     for origin in [(100, 0), (0, 77), (-1, 0)]:
         with pytest.raises(RuntimeError, match="leaves the raster"):
             engine.letterbox_scene_tiles(dev, [(0, 0), origin], (1024, 1024))
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("shape", [(2, 20, 20, 384), (3, 13, 17, 16), (1, 5, 3, 8), (2, 40, 40, 64), (1, 80, 80, 32)])
+def test_sppf_pools_match_chained_max_pool2d(lib, precision, shape):
+    """aq_sppf_pool: y1 = mp5(x), y2 = mp5(y1), y3 = mp5(y2) written into slices 1..3 of the [x|y1|y2|y3] buffer ([UPSTREAM SPPF.forward]:
+    three chained MaxPool2d(5, 1, 2)); bit-exact against torch (max has no rounding).  Small planes run the fused in-LDS kernel
+    (separable passes), large ones the three-launch path; the buffer has a channel offset and extra channels on both sides."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from aquaculture_amd import engine
+    B, H, W, c = shape
+    dt = torch.bfloat16 if precision == "bf16" else torch.float32
+    g = torch.Generator().manual_seed(H * 31 + c)
+    ld, off = 4 * c + 16, 8
+    buf = torch.full((B, H, W, ld), -7.0, dtype=dt)
+    x = torch.randn(B, H, W, c, generator=g).to(dt)
+    buf[..., off:off + c] = x
+    dev = buf.cuda()
+    engine._check(lib.aq_sppf_pool(dev.data_ptr(), ld, off, c, B, H, W, 0 if precision == "bf16" else 1, torch.cuda.current_stream().cuda_stream))
+    got = dev.cpu()
+    y = x.float().permute(0, 3, 1, 2)
+    for s in range(1, 4):
+        y = F.max_pool2d(y, 5, 1, 2)
+        assert torch.equal(got[..., off + s * c: off + (s + 1) * c].float(), y.permute(0, 2, 3, 1)), s
+    assert torch.equal(got[..., off:off + c], x) and (got[..., :off] == -7.0).all() and (got[..., off + 4 * c:] == -7.0).all()

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Per-op HIP-event times of one engine step (single stream), autotuned: python tools/op_times.py [--batch 64] [--grep model.9]"""
+import argparse
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from aquaculture_amd import checkpoint, engine, tiles  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--grep", default="")
+ap.add_argument("--lib", default=None)
+a = ap.parse_args()
+if a.lib:
+    engine.load_library(a.lib)
+eng = engine.Engine(checkpoint.synthetic_checkpoint("yolov5m", 5), "bf16")
+x = torch.from_numpy(tiles.synthetic_batch(range(a.batch), 640)).cuda()
+eng.autotune(x)
+eng.infer(x)
+eng.profile(True, a.reps)
+for _ in range(a.reps):
+    eng.infer(x)
+torch.cuda.synchronize()
+ms, calls = eng.op_times_ms()
+for i, o in enumerate(eng.plan.ops):
+    if a.grep in o.name:
+        print(f"{i:3d} {o.name:28s} {ms[i] * 1e3:8.1f} us")
+print(f"total {ms.sum():.3f} ms over {calls} calls")
