@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void sppf_pool3_kernel(char* __restrict__ base
     // 10 LDS reads per output instead of 25: the kernel is bound by LDS bandwidth, not by HBM.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int hw = H * W, n = hw * GPB;
-    uint4* plane[3] = {(uint4*)smem, (uint4*)smem + n, (uint4*)smem + 2 * n};
+    uint4* const src = (uint4*)smem;       // stage input, overwritten by the stage output (its rows are dead once tmp is complete)
+    uint4* const tmp = (uint4*)smem + n;   // row maxima
     const int gblocks = groups / GPB;
     const int b = blockIdx.x / gblocks, g0 = (blockIdx.x - b * gblocks) * GPB;
     char* img = base + (long long)b * hw * ld_b + g0 * 16;
@@ -135,14 +136,10 @@ __global__ __launch_bounds__(256) void sppf_pool3_kernel(char* __restrict__ base
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int pix = i / GPB, g = i - pix * GPB;
         const uint4 v = *(const uint4*)(img + (long long)pix * ld_b + g * 16);
-        plane[0][i] = F32 ? v : key16(v);                  // bf16: keep the planes as order-preserving int16 keys
+        src[i] = F32 ? v : key16(v);                       // bf16: keep the planes as order-preserving int16 keys
     }
     __syncthreads();
-    int cur = 0;                                           // plane[cur] = input of this stage, plane[2] = row maxima, plane[cur ^ 1] = output
     for (int s = 0; s < 3; ++s) {
-        const uint4* src = plane[cur];
-        uint4* tmp = plane[2];
-        uint4* dst = plane[cur ^ 1];
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int pix = i / GPB, g = i - pix * GPB;
             const int y = pix / W, x = pix - y * W;
@@ -158,11 +155,10 @@ __global__ __launch_bounds__(256) void sppf_pool3_kernel(char* __restrict__ base
             const int y0 = max(y - 2, 0), y1 = min(y + 2, H - 1);
             uint4 m = tmp[i];
             for (int yy = y0; yy <= y1; ++yy) m = mx(m, tmp[(yy * W + x) * GPB + g]);
-            dst[i] = m;
+            src[i] = m;
             *(uint4*)(img + (long long)pix * ld_b + (long long)(s + 1) * slice_b + g * 16) = F32 ? m : key16(m);
         }
         __syncthreads();
-        cur ^= 1;
     }
 }
 
@@ -246,8 +242,8 @@ extern "C" int aq_sppf_pool(void* buf_dev, int ld, int ch_off, int c, int B, int
     const long long n = (long long)B * H * W * groups;
     AQ_REQUIRE(n < (1LL << 31), "sppf_pool: batch too large");
     char* base = (char*)buf_dev + (long long)ch_off * eb;
-    constexpr int GPB = 2;
-    const size_t plane_lds = (size_t)3 * H * W * 16 * GPB;
+    constexpr int GPB = 4;
+    const size_t plane_lds = (size_t)2 * H * W * 16 * GPB;
     if (plane_lds <= 64 * 1024 && groups % GPB == 0 && (long long)B * groups < (1LL << 31)) {   // plane fits LDS: one fused launch
         const unsigned grid = (unsigned)(B * (groups / GPB));
         if (precision == AQ_FP32)
