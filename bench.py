@@ -99,6 +99,7 @@ def cpu_baseline(ck, size: int, budget_s: float) -> dict:
 def main() -> int:
     a = parse()
     from aquaculture_amd import checkpoint, dist as aqdist, spec
+    from aquaculture_amd import engine as aqengine
     from aquaculture_amd.engine import Engine
 
     # one rank per GPU over RCCL ("nccl"); AQ_DIST_BACKEND=gloo is the single-GPU rehearsal of the N > 1 code path
@@ -203,20 +204,25 @@ def main() -> int:
             tt = float(ms[ii].sum()) * 1e-3
             ff = float(sum(plan.ops[i].flops_per_tile for i in ii)) * B
             n_ig = eng.lib.aq_conv_num_configs()
-            if cbest >= 1000:
+            one_per_wg = cbest >= aqengine.CONV_CFG_ONE_TILE_PER_WG          # flag OR-ed into a tile-shape id
+            shape = cbest & (aqengine.CONV_CFG_ONE_TILE_PER_WG - 1)
+            if not one_per_wg and cbest >= 1000:
                 kname = "downblock_kernel<96, 192> (direct 3x3/s2)"
             else:
                 import ctypes as _C
                 bm, bn = _C.c_int(), _C.c_int()
-                eng.lib.aq_conv_config_tiles(cbest, _C.byref(bm), _C.byref(bn))
+                eng.lib.aq_conv_config_tiles(shape, _C.byref(bm), _C.byref(bn))
                 n_igemm = 21                                  # conv_igemm.hip's shape table; halo shapes follow (tools/stamp_conv.py)
-                kname = f"{'conv3x3_halo_kernel' if cbest >= n_igemm else 'conv_igemm_kernel'} tile {bm.value}x{bn.value} (config {cbest} of {n_ig})"
+                kname = (f"{'conv3x3_halo_kernel' if shape >= n_igemm else 'conv_igemm_kernel'} tile {bm.value}x{bn.value} "
+                         f"(shape {shape} of {n_ig}, {'one workgroup per tile' if one_per_wg else 'persistent grid'})")
             single = {"config": cbest, "kernel": kname, "launches_per_step": len(ii), "avg_launch_ms": round(1e3 * tt / len(ii), 4),
                       "tflops": round(ff / tt / 1e12, 1), "frac": round(ff / tt / 1e12 / peak, 4)}
-        traffic = None
+        traffic = None                                       # PMC figure: only for the workload it was collected on
         try:
             with open(a.traffic_json) as f:
-                traffic = json.load(f).get("bytes_per_launch")
+                tj = json.load(f)
+            if a.variant == "yolov5m" and a.size == 640 and a.precision == "bf16" and int(tj.get("batch", -1)) == B:
+                traffic = tj.get("bytes_per_launch")
         except (OSError, ValueError):
             pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
