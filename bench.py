@@ -34,8 +34,8 @@ PEAK_F32_TFLOPS = 157.3
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=100)     # ~0.5 s timed at batch 64: the first tens of steps still see the clocks settle
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--batch", type=int, default=64)
     p.add_argument("--size", type=int, default=640)
     p.add_argument("--variant", default="yolov5m")
