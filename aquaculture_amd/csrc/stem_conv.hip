@@ -37,7 +37,9 @@ template <bool F32> struct StemGeom {
     static constexpr int PROWB = kPRowDw * 4 * EB + 16;           // patch row stride in bytes (+16: rows start on shifted banks)
     static constexpr int KS = F32 ? 6 * kKyPad / 4 : 5;           // MFMA k-steps: 36 x (K=4) fp32, 5 x (K=32) bf16 (K 144 -> 160)
     static constexpr int PATCHB = kPH * PROWB;
-    static constexpr int LDS = 2 * PATCHB + 256 * EB;             // two patch buffers + value table
+    static constexpr int LUTB = 256 * EB;
+    static constexpr int STAGEB = ((kPH * kPRowDw + 255) / 256) * 1024;   // raw input dwords of one patch, lane-linear (DMA variant)
+    static constexpr int LDS = 2 * PATCHB + LUTB + STAGEB;        // two patch buffers + value table + raw staging
 };
 
 // Host/device agreement on the A-fragment image: [k-step][M block][lane] -> 8 bf16 (16 B) or 1 float.
@@ -45,8 +47,14 @@ template <bool F32> struct StemGeom {
 //   fp32: lane holds K = 4 * s + g: ky = s / 6, j = 4 * (s % 6) + g
 // j < 18 maps to (kx, c) = (j / 3, j % 3); everything else is zero.
 
-template <bool F32, int MB>
+// DMA (bf16, image rows whose byte length is a multiple of 4): the raw input dwords of the NEXT tile's patch travel by LDS-DMA into a
+// staging area instead of through registers, all waits are hand-counted and the barrier is a bare s_barrier.  With register loads the
+// compiler cannot count the output stores issued since (the block loop has wave-uniform skips), waits with vmcnt(0) before the
+// conversion, and __syncthreads adds another vmcnt(0): every tile then ended by draining ALL of its output stores -- 88 of the
+// kernel's 237 us (measured by compiling the load out).  Here a full tile waits with vmcnt(stores of this tile), i.e. for the DMA only.
+template <bool F32, int MB, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const ConvParams p, const uint8_t* __restrict__ tiles, int tiles_x, int tiles_y) {
+    static_assert(!(DMA && F32), "the DMA variant converts arithmetically: bf16 only");
     using G = StemGeom<F32>;
     using elem_t = typename std::conditional<F32, float, bf16_t>::type;
     using afrag_t = typename std::conditional<F32, float, bf16x8>::type;
@@ -123,30 +131,89 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const ConvParams p, c
             const int r = i / kPRowDw, d = i - r * kPRowDw;
             if (i < kPH * kPRowDw) {
                 const uint32_t v = raw[it];
-                const elem_t e0 = s_lut[v & 255], e1 = s_lut[(v >> 8) & 255], e2 = s_lut[(v >> 16) & 255], e3 = s_lut[v >> 24];
                 char* dst = patch + r * PROWB + d * 4 * EB;
-                if constexpr (F32) *(f32x4*)dst = f32x4{e0, e1, e2, e3};
-                else *(uint2*)dst = make_uint2((uint32_t)e0 | ((uint32_t)e1 << 16), (uint32_t)e2 | ((uint32_t)e3 << 16));
+                if constexpr (F32) {
+                    const elem_t e0 = s_lut[v & 255], e1 = s_lut[(v >> 8) & 255], e2 = s_lut[(v >> 16) & 255], e3 = s_lut[v >> 24];
+                    *(f32x4*)dst = f32x4{e0, e1, e2, e3};
+                } else {
+                    // bf16: RNE(v * (1/255)) == RNE(v / 255) for all 256 byte values (checked exhaustively, tests/test_host_logic.py),
+                    // so the four table look-ups (dependent LDS reads) become v_cvt_f32_ubyte + v_mul + v_cvt_pk_bf16_f32
+                    constexpr float k = 1.0f / 255.0f;
+                    const float f0 = (float)(v & 255u) * k, f1 = (float)((v >> 8) & 255u) * k, f2 = (float)((v >> 16) & 255u) * k,
+                                f3 = (float)(v >> 24) * k;
+                    *(uint2*)dst = make_uint2(pack_bf16x2(f0, f1), pack_bf16x2(f2, f3));
+                }
             }
         }
     };
+
+    // ---- DMA variant: raw dwords -> staging (lane-linear: slot i = tid + 256 it), then staging -> patch ----
+    char* s_stage = smem + 2 * G::PATCHB + G::LUTB;
+    auto dma_raw = [&](int tile) {
+        const int b = tile / tiles_per_img, tr = tile - b * tiles_per_img;
+        const int ty0 = tr / tiles_x, tx0 = tr - ty0 * tiles_x;
+        const int y0 = ty0 * kTH, x0 = tx0 * kTW;
+        const uint8_t* img = tiles + (size_t)b * H * W * 3;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            const int r = i / kPRowDw, d = i - r * kPRowDw;
+            const int iy = 2 * y0 - 2 + r, byte0 = 6 * x0 - 8 + 4 * d;
+            const bool ok = tile < p.n_tiles_n && i < kPH * kPRowDw && iy >= 0 && iy < H && byte0 >= 0 && byte0 < W * 3;
+            const char* src = ok ? (const char*)img + (size_t)iy * W * 3 + byte0 : p.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(s_stage + (it * 256 + wave * 64) * 4), 4, 0, 0);
+        }
+    };
+    auto convert_stage = [&](char* patch) {       // each lane converts the slots it loaded itself: no barrier between DMA and here
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            const int r = i / kPRowDw, d = i - r * kPRowDw;
+            if (i < kPH * kPRowDw) {
+                const uint32_t v = *(const uint32_t*)(s_stage + i * 4);
+                constexpr float k = 1.0f / 255.0f;
+                const float f0 = (float)(v & 255u) * k, f1 = (float)((v >> 8) & 255u) * k, f2 = (float)((v >> 16) & 255u) * k,
+                            f3 = (float)(v >> 24) * k;
+                const uint2 o = make_uint2(pack_bf16x2(f0, f1), pack_bf16x2(f2, f3));
+                // written by asm: a visible LDS store would make the compiler wait for every outstanding LDS-DMA and store first
+                asm volatile("ds_write_b64 %0, %1" ::"v"((uint32_t)(uintptr_t)(patch + r * PROWB + d * 4 * EB)), "v"(o) : "memory");
+            }
+        }
+    };
+    constexpr int NST = 8 * (MB / 2 + (MB & 1));             // output stores one wave issues for a full tile
 
     // Pipeline over this workgroup's tiles t0, t0+G, ...: while tile t is multiplied out of patch buffer `cur`, the raw
     // dwords of tile t+G are in flight; they are converted into the other buffer after the compute phase, and one barrier
     // per tile separates "buffer written by all waves" from "buffer read" (and the reads of two tiles ago from the rewrite).
     int tile = first_tile(gridDim.x, blockIdx.x);
     uint32_t raw[NIT];
-    load_raw(tile, raw);
-    __syncthreads();                                         // value table is complete
-    convert(raw, s_patch);
-    load_raw(tile + (int)gridDim.x, raw);
+    if constexpr (DMA) {
+        __syncthreads();                                     // (the value table is not used by this variant; keeps the prologue alike)
+        dma_raw(tile);
+        wait_vmcnt<0>();
+        convert_stage(s_patch);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // staging read, patch written
+        dma_raw(tile + (int)gridDim.x);
+    } else {
+        load_raw(tile, raw);
+        __syncthreads();                                     // value table is complete
+        convert(raw, s_patch);
+        load_raw(tile + (int)gridDim.x, raw);
+    }
     int cur = 0;
     for (; tile < p.n_tiles_n; tile += gridDim.x, cur ^= 1) {
         const int b = tile / tiles_per_img, tr = tile - b * tiles_per_img;
         const int ty0 = tr / tiles_x, tx0 = tr - ty0 * tiles_x;
         const int y0 = ty0 * kTH, x0 = tx0 * kTW;
         const char* patch = s_patch + cur * G::PATCHB;
-        __syncthreads();
+        if constexpr (DMA) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            __syncthreads();
+        }
         // ---- 8 blocks of 16 pixels per wave: rows 2*wave, 2*wave+1 x 4 column blocks ----
 #pragma unroll 2
         for (int q = 0; q < 8; ++q) {
@@ -216,29 +283,38 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const ConvParams p, c
                 }
             }
         }
-        convert(raw, s_patch + (cur ^ 1) * G::PATCHB);       // next tile's patch (all zeros past the last tile)
-        load_raw(tile + 2 * (int)gridDim.x, raw);
+        if constexpr (DMA) {
+            // the DMA of the next tile's raw dwords is older than this tile's output stores: a full tile issued exactly NST of them
+            const bool full = y0 + kTH <= Ho && x0 + kTW <= Wo;
+            if (full) wait_vmcnt<NST>(); else wait_vmcnt<0>();
+            convert_stage(s_patch + (cur ^ 1) * G::PATCHB);   // next tile's patch (all zeros past the last tile)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_raw(tile + 2 * (int)gridDim.x);
+        } else {
+            convert(raw, s_patch + (cur ^ 1) * G::PATCHB);   // next tile's patch (all zeros past the last tile)
+            load_raw(tile + 2 * (int)gridDim.x, raw);
+        }
     }
 }
 
-int g_stem_occ[2][kMaxMB + 1];                // resident workgroups per CU, 0 = not queried yet
+int g_stem_occ[4][kMaxMB + 1];                // resident workgroups per CU, 0 = not queried yet ([F32 + 2 * DMA])
 int g_stem_cus = 0;
 
 size_t stem_packed_bytes(bool f32, int mb) {
     return f32 ? (size_t)StemGeom<true>::KS * mb * 64 * 4 : (size_t)StemGeom<false>::KS * mb * 64 * 16;
 }
 
-template <bool F32, int MB>
+template <bool F32, int MB, bool DMA = false>
 int launch_stem(const ConvParams& p, const uint8_t* tiles, int tiles_x, int tiles_y, hipStream_t stream) {
-    auto fn = stem_conv_kernel<F32, MB>;
+    auto fn = stem_conv_kernel<F32, MB, DMA>;
     constexpr size_t lds = StemGeom<F32>::LDS;
-    if (!g_stem_occ[F32][MB]) {
+    if (!g_stem_occ[F32 + 2 * DMA][MB]) {
         AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int occ = 0;
         AQ_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)fn, 256, lds));
-        g_stem_occ[F32][MB] = occ > 0 ? occ : 1;
+        g_stem_occ[F32 + 2 * DMA][MB] = occ > 0 ? occ : 1;
     }
-    long long grid = (long long)g_stem_cus * g_stem_occ[F32][MB];
+    long long grid = (long long)g_stem_cus * g_stem_occ[F32 + 2 * DMA][MB];
     if (grid > p.n_tiles_n) grid = p.n_tiles_n;
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, stream, p, tiles, tiles_x, tiles_y);
     AQ_CHECK_HIP(hipGetLastError());
@@ -306,7 +382,14 @@ extern "C" int aq_stem_conv(const uint8_t* tiles_dev, void* out_dev, int out_ld,
     }
     const hipStream_t st = (hipStream_t)stream;
     const int mb = (cout + 15) / 16;
-#define AQ_STEM_CASE(M) case M: return f32 ? launch_stem<true, M>(p, tiles_dev, tiles_x, tiles_y, st) : launch_stem<false, M>(p, tiles_dev, tiles_x, tiles_y, st)
+    // DMA variant: bf16, every image row a whole number of dwords from a 4-byte aligned base (a dword is inside or outside the row)
+    const bool dma = !f32 && (W % 4) == 0 && ((uintptr_t)tiles_dev & 3) == 0 && getenv("AQ_STEM_NO_DMA") == nullptr;
+    if (dma) {
+        p.zero = aq_zero_page();
+        AQ_REQUIRE(p.zero, "stem_conv: zero page allocation failed");
+    }
+#define AQ_STEM_CASE(M) case M: return f32 ? launch_stem<true, M>(p, tiles_dev, tiles_x, tiles_y, st) \
+                                        : (dma ? launch_stem<false, M, true>(p, tiles_dev, tiles_x, tiles_y, st) : launch_stem<false, M>(p, tiles_dev, tiles_x, tiles_y, st))
     switch (mb) {
         AQ_STEM_CASE(1);
         AQ_STEM_CASE(2);

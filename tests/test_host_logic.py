@@ -136,3 +136,17 @@ def test_no_cpu_fallback(synth_ck):
         engine.nms(torch.zeros(1, 10, 10), 5)
     src = "".join(open(os.path.join(ROOT, "aquaculture_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "aquaculture_amd")) if f.endswith(".py"))
     assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_bf16_byte_normalisation_by_reciprocal_is_exact():
+    """The bf16 stem kernel converts uint8 pixels with v * (1/255) instead of v / 255 ([UPSTREAM detect.py: im.float() / 255]): after
+    round-to-nearest-even to bf16 the two agree for every byte value (in fp32 they differ for 126 of them, so fp32 mode keeps v / 255)."""
+    import numpy as np
+    v = np.arange(256, dtype=np.float32)
+    a = (v / np.float32(255.0)).astype(np.float32)
+    b = (v * np.float32(1.0 / 255.0)).astype(np.float32)
+
+    def bf16(x):
+        u = x.view(np.uint32).astype(np.uint64)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
+    assert np.array_equal(bf16(a), bf16(b)) and int((a != b).sum()) > 0
