@@ -444,10 +444,28 @@ __global__ __launch_bounds__(NW * 64) void bottleneck_kernel(const BtlParams p) 
                     char* o = p.out + ((long long)(b * H + y) * W + x) * p.out_ld_b + cbase * 2;
                     uint2 xr[MBW];
                     if (p.shortcut) {
+                        if constexpr (RESG) {
 #pragma unroll
-                        for (int m = 0; m < MBW; ++m) {
-                            if constexpr (RESG) xr[m] = xg[j][m];
-                            else xr[m] = *(const uint2*)(xc + boff[j] + m * 32);
+                            for (int m = 0; m < MBW; ++m) xr[m] = xg[j][m];
+                        } else {
+                            // Read by asm, wait included: for a VISIBLE read of the x patch the compiler cannot tell the buffer being
+                            // read from the one the next tile's LDS-DMA is filling and waits with vmcnt(0) -- which, vmcnt being in
+                            // order, also waits for the output store of the previous block: the four stores of a step were serialised.
+                            const uint32_t xa = (uint32_t)(uintptr_t)(xc + boff[j]);
+                            if constexpr (MBW == 1)
+                                asm volatile("ds_read_b64 %0, %1\ns_waitcnt lgkmcnt(0)" : "=&v"(xr[0]) : "v"(xa) : "memory");
+                            else if constexpr (MBW == 2)
+                                asm volatile("ds_read_b64 %0, %2\nds_read_b64 %1, %2 offset:32\ns_waitcnt lgkmcnt(0)"
+                                             : "=&v"(xr[0]), "=&v"(xr[1]) : "v"(xa) : "memory");
+                            else if constexpr (MBW == 3)
+                                asm volatile("ds_read_b64 %0, %3\nds_read_b64 %1, %3 offset:32\nds_read_b64 %2, %3 offset:64\ns_waitcnt lgkmcnt(0)"
+                                             : "=&v"(xr[0]), "=&v"(xr[1]), "=&v"(xr[2]) : "v"(xa) : "memory");
+                            else {
+                                static_assert(MBW == 4, "shortcut read");
+                                asm volatile("ds_read_b64 %0, %4\nds_read_b64 %1, %4 offset:32\nds_read_b64 %2, %4 offset:64\n"
+                                             "ds_read_b64 %3, %4 offset:96\ns_waitcnt lgkmcnt(0)"
+                                             : "=&v"(xr[0]), "=&v"(xr[1]), "=&v"(xr[2]), "=&v"(xr[3]) : "v"(xa) : "memory");
+                            }
                         }
                     }
 #pragma unroll
