@@ -330,8 +330,13 @@ __global__ __launch_bounds__(NW * 64) void bottleneck_kernel(const BtlParams p) 
                         for (int j = 0; j < 4; ++j) {
                             const int y = y0 + ty + j / G::NBR, x = x0 + 16 * (j % G::NBR) + l15;
                             const char* src = p.in + ((long long)(b * H + y) * W + x) * p.in_ld_b + cbase * 2;
+                            // Loaded by asm: for a load the compiler can see it puts s_waitcnt vmcnt(0) in front of the MFMA loop below
+                            // (twice), which also waits for the next patch's LDS-DMA issued there -- even in launches without a
+                            // shortcut, because the wait sits after the join.  The hand-written wait is after the MFMA loop.
+                            const char* ok_src = (y < H && x < W) ? src : (const char*)p.zero;
 #pragma unroll
-                            for (int m = 0; m < MBW; ++m) xg[j][m] = (y < H && x < W) ? *(const uint2*)(src + m * 32) : make_uint2(0, 0);
+                            for (int m = 0; m < MBW; ++m)
+                                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(xg[j][m]) : "v"(ok_src + ((y < H && x < W) ? m * 32 : 0)) : "memory");
                         }
                     }
                 }
@@ -433,6 +438,12 @@ __global__ __launch_bounds__(NW * 64) void bottleneck_kernel(const BtlParams p) 
                 }
                 if constexpr (STAMP) asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[3][MBW - 1][3]));
                 stamp(6);
+                if constexpr (RESG) {
+                    if (p.shortcut) {       // the shortcut values (and, vmcnt being in order, the DMA issued during the MFMA loop) have landed
+                        static_assert(!RESG || MBW == 1, "shortcut registers of the RESG shape");
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xg[0][0]), "+v"(xg[1][0]), "+v"(xg[2][0]), "+v"(xg[3][0])::"memory");
+                    }
+                }
                 f32x4 b2v[MBW];
 #pragma unroll
                 for (int m = 0; m < MBW; ++m) b2v[m] = *(const f32x4*)(s_b + G::C + cbase + m * 16);

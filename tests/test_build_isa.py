@@ -1,0 +1,67 @@
+"""Build-time check of the one place where registers are loaded by inline asm and waited for by hand.
+
+`bottleneck_kernel` (C = 96 shape) re-reads the shortcut from global memory with `asm volatile("global_load_dwordx2 ...")` so that the
+compiler does not put `s_waitcnt vmcnt(0)` in front of the MFMA loop (that wait also drained the next patch's LDS-DMA).  The price: the
+compiler does not know those registers are in flight until the hand-written `s_waitcnt vmcnt(0)` after the loop.  This test compiles the
+file to gfx950 assembly (no GPU needed) and checks that NO instruction between the loads and that wait reads or writes them -- a
+register-allocator copy or spill there would read stale data.  It also checks that the compiler inserted no vmcnt(0) of its own in the
+steady-state loop of that kernel."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _regs(text):
+    r = set()
+    for m in re.finditer(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]", text):
+        r |= {int(m.group(1))} if m.group(1) else set(range(int(m.group(2)), int(m.group(3)) + 1))
+    return r
+
+
+@pytest.fixture(scope="module")
+def bottleneck_asm(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "bottleneck.s"
+    src = os.path.join(ROOT, "aquaculture_amd", "csrc", "bottleneck.hip")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{os.path.dirname(src)}", "--cuda-device-only",
+                    "-S", src, "-o", str(out)], check=True, capture_output=True)
+    return out.read_text()
+
+
+def test_asm_loaded_shortcut_registers_are_untouched_until_the_wait(bottleneck_asm):
+    kernels = re.split(r"\n(?=_ZN\S*bottleneck_kernel\S*:\s*; @)", bottleneck_asm)[1:]
+    checked = 0
+    for k in kernels:
+        name = k.split(":", 1)[0]
+        if name.endswith("ELb1EEEvNS_9BtlParamsE"):
+            continue                                        # stamped diagnostic builds (tools/stamp_conv.py): timing probes, not the product
+        body = k.split("s_endpgm")[0].split("\n")
+        loads = [i for i, l in enumerate(body) if "global_load_dwordx2" in l and "ASMSTART" in body[i - 1]]
+        if not loads:
+            continue                                        # shapes that read the shortcut from LDS
+        loaded = set()
+        for i in loads:
+            loaded |= _regs(body[i].split(",")[0])
+        wait = next(i for i, l in enumerate(body) if i > loads[-1] and "s_waitcnt vmcnt(0)" in l and "ASMSTART" in body[i - 1])
+        for i in range(loads[0] + 1, wait):
+            line = body[i].split(";")[0]
+            if i in loads:
+                assert not (_regs(line.split(",", 1)[1]) & loaded - _regs(line.split(",")[0])), body[i]   # address regs are not in-flight ones
+                continue
+            assert not (_regs(line) & loaded), f"{body[i].strip()} touches an in-flight register"
+        # no compiler-inserted vmcnt(0) inside the loops of this kernel (the hand-written ones sit between ASMSTART / ASMEND)
+        in_loop = False
+        for i, l in enumerate(body):
+            if l.startswith(".LBB"):
+                in_loop = "Loop" in l
+            if in_loop and "s_waitcnt" in l and "vmcnt(0)" in l:
+                assert "ASMSTART" in body[i - 1], f"compiler-inserted {l.strip()} in a loop"
+        checked += 1
+    assert checked >= 1
