@@ -69,17 +69,27 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, f32x16 (&acc
                                                                   : make_uint4(0, 0, 0, 0);
                 }
     }
+    // LDS reads of this function are inline asm with their own lgkmcnt wait.  For a VISIBLE LDS read the compiler, which cannot tell
+    // the staging / bias area from the buffers an LDS-DMA may still be filling, emits s_waitcnt vmcnt(0) -- and vmcnt being in order,
+    // that waited for the output stores of the previous block as well: the stores of an epilogue went out one block at a time.
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int pbase = pwave + j * 32;
+    for (int i = 0; i < TM; ++i) {
+        const int cblk = cwave + i * 32;
+        f32x4 bias4[4];                                        // the block row's bias, rows 8 g + 4 h .. + 3 (read once per i, not per (i, j))
+        {
+            const uint32_t ba = (uint32_t)(uintptr_t)(sbias + cblk + 4 * h);
+            asm volatile("ds_read_b128 %0, %4\nds_read_b128 %1, %4 offset:32\nds_read_b128 %2, %4 offset:64\nds_read_b128 %3, %4 offset:96\n"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(bias4[0]), "=&v"(bias4[1]), "=&v"(bias4[2]), "=&v"(bias4[3]) : "v"(ba) : "memory");
+        }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int cblk = cwave + i * 32;
+        for (int j = 0; j < TN; ++j) {
+            const int pbase = pwave + j * 32;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cl = 8 * g + 4 * h;
                 if (cblk + 8 * g >= p.cout) continue;          // padding rows of the last M block: nothing to compute
-                const f32x4 bv = *(const f32x4*)(sbias + cblk + cl);
+                const f32x4 bv = bias4[g];
                 f32x4 v;
                 if constexpr (F32) {
 #pragma unroll
@@ -106,12 +116,19 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, f32x16 (&acc
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            f32x4 lohi[2][2];
+            {
+                const uint32_t sa = (uint32_t)(uintptr_t)(stg + pix * kStgRow + ch * 32);
+                asm volatile("ds_read_b128 %0, %4\nds_read_b128 %1, %4 offset:16\nds_read_b128 %2, %4 offset:%5\nds_read_b128 %3, %4 offset:%6\n"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(lohi[0][0]), "=&v"(lohi[0][1]), "=&v"(lohi[1][0]), "=&v"(lohi[1][1])
+                             : "v"(sa), "n"(16 * kStgRow), "n"(16 * kStgRow + 16) : "memory");
+            }
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int px = pix + 16 * it;
                 const int P = pbase + px, c0 = cblk + ch * 8;
-                const f32x4 lo = *(const f32x4*)(stg + px * kStgRow + ch * 32);
-                const f32x4 hi = *(const f32x4*)(stg + px * kStgRow + ch * 32 + 16);
+                const f32x4 lo = lohi[it][0], hi = lohi[it][1];
                 if (P < p.npix && c0 < p.cout) {
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     char* orow = p.out + (long long)P * p.out_ld_b;
