@@ -157,7 +157,7 @@ def main():
     # compact text table
     def g(r, k):
         return r.get(k, 0.0)
-    lines = ["op name                     us     TF/s  mfma%  valu%  lds%  wait%  waitinst% | VALU/MFMA inst  ldsconf% | rdMB  wrMB"]
+    lines = ["op name                     us     TF/s  mfma%  valu%  lds%  wait%  waitinst% | VALU/MFMA inst  ldsconf% | rdMB  wrMB   HBM TB/s"]
     for r in rows:
         dur = g(r, "dur_ns_sq1") or g(r, "dur_ns_sq2") or g(r, "dur_ns_fetch")
         if not dur:
@@ -165,14 +165,15 @@ def main():
         wc = g(r, "SQ_WAVE_CYCLES") or 1.0
         busy = g(r, "SQ_BUSY_CYCLES") or 1.0
         mf = g(r, "SQ_INSTS_MFMA") or 0.0
-        line = "%3d %-22s %7.1f %7.1f %6.1f %6.1f %5.1f %6.1f %9.1f | %7.1f %8.0f %7.1f | %6.1f %6.1f" % (
+        line = "%3d %-22s %7.1f %7.1f %6.1f %6.1f %5.1f %6.1f %9.1f | %7.1f %8.0f %7.1f | %6.1f %6.1f %8.2f" % (
             r["op"], r["name"][:22], dur / 1e3, r["flops"] / max(dur, 1) / 1e3,
             100 * g(r, "SQ_VALU_MFMA_BUSY_CYCLES") / (busy * 4 if busy else 1),
             100 * g(r, "SQ_ACTIVE_INST_VALU") / wc, 100 * g(r, "SQ_ACTIVE_INST_LDS") / wc, 100 * g(r, "SQ_WAIT_ANY") / wc,
             100 * g(r, "SQ_WAIT_INST_ANY") / wc,
             g(r, "SQ_INSTS_VALU") / mf if mf else 0.0, mf,
             100 * g(r, "SQ_LDS_BANK_CONFLICT") / max(g(r, "SQ_LDS_IDX_ACTIVE"), 1.0),
-            2 * g(r, "FETCH_SIZE") / 1024, g(r, "WRITE_SIZE") / 1024)
+            2 * g(r, "FETCH_SIZE") / 1024, g(r, "WRITE_SIZE") / 1024,
+            (2 * g(r, "FETCH_SIZE") + g(r, "WRITE_SIZE")) * 1024 / max(dur, 1) / 1e3)   # bytes / ns = GB/s; / 1e3 = TB/s
         lines.append(line)
     txt = "\n".join(lines)
     with open(os.path.join(a.out, "per_op.txt"), "w") as f:
