@@ -113,3 +113,21 @@ def test_mapped_scene_reads_the_same_bytes(tmp_path):
     raw = open(tmp_path / "plain.tif", "rb").read()
     open(tmp_path / "cut.tif", "wb").write(raw[: len(raw) // 2])
     assert scenes._mapped_strips(str(tmp_path / "cut.tif")) is None
+
+
+def test_tile_grid_properties_hold_for_arbitrary_sizes():
+    """Property form of the grid contract (hypothesis): the tiles partition the raster exactly once, come in the reference's order
+    (x outer, y inner), no tile is larger than the tile size and only the last row / column is cut short."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(1, 9000), st.integers(1, 9000), st.sampled_from([256, 640, 1000, 1024]))
+    def check(w, h, ts):
+        g = scenes.tile_grid(w, h, ts)
+        assert g == _reference_loop(w, h, ts)
+        assert sum(tw * th for _, _, tw, th in g) == w * h and len(set((x, y) for x, y, _, _ in g)) == len(g)
+        assert g == sorted(g, key=lambda t: (t[0], t[1]))
+        for x, y, tw, th in g:
+            assert 0 < tw <= ts and 0 < th <= ts and x % ts == 0 and y % ts == 0
+            assert (tw == ts or x + tw == w) and (th == ts or y + th == h)
+    check()
