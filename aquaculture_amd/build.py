@@ -25,6 +25,7 @@ SOURCES = [
     ("bottleneck.hip", []),
     ("downblock.hip", []),
     ("conv1x1_direct.hip", []),
+    ("conv3x3_pl.hip", []),
     ("pointwise.hip", []),
     ("detect_nms.hip", ["-ffp-contract=off"]),   # bit-level parity with the oracle's fp32 op order
     ("engine.cpp", ["-x", "hip"]),

@@ -1,0 +1,454 @@
+// 3x3 / stride 1 / pad 1 convolution, bf16, for the wide Bottleneck layers (Cin = Cout = 192, 384 in yolov5m), gfx950.
+//
+// Same operation as conv3x3_halo_kernel (out = (res +) SiLU(conv(x, W') + b'), NHWC in and out;
+// [UPSTREAM models/common.py Bottleneck.cv2 / Conv.forward_fuse], reached through reference README.md:77), rebuilt around
+// what round 1's ablation found: the per-(tap, chunk) workgroup barrier, the per-step address arithmetic and the epilogue
+// did not overlap with the MFMAs.  Structure:
+//
+//   * 4 waves, one per SIMD, the whole 512-register file each.  The waves split M: wave w owns output channels
+//     [48 w, 48 w + 48) of a 192-row M tile for ALL pixels of the tile (NB blocks of 16 pixels), on
+//     v_mfma_f32_16x16x32_bf16 (3 x NB accumulators).
+//   * WEIGHTS NEVER TOUCH LDS: they are packed on the host in MFMA A-fragment order, one contiguous 6 KB stream per
+//     (wave, tap-step), and each wave loads its own fragments straight from L2 into registers two tap-steps ahead
+//     (no sharing between waves, so nothing to stage).
+//   * LDS holds only the INPUT REGION of the pixel tile, slot-major: for a 64-channel chunk, 8 planes (one per 16-byte
+//     channel group) of 384 region rows x 16 B.  16 lanes reading 16 consecutive pixels of one plane hit 256 contiguous
+//     bytes, so every ds_read_b128 is conflict-free for every tap shift WITHOUT a swizzle, and tap, k-step and pixel
+//     block are plain address offsets.  Region rows are PADDED pixel coordinates: one zero pixel after every image row
+//     and one zero row after every image, so a tap that falls outside the image reads zeros with no mask.  The padding
+//     exists only in LDS: the LDS-DMA's per-lane source address is the NHWC pixel (or a zero page).
+//   * three chunk buffers form a ring: while chunk g is computed, chunk g + 2 (possibly of the NEXT tile) is loading.
+//     ONE workgroup barrier per chunk (9 taps x 2 k-steps x 3 NB MFMAs per wave), not per (tap, chunk).
+//   * every vector-memory operation of the loop (LDS-DMA, weight loads, residual loads, output stores) is inline asm
+//     with hand-counted s_waitcnt vmcnt(N): the compiler never sees them, so it never drains them (round 1's vmcnt(0)
+//     findings); fragment reads and MFMAs are ordinary code that it schedules and pads for hazards.
+#include "conv_device.h"
+#include <type_traits>
+
+using namespace aqdev;
+
+namespace {
+
+constexpr int PL_ROWS = 384;                 // region rows per plane: 6 LDS-DMA groups of 64 rows
+constexpr int PL_PS = PL_ROWS * 16;          // plane stride (a multiple of 256 B: keeps the 16-lane groups on distinct banks)
+constexpr int PL_CHUNK = 8 * PL_PS;          // one 64-channel chunk of the region
+constexpr int PL_BIAS = 3 * PL_CHUNK;        // bias follows the three ring buffers
+constexpr int PL_BM = 192;                   // M tile: 4 waves x 3 blocks of 16 rows
+constexpr int PL_STEP_B = 6 * 1024;          // weight bytes per (wave, tap-step): 2 k-steps x 3 M blocks x 1 KB
+
+struct PlParams {
+    const char* in;            // first channel of the input slice
+    long long in_sp, in_ss;    // byte strides: per pixel, per 16-byte channel group (NHWC: row length, 16)
+    char* out;
+    const char* res;
+    const char* w;             // aq_pack_conv3x3_pl image
+    const float* bias;
+    const char* zero;          // >= 16 zero bytes
+    int out_ld_b, res_ld_b;
+    int B, H, W, npix, cout, act;
+    int CC;                    // 64-channel chunks (Cin / 64)
+    int n_mt, ntiles;
+    float inv_hw, inv_w, inv_hpwp, inv_wp;
+};
+
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N - 1, so every register-array index is a constant
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_impl(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>());
+        static_for_impl<I + 1, N>(f);
+    }
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<0, N>(f); }
+
+__device__ __forceinline__ void pl_dma16(const char* gsrc, unsigned lds_dst) {
+    // LDS-DMA the compiler does not see: 16 B per lane from a per-lane address to lds_dst + lane * 16
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst));
+}
+template <int OFF>
+__device__ __forceinline__ void pl_ldw(bf16x8& d, unsigned voff, const char* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
+}
+__device__ __forceinline__ void pl_ld8(u32x2& d, const char* addr) {
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(addr));
+}
+__device__ __forceinline__ void pl_st8(char* addr, u32x2 v, unsigned long long mask) {
+    // always issued (vmcnt bookkeeping is by count); lanes outside `mask` are switched off
+    unsigned long long save;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx2 %2, %3, off\n\ts_nop 0\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
+}
+// All but the wave's N youngest vector-memory operations are done.  The wait itself names no register, so that a wait chosen at run
+// time (two immediates behind a wave-uniform branch) does not make the compiler copy registers where the paths merge; pl_tie_a after
+// the merge is what orders the users of the six A fragments behind it (volatile asm statements keep their order).
+template <int N>
+__device__ __forceinline__ void pl_wait() {
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
+}
+__device__ __forceinline__ void pl_tie_a(bf16x8 (&a)[6]) {
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]));
+}
+template <int I, int CNT>
+__device__ __forceinline__ void pl_tie(u32x2 (&r)[CNT]) {
+    if constexpr (I < CNT) {
+        asm volatile("" : "+v"(r[I]));
+        pl_tie<I + 1, CNT>(r);
+    }
+}
+template <int N, int CNT>
+__device__ __forceinline__ void pl_wait_r(u32x2 (&r)[CNT]) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
+    pl_tie<0, CNT>(r);
+}
+
+template <int NB, bool RES>
+__global__ __launch_bounds__(256, 1) void conv3x3_pl_kernel(const PlParams p) {
+    constexpr int BN = NB * 16;
+    constexpr int PD = 5;                        // B fragments in flight ahead of their MFMAs
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q = lane >> 4;
+    float* sbias = (float*)(smem + PL_BIAS);
+    const int G = gridDim.x;
+    int tile = first_tile(G, blockIdx.x);
+    if (tile >= p.ntiles) return;
+    for (int i = tid; i < p.cout; i += 256) sbias[i] = p.bias[i];
+
+    const int HW = p.H * p.W, Wp = p.W + 1, HpWp = (p.H + 1) * Wp, lead = p.W + 2;
+    const unsigned smem_base = (unsigned)(uintptr_t)smem;
+    const long long zoff = p.zero - p.in;        // the zero page as an offset from the input (a select between offsets, not a branch)
+
+    // pixel index -> padded coordinate (one zero pixel after each image row, one zero row after each image, `lead` zeros in front)
+    auto pp_of = [&](int P) -> int {
+        // reciprocal multiply + one correction step, branch-free (exact for P < 2^23)
+        int b = (int)((float)P * p.inv_hw);
+        int rem = P - b * HW;
+        const int lo = rem < 0, hi = rem >= HW;
+        b += hi - lo; rem += (lo - hi) * HW;
+        int y = (int)((float)rem * p.inv_w);
+        const int x = rem - y * p.W;
+        y += (int)(x >= p.W) - (int)(x < 0);
+        return P + lead + b * (p.H + p.W + 1) + y;
+    };
+    // padded coordinate -> pixel index, or -1 for padding / outside the batch
+    auto unpad = [&](int Pp) -> int {
+        const int Pq = Pp - lead;
+        int b = (int)((float)Pq * p.inv_hpwp);
+        int rem = Pq - b * HpWp;
+        const int lo = rem < 0, hi = rem >= HpWp;
+        b += hi - lo; rem += (lo - hi) * HpWp;
+        int y = (int)((float)rem * p.inv_wp);
+        int x = rem - y * Wp;
+        const int xl = x < 0, xh = x >= Wp;
+        y += xh - xl; x += (xl - xh) * Wp;
+        const bool ok = (Pq >= 0) & (b < p.B) & (x < p.W) & (y < p.H);
+        return ok ? b * HW + y * p.W + x : -1;
+    };
+
+    int prow[6];                  // source pixel of region row 64 k + lane, for the tile the LDS-DMA is currently loading
+    auto region_rows = [&](int t_) {
+        const int rs = pp_of((t_ / p.n_mt) * BN) - lead;
+        static_for<6>([&](auto K) { prow[K] = unpad(rs + 64 * K + lane); });
+    };
+    auto no_rows = [&]() { static_for<6>([&](auto K) { prow[K] = -1; }); };
+    // the two LDS-DMA instructions of slot k (0..5) of a chunk: planes 2 w and 2 w + 1, rows 64 k .. 64 k + 63
+    auto dma_pair = [&](auto K, int cd, int bd) {
+        const int P = prow[K];
+        static_for<2>([&](auto S2) {
+            const int s = 2 * wave + S2;
+            const long long goff = (long long)(8 * cd + s) * p.in_ss + (long long)max(P, 0) * p.in_sp;
+            const long long m = (long long)(P >> 31);                 // all ones for a padding row: take the zero page
+            pl_dma16(p.in + ((goff & ~m) | (zoff & m)), smem_base + bd * PL_CHUNK + s * PL_PS + K * 1024);
+        });
+    };
+    const unsigned aoff = lane * 16;
+    auto a_base = [&](int t_, int c) -> const char* {     // weight stream of (this wave, M tile of tile t_, chunk c, tap 0), biased by 3 KB
+        const int mt = t_ % p.n_mt;
+        return p.w + ((long long)((mt * 4 + wave) * p.CC + c) * 9) * PL_STEP_B + 3072;
+    };
+    auto load_a = [&](bf16x8 (&a)[6], const char* sb) {
+        pl_ldw<-3072>(a[0], aoff, sb); pl_ldw<-2048>(a[1], aoff, sb); pl_ldw<-1024>(a[2], aoff, sb);
+        pl_ldw<0>(a[3], aoff, sb); pl_ldw<1024>(a[4], aoff, sb); pl_ldw<2048>(a[5], aoff, sb);
+    };
+
+    bf16x8 A0[6], A1[6], A2[6];   // weight fragments of tap-steps T, T + 1, T + 2 (set = tap % 3)
+    f32x4 acc[3][NB];
+    int addr[NB];                 // byte offset of this lane's B fragment for (pixel block j, tap (-1,-1), k-step 0) in ring buffer 0
+    u32x2 rA[NB], rB[NB];         // residual batches (one M block x NB pixel blocks each)
+
+    // ---------------- prologue: chunks 0 and 1 of the first tile, weights of tap-steps 0 and 1 ----------------
+    region_rows(tile);
+    static_for<6>([&](auto K) { dma_pair(K, 0, 0); });
+    load_a(A0, a_base(tile, 0));
+    load_a(A1, a_base(tile, 0) + PL_STEP_B);
+    static_for<6>([&](auto K) { dma_pair(K, 1, 1); });
+    bool first = true;
+    int buf = 0;                  // ring buffer of the chunk being computed
+
+    while (true) {
+        const int nt = tile / p.n_mt, mt = tile - nt * p.n_mt;
+        const int n0 = nt * BN;
+        const int next_tile = tile + G;
+        const bool has_next = next_tile < p.ntiles;
+        const int cbase = mt * PL_BM + wave * 48;
+        {
+            const int rs = pp_of(n0) - lead;
+            static_for<NB>([&](auto J) {
+                const int P = min(n0 + 16 * J + l15, p.npix - 1);
+                addr[J] = q * PL_PS + (pp_of(P) - rs - Wp - 1) * 16;
+            });
+        }
+        static_for<3 * NB>([&](auto IJ) { acc[IJ / NB][IJ % NB] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+
+        for (int c = 0; c < p.CC; ++c) {
+            const bool lastc = c + 1 == p.CC;
+            // chunk c has landed in every wave's view (own DMA: covered by the counted waits of the previous chunk, or the
+            // explicit one below for the very first chunk; other waves': the barrier), and every wave is done with the
+            // buffer that chunk c + 2 will overwrite
+            if (first && c == 0) wait_vmcnt<12>();       // all but chunk 1's LDS-DMA: chunk 0 and the weights of taps 0 and 1 are in
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // target of this chunk's LDS-DMA: chunk c + 2 of this tile, or chunk c + 2 - CC of the next one
+            int cd = c + 2, bd = buf + 2;
+            if (bd >= 3) bd -= 3;
+            if (cd >= p.CC) {
+                cd -= p.CC;
+                if (cd == 0) { if (has_next) region_rows(next_tile); else no_rows(); }
+            }
+            const char* a_cur = a_base(tile, c);
+            const char* a_nxt = !lastc ? a_base(tile, c + 1) : a_base(has_next ? next_tile : tile, 0);
+            const int bufoff = buf * PL_CHUNK;
+            if constexpr (RES) {
+                // residual batch 0, fetched at the top of EVERY chunk so that the wait counts of the chunk body are constants (the
+                // last chunk's copy is the one the epilogue reads; pl_keep below holds the registers until every copy has landed)
+                static_for<NB>([&](auto J) {
+                    const int P = min(n0 + 16 * J + l15, p.npix - 1);
+                    pl_ld8(rA[J], p.res + (long long)P * p.res_ld_b + (cbase + 4 * q) * 2);
+                });
+            }
+            // One stream of 18 NB elements per chunk: element n = (tap t, k-step ks, pixel block j) is ONE B fragment read from the
+            // region and three MFMAs (the wave's three M blocks).  The read runs PD elements ahead of its MFMAs through a small
+            // rotating set of registers; all indices are compile-time constants (the chunk body is fully unrolled).
+            constexpr int NE = 18 * NB;
+            bf16x8 bq[PD + 1];
+            int so[9];                  // ring buffer + tap shift; opaque to the optimiser so that addr[j] + so[t] is not pre-added per tap and tile (117 registers)
+            static_for<9>([&](auto T) {
+                int v = bufoff + ((T / 3) * Wp + (T % 3)) * 16;
+                asm volatile("" : "+s"(v));
+                so[T] = v;
+            });
+            auto b_read = [&](auto N_) -> bf16x8 {
+                constexpr int n = N_, h = n / NB, j = n - h * NB, t = h >> 1, ks = h & 1;
+                return *(const bf16x8*)(smem + (addr[j] + so[t]) + ks * 4 * PL_PS);
+            };
+            static_for<PD>([&](auto N_) { bq[N_] = b_read(N_); });
+            static_for<NE>([&](auto N_) {
+                constexpr int n = N_, h = n / NB, j = n - h * NB, t = h >> 1, ks = h & 1;
+                if constexpr (n + PD < NE) bq[(n + PD) % (PD + 1)] = b_read(std::integral_constant<int, n + PD>());
+                bf16x8 (&Acur)[6] = t % 3 == 0 ? A0 : (t % 3 == 1 ? A1 : A2);
+                if constexpr (j == 0 && ks == 0) {
+                    // ---- issue slot: LDS-DMA pair, residual batch 0 (last tap of the tile), weights of tap-step T + 2 ----
+                    if constexpr (t < 6) dma_pair(std::integral_constant<int, (t < 6 ? t : 0)>(), cd, bd);
+                    bf16x8 (&Anew)[6] = (t + 2) % 3 == 0 ? A0 : ((t + 2) % 3 == 1 ? A1 : A2);
+                    load_a(Anew, t + 2 < 9 ? a_cur + (t + 2) * PL_STEP_B : a_nxt + (t + 2 - 9) * PL_STEP_B);
+                    // ---- weights of this tap-step: younger operations = slot T - 1 and slot T (+ the epilogue's after a tile seam) ----
+                    // younger operations: slot T - 1 and slot T (6 weight loads + 2 LDS-DMA in taps 0..5 each) and, for taps 0 and 1,
+                    // the residual batch issued at the top of the chunk.  No count depends on a run-time condition: after a tile seam
+                    // the epilogue's loads and stores are younger too, and ignoring them only waits for a few of those stores.
+                    constexpr int kStd = 12 + (t >= 1 && t <= 6 ? 2 : 0) + (t < 6 ? 2 : 0) + (RES && t < 2 ? NB : 0);
+                    pl_wait<kStd>();
+                    pl_tie_a(Acur);
+                }
+                static_for<3>([&](auto I) {
+                    acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Acur[3 * ks + I], bq[n % (PD + 1)], acc[I][j], 0, 0, 0);
+                });
+                __builtin_amdgcn_sched_barrier(0);      // keep this order: the read of element n + PD, the issue slot, three MFMAs
+            });
+            if constexpr (RES) pl_tie<0, NB>(rA);      // landed by now (older than the last tap-steps' counted waits), and never free in between
+            buf = buf == 2 ? 0 : buf + 1;
+            first = false;
+        }
+
+        // ---------------- epilogue: +bias, SiLU, (+residual), bf16, 8-byte stores; one M block (NB pixel blocks) at a time ----------------
+        unsigned long long omask[NB];
+        static_for<NB>([&](auto J) { omask[J] = __ballot(n0 + 16 * J + l15 < p.npix); });
+        static_for<3>([&](auto I) {
+            constexpr int i = I;
+            u32x2 (&rcur)[NB] = (i & 1) ? rB : rA;
+            u32x2 (&rnxt)[NB] = (i & 1) ? rA : rB;
+            if constexpr (RES) {
+                if constexpr (i < 2) {
+                    static_for<NB>([&](auto J) {
+                        const int P = min(n0 + 16 * J + l15, p.npix - 1);
+                        pl_ld8(rnxt[J], p.res + (long long)P * p.res_ld_b + (cbase + 16 * (i + 1) + 4 * q) * 2);
+                    });
+                }
+                // batch 0 landed during the last chunk; younger than batch 1: the stores of block 0 + batch 2; than batch 2: the stores of block 1
+                if constexpr (i == 1) pl_wait_r<2 * NB, NB>(rcur);
+                else if constexpr (i == 2) pl_wait_r<NB, NB>(rcur);
+            }
+            const f32x4 bv = *(const f32x4*)(sbias + cbase + 16 * i + 4 * q);
+            static_for<NB>([&](auto J) {
+                f32x4 v = acc[i][J] + bv;
+                if (p.act) {
+                    const f32x4 t = v * -1.44269504f;
+                    f32x4 d = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]), __builtin_amdgcn_exp2f(t[3])};
+                    d = d + 1.0f;
+                    const f32x4 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
+                    v = v * r;
+                }
+                if constexpr (RES) {
+                    const u32x2 rv = rcur[J];
+                    v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
+                    v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
+                }
+                const u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                const int P = min(n0 + 16 * J + l15, p.npix - 1);
+                pl_st8(p.out + (long long)P * p.out_ld_b + (cbase + 16 * i + 4 * q) * 2, o, omask[J]);
+            });
+            __builtin_amdgcn_sched_barrier(0);          // one M block at a time: do not pull all 3 NB accumulators into VGPRs up front
+        });
+        if (!has_next) break;
+        tile = next_tile;
+    }
+    // the weight loads issued for a tile that does not exist must not outlive their registers: wait, THEN let the registers go
+    wait_vmcnt<0>();
+    pl_tie_a(A0); pl_tie_a(A1); pl_tie_a(A2);
+}
+
+struct PlKernel { int nb; void (*plain)(const PlParams); void (*res)(const PlParams); };
+#define PLK(NB) { NB, conv3x3_pl_kernel<NB, false>, conv3x3_pl_kernel<NB, true> }
+const PlKernel kPl[] = { PLK(13), PLK(10), PLK(7) };
+constexpr int kNumPl = sizeof(kPl) / sizeof(kPl[0]);
+bool g_pl_attr[64][kNumPl][2];
+int g_pl_cus[64];
+
+// widest run of padded coordinates any tile of bn pixels needs, halo included
+int pl_region_rows(int B, int H, int W, int bn) {
+    const long long npix = (long long)B * H * W;
+    auto pp = [&](long long P) { const long long b = P / (H * W), y = (P % (H * W)) / W; return P + b * (H + W + 1) + y; };
+    long long worst = 0;
+    for (long long n0 = 0; n0 < npix; n0 += bn) {
+        const long long n1 = (n0 + bn - 1 < npix - 1) ? n0 + bn - 1 : npix - 1;
+        const long long span = pp(n1) - pp(n0) + 1 + 2 * (W + 2);
+        if (span > worst) worst = span;
+    }
+    return (int)worst;
+}
+
+}  // namespace
+
+extern "C" int aq_conv3x3_pl_supported(int cin, int cout) {
+    return cin >= 128 && cin % 64 == 0 && cout % PL_BM == 0 && cout <= 3840;
+}
+
+// Packs fused fp32 weights KRSC (cout, 3, 3, cin) into per-wave A-fragment streams:
+// [M tile][wave][chunk][tap][k-step][M block i][lane] x 8 bf16, where lane (r = lane & 15, g = lane >> 4) holds output channel
+// 192 mt + 48 wave + 16 i + r and input channels 64 chunk + 32 kstep + 8 g .. + 7 of that tap.
+extern "C" int aq_pack_conv3x3_pl(const float* w_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream) {
+    AQ_REQUIRE(w_host && bytes && aq_conv3x3_pl_supported(cin, cout), "pack_conv3x3_pl: unsupported %d -> %d", cin, cout);
+    const int n_mt = cout / PL_BM, CC = cin / 64;
+    *bytes = (size_t)n_mt * 4 * CC * 9 * PL_STEP_B;
+    if (!packed_dev) return AQ_OK;
+    bf16_t* host = (bf16_t*)calloc(1, *bytes);
+    AQ_REQUIRE(host, "pack_conv3x3_pl: out of host memory");
+    bf16_t* dst = host;
+    for (int mt = 0; mt < n_mt; ++mt)
+        for (int wv = 0; wv < 4; ++wv)
+            for (int c = 0; c < CC; ++c)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int ks = 0; ks < 2; ++ks)
+                        for (int i = 0; i < 3; ++i)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int co = mt * PL_BM + wv * 48 + i * 16 + (lane & 15);
+                                const int ci = 64 * c + 32 * ks + 8 * (lane >> 4);
+                                const float* src = w_host + ((size_t)co * 9 + tap) * cin + ci;
+                                for (int e = 0; e < 8; ++e) *dst++ = aq_f2bf(src[e]);
+                            }
+    hipError_t e = hipMemcpyAsync(packed_dev, host, *bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    free(host);
+    AQ_CHECK_HIP(e);
+    return AQ_OK;
+}
+
+// Pixel blocks per tile for this geometry: the fewest (rounds x tile size) over the kernel's instantiations whose region fits
+static int pl_pick(int B, int H, int W, int n_mt, int cus, int* rows_out) {
+    const long long npix = (long long)B * H * W;
+    int best = -1;
+    double best_cost = 1e30;
+    for (int k = 0; k < kNumPl; ++k) {
+        const int bn = kPl[k].nb * 16;
+        const int rows = pl_region_rows(B, H, W, bn);
+        if (rows > PL_ROWS) continue;
+        const long long tiles = (npix + bn - 1) / bn * n_mt;
+        const long long rounds = (tiles + cus - 1) / cus;
+        const double cost = (double)rounds * (bn + 24);      // + a tile's fixed cost (epilogue, barriers) in pixel units
+        if (cost < best_cost) { best_cost = cost; best = k; if (rows_out) *rows_out = rows; }
+    }
+    return best;
+}
+
+// in: bf16 pixels, `cin` channels; element (pixel P, channel group g) at in + P * in_sp + g * in_ss bytes (NHWC: in_sp = row bytes,
+// in_ss = 16).  out / res: NHWC bf16 with row lengths out_ld / res_ld (elements), channel slices at *_choff.
+extern "C" int aq_conv3x3_pl(const void* in_dev, long long in_sp, long long in_ss, int cin, void* out_dev, int out_ld, int out_choff,
+                             int cout, const void* res_dev, int res_ld, int res_choff, const void* packed_w_dev, const float* bias_dev,
+                             int B, int H, int W, int act, void* stream) {
+    AQ_REQUIRE(in_dev && out_dev && packed_w_dev && bias_dev, "conv3x3_pl: null pointer");
+    AQ_REQUIRE(aq_conv3x3_pl_supported(cin, cout), "conv3x3_pl: unsupported %d -> %d", cin, cout);
+    AQ_REQUIRE(B > 0 && H > 0 && W > 0 && (long long)B * (H + 1) * (W + 1) + W + 2 < (1LL << 23), "conv3x3_pl: shape outside the fast-index range");
+    AQ_REQUIRE(in_sp % 16 == 0 && in_ss % 16 == 0 && out_ld % 4 == 0 && out_choff % 4 == 0 && out_choff + cout <= out_ld,
+               "conv3x3_pl: slices must be 8-byte aligned and inside their rows");
+    AQ_REQUIRE(!res_dev || (res_ld % 4 == 0 && res_choff % 4 == 0 && res_choff + cout <= res_ld), "conv3x3_pl: bad residual slice");
+    int dev = 0;
+    AQ_CHECK_HIP(hipGetDevice(&dev));
+    AQ_REQUIRE(dev >= 0 && dev < 64, "conv3x3_pl: device ordinal %d", dev);
+    if (g_pl_cus[dev] == 0) {
+        int cus = 256;
+        AQ_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        g_pl_cus[dev] = cus;
+    }
+    PlParams p{};
+    p.in = (const char*)in_dev; p.in_sp = in_sp; p.in_ss = in_ss;
+    p.out = (char*)out_dev + (size_t)out_choff * 2; p.out_ld_b = out_ld * 2;
+    if (res_dev) { p.res = (const char*)res_dev + (size_t)res_choff * 2; p.res_ld_b = res_ld * 2; }
+    p.w = (const char*)packed_w_dev; p.bias = bias_dev;
+    p.zero = aq_zero_page();
+    AQ_REQUIRE(p.zero, "conv3x3_pl: zero page allocation failed");
+    p.B = B; p.H = H; p.W = W; p.npix = B * H * W; p.cout = cout; p.act = act;
+    p.CC = cin / 64; p.n_mt = cout / PL_BM;
+    p.inv_hw = 1.0f / (float)(H * W); p.inv_w = 1.0f / (float)W;
+    p.inv_hpwp = 1.0f / (float)((H + 1) * (W + 1)); p.inv_wp = 1.0f / (float)(W + 1);
+    int rows = 0, k = pl_pick(B, H, W, p.n_mt, g_pl_cus[dev], &rows);
+    const char* forced = getenv("AQ_PL_NB");
+    if (forced && *forced) {
+        k = -1;
+        for (int i = 0; i < kNumPl; ++i)
+            if (kPl[i].nb == atoi(forced) && pl_region_rows(B, H, W, kPl[i].nb * 16) <= PL_ROWS) k = i;
+    }
+    AQ_REQUIRE(k >= 0, "conv3x3_pl: no tile of this kernel fits a %d-wide image in its %d region rows", W, PL_ROWS);
+    const int bn = kPl[k].nb * 16;
+    const long long ntiles = ((long long)p.npix + bn - 1) / bn * p.n_mt;
+    AQ_REQUIRE(ntiles > 0 && ntiles < (1LL << 30), "conv3x3_pl: bad tile count");
+    p.ntiles = (int)ntiles;
+    auto fn = res_dev ? kPl[k].res : kPl[k].plain;
+    const size_t lds = (size_t)PL_BIAS + (size_t)cout * 4;
+    AQ_REQUIRE(lds <= 160 * 1024, "conv3x3_pl: LDS");
+    if (!g_pl_attr[dev][k][res_dev ? 1 : 0]) {
+        AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        g_pl_attr[dev][k][res_dev ? 1 : 0] = true;
+    }
+    long long grid = g_pl_cus[dev];
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
+    AQ_CHECK_HIP(hipGetLastError());
+    return AQ_OK;
+}

@@ -22,7 +22,7 @@ void aq_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* aq_last_error(void) { return g_err; }
-extern "C" int aq_version(void) { return 3; }   // 2: fused stem / Bottleneck / down-block ops, direct 1x1 and 3x3/s2 candidates; 3: one-tile-per-workgroup grids
+extern "C" int aq_version(void) { return 4; }   // 2: fused stem / Bottleneck / down-block ops, direct 1x1 and 3x3/s2 candidates; 3: one-tile-per-workgroup grids
 
 namespace {
 
@@ -35,7 +35,7 @@ struct PackedW {
     float* bias = nullptr;  // [cout_rows]
     int kgroups = 0, kgroups_pad = 0, G = 0, cout_rows = 0;
     void* w_direct = nullptr;   // layers a direct kernel supports: its A-fragment image (csrc/conv1x1_direct.hip, csrc/downblock.hip)
-    int direct_cfg = -1;        // AQ_CONV_CFG_DIRECT1X1 / AQ_CONV_CFG_DIRECT3X3S2
+    int direct_cfg = -1;        // AQ_CONV_CFG_DIRECT1X1 / AQ_CONV_CFG_DIRECT3X3S2 / AQ_CONV_CFG_PL3X3
 };
 
 // Host-side packing: KRSC fp32 -> [cout_rows][kgroups_pad*16 B] of bf16 / fp32, zero padded.
@@ -160,6 +160,15 @@ int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStr
         return aq_conv3x3s2_direct(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
                                    tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
                                    op.src.channels, op.dst.channels, pw.w_direct, pw.bias, B, ps.h, ps.w, op.act, stream);
+    }
+    if (cfg == AQ_CONV_CFG_PL3X3) {
+        if (pw.direct_cfg != cfg) { aq_set_error("conv op %d has no planar 3x3 form", oi); return AQ_ERR_INVALID; }
+        const int ld = e->tensors[op.src.tensor].channels;
+        return aq_conv3x3_pl(tptr(e, ws, tiles, op.src.tensor) + (size_t)op.src.ch_off * 2, (long long)ld * 2, 16, op.src.channels,
+                             tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off, op.dst.channels,
+                             op.res.tensor >= 0 ? tptr(e, ws, tiles, op.res.tensor) : nullptr,
+                             op.res.tensor >= 0 ? e->tensors[op.res.tensor].channels : 0, op.res.ch_off,
+                             pw.w_direct, pw.bias, B, ps.h, ps.w, op.act, stream);
     }
     if (cfg == AQ_CONV_CFG_DIRECT1X1) {
         if (pw.direct_cfg != cfg) { aq_set_error("conv op %d has no direct 1x1 form", oi); return AQ_ERR_INVALID; }
@@ -447,6 +456,17 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
                 return fail(AQ_ERR_HIP);
             }
             pw.direct_cfg = AQ_CONV_CFG_DIRECT3X3S2;
+        }
+        if (d->precision == AQ_BF16 && op.k == 3 && op.stride == 1 && op.pad == 1 && e->tensors[op.dst.tensor].dtype == AQ_T_ACT &&
+            op.src.ch_off % 8 == 0 && aq_conv3x3_pl_supported(op.src.channels, op.dst.channels)) {
+            size_t nb = 0;
+            if (aq_pack_conv3x3_pl(op.weight, op.src.channels, op.dst.channels, nullptr, &nb, nullptr) != AQ_OK ||
+                hipMalloc(&pw.w_direct, nb) != hipSuccess ||
+                aq_pack_conv3x3_pl(op.weight, op.src.channels, op.dst.channels, pw.w_direct, &nb, nullptr) != AQ_OK) {
+                aq_set_error("engine_create: planar 3x3 weight upload failed (op %zu)", oi);
+                return fail(AQ_ERR_HIP);
+            }
+            pw.direct_cfg = AQ_CONV_CFG_PL3X3;
         }
         op.weight = nullptr; op.bias = nullptr;   // host pointers are not kept
     }

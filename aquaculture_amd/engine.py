@@ -64,7 +64,8 @@ EXPORTS = (
     "aq_engine_op_times", "aq_engine_num_ops", "aq_engine_set_conv_config", "aq_engine_autotune", "aq_engine_set_tuned_table",
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
     "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
-    "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct", "aq_preprocess_s2d", "aq_sppf_pool",
+    "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct",
+    "aq_conv3x3_pl_supported", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_letterbox_tiles_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
 
@@ -114,6 +115,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_conv3x3s2_direct_supported.argtypes = [i32, i32]
     lib.aq_pack_conv3x3s2_direct.argtypes = [C.POINTER(f32), i32, i32, vp, C.POINTER(sz), vp]
     lib.aq_conv3x3s2_direct.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp]
+    lib.aq_conv3x3_pl_supported.argtypes = [i32, i32]
+    lib.aq_pack_conv3x3_pl.argtypes = [C.POINTER(f32), i32, i32, vp, C.POINTER(sz), vp]
+    lib.aq_conv3x3_pl.argtypes = [vp, C.c_longlong, C.c_longlong, i32, vp, i32, i32, i32, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp]
     lib.aq_preprocess_s2d.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.aq_sppf_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.aq_upsample2x.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -558,7 +562,36 @@ def downblock_nhwc(x: torch.Tensor, wa_oihw: torch.Tensor, ba: torch.Tensor, wb_
 
 CONV_CFG_DIRECT1X1 = 1000   # AQ_CONV_CFG_DIRECT1X1
 CONV_CFG_DIRECT3X3S2 = 1001  # AQ_CONV_CFG_DIRECT3X3S2
+CONV_CFG_PL3X3 = 1002       # AQ_CONV_CFG_PL3X3
 CONV_CFG_ONE_TILE_PER_WG = 4096  # AQ_CONV_CFG_ONE_TILE_PER_WG (OR-ed into a tile configuration id)
+
+
+def conv3x3_pl_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, act: bool = True,
+                    residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 NHWC [B,H,W,cin] (may be a channel slice) -> (residual +) SiLU(conv3x3/s1/p1(x) + b) through aq_conv3x3_pl (tests).
+    ``out`` and ``residual`` may be channel slices of wider tensors; ``residual`` may be ``out`` itself (in-place shortcut)."""
+    _require_gpu()
+    lib = load_library()
+    assert x.dtype == torch.bfloat16 and x.stride(3) == 1
+    B, H, W, cin = x.shape
+    cout = w_oihw.shape[0]
+    ld = x.stride(2)
+    assert x.stride(1) == W * ld and x.stride(0) == H * W * ld, "x must be a channel slice of a dense NHWC tensor"
+    w = np.ascontiguousarray(w_oihw.permute(0, 2, 3, 1).float().cpu().numpy())
+    n = C.c_size_t()
+    wp = w.ctypes.data_as(C.POINTER(C.c_float))
+    _check(lib.aq_pack_conv3x3_pl(wp, cin, cout, None, C.byref(n), None))
+    wbuf = torch.empty(n.value, dtype=torch.uint8, device=x.device)
+    _check(lib.aq_pack_conv3x3_pl(wp, cin, cout, wbuf.data_ptr(), C.byref(n), _stream_ptr()))
+    bbuf = bias.float().to(x.device).contiguous()
+    if out is None:
+        out = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=x.device)
+    assert out.stride(3) == 1 and (residual is None or residual.stride(3) == 1)
+    _check(lib.aq_conv3x3_pl(x.data_ptr(), ld * 2, 16, cin, out.data_ptr(), out.stride(2), 0, cout,
+                             residual.data_ptr() if residual is not None else None, residual.stride(2) if residual is not None else 0, 0,
+                             wbuf.data_ptr(), bbuf.data_ptr(), B, H, W, int(act), _stream_ptr()))
+    torch.cuda.current_stream().synchronize()
+    return out
 
 
 def conv1x1_direct_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, act: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -194,6 +194,19 @@ int aq_conv3x3s2_direct_supported(int cin, int cout);
 int aq_pack_conv3x3s2_direct(const float* w_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream);
 int aq_conv3x3s2_direct(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff, int cin, int cout,
                         const void* packed_w_dev, const float* bias_dev, int B, int H, int W, int act, void* stream);
+/* 3x3 / stride 1 / pad 1 convolution of the wide Bottleneck layers (bf16; Cin a multiple of 64 and >= 128, Cout a multiple of 192:
+ * yolov5m's 192 -> 192 and 384 -> 384 [UPSTREAM models/common.py Bottleneck.cv2]): four waves, one per SIMD, weights streamed from L2
+ * straight into registers in MFMA-fragment order (aq_pack_conv3x3_pl), the input region staged in LDS as padded, slot-major planes
+ * (conflict-free fragment reads for every tap with no masks), a three-buffer chunk ring with ONE workgroup barrier per 64-channel chunk.
+ * Same operation as aq_conv2d with k = 3, stride = 1, pad = 1; the engine's autotuner times it per layer under AQ_CONV_CFG_PL3X3.
+ * in_dev: first channel of the input; element (pixel P, 16-byte channel group g) lives at in_dev + P * in_pixel_stride_b +
+ * g * in_group_stride_b (NHWC: row bytes and 16).  out / res: NHWC bf16 slices as in aq_conv2d (res may alias out: in-place shortcut). */
+#define AQ_CONV_CFG_PL3X3 1002
+int aq_conv3x3_pl_supported(int cin, int cout);
+int aq_pack_conv3x3_pl(const float* w_krsc_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream);
+int aq_conv3x3_pl(const void* in_dev, long long in_pixel_stride_b, long long in_group_stride_b, int cin,
+                  void* out_dev, int out_ld, int out_choff, int cout, const void* res_dev, int res_ld, int res_choff,
+                  const void* packed_w_dev, const float* bias_dev, int B, int H, int W, int act, void* stream);
 /* uint8 RGB NHWC -> 2x2 space-to-depth, 16 channels, value/255 ([UPSTREAM detect.py: im.float()/255]). */
 int aq_preprocess_s2d(const uint8_t* tiles_dev, void* out_dev, int B, int H, int W, int precision, void* stream);
 /* Letterbox on device (the real 1024x1024 tiles of reference src/load_data/tile_tifs.py:13 -> 640x640):

@@ -288,3 +288,66 @@ def test_direct_conv3x3s2_matches_reference(lib, shape):
         got = outw[..., 8:].float().cpu()
         assert (outw[..., :8] == 7.0).all()
         torch.testing.assert_close(got, ref.bfloat16().float(), rtol=2 ** -7, atol=4e-3)
+
+
+PL_CASES = [
+    # B, H, W, Cin, Cout, residual mode (None / "sep" / "inplace"), act
+    (3, 40, 40, 192, 192, "inplace", True),    # yolov5m model.6 Bottleneck.cv2: several tiles, batch seams inside tiles, in-place shortcut
+    (2, 20, 20, 384, 384, "sep", True),        # model.8: two M tiles, six chunks
+    (1, 9, 7, 192, 192, "sep", True),          # sub-tile ragged image: every border case inside one tile
+    (2, 13, 24, 128, 192, None, True),         # two chunks only (the ring wraps into the next tile at once)
+    (5, 20, 20, 192, 192, None, False),        # no activation, no shortcut
+    (2, 36, 44, 256, 384, "inplace", True),    # four chunks, two M tiles, odd sizes
+    (40, 40, 40, 192, 192, "inplace", True),   # more tiles than CUs: persistent workgroups walk several tiles (prefetch across the tile seam)
+    (70, 20, 20, 384, 384, "sep", True),       # the same with two M tiles
+]
+
+
+@pytest.mark.parametrize("case", PL_CASES)
+@pytest.mark.parametrize("nb", [13, 10, 7])
+def test_planar_conv3x3_matches_reference(lib, case, nb, monkeypatch):
+    """aq_conv3x3_pl vs F.conv2d on bf16-rounded operands; input, output and shortcut are channel slices of wider tensors; every
+    pixel-block count of the kernel, tiles that end inside images, at image seams and past the end of the batch."""
+    from aquaculture_amd import engine
+    B, H, W, cin, c, resmode, act = case
+    monkeypatch.setenv("AQ_PL_NB", str(nb))
+    g = torch.Generator().manual_seed(c * 7 + H * 3 + nb)
+    xw = (torch.randn(B, H, W, cin + 16, generator=g) * 0.8).bfloat16().cuda()
+    x = xw[..., 8:8 + cin]
+    w = torch.randn(c, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(c, generator=g) * 0.2
+    outw = torch.full((B, H, W, c + 24), 7.0, dtype=torch.bfloat16, device="cuda")
+    out = outw[..., 16:16 + c]
+    res = None
+    if resmode == "sep":
+        resw = (torch.randn(B, H, W, c + 8, generator=g)).bfloat16().cuda()
+        res = resw[..., 8:]
+    elif resmode == "inplace":
+        out.copy_((torch.randn(B, H, W, c, generator=g)).bfloat16())
+        res = out
+    res_host = res.float().cpu().clone() if res is not None else None
+    engine.conv3x3_pl_nhwc(x, w, b, act, residual=res, out=out)
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.bfloat16().float(), b, padding=1)
+    ref = (F.silu(ref) if act else ref).permute(0, 2, 3, 1)
+    if res_host is not None:
+        ref = ref + res_host
+    got = out.float().cpu()
+    assert (outw[..., :16] == 7.0).all() and (outw[..., 16 + c:] == 7.0).all(), "wrote outside its channel slice"
+    torch.testing.assert_close(got, ref.bfloat16().float(), rtol=2 ** -7, atol=4e-3)
+
+
+def test_planar_conv3x3_in_engine(lib, synth_ck):
+    """Forcing the planar kernel on every 3x3/s1 layer it supports leaves the head outputs within bf16 noise of the default engine."""
+    from aquaculture_amd import engine, tiles
+    x = torch.from_numpy(tiles.synthetic_batch([5, 7], 128)).cuda()
+    ref = engine.Engine(synth_ck, "bf16").forward_raw(x).float().cpu()
+    eng = engine.Engine(synth_ck, "bf16")
+    forced = 0
+    for i, o in enumerate(eng.plan.ops):
+        if o.kind == 1 and o.k == 3 and o.stride == 1 and eng.lib.aq_conv3x3_pl_supported(o.src.channels, o.dst.channels):
+            eng.set_conv_config(i, engine.CONV_CFG_PL3X3)
+            forced += 1
+    assert forced >= 14
+    got = eng.forward_raw(x).float().cpu()
+    err = (got - ref).abs()
+    assert float(err[..., 4].max()) < 0.1 and float(err[..., :4].mean()) < 1.0, (float(err[..., 4].max()), float(err[..., :4].mean()))

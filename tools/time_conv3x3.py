@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""A/B timing of the 3x3/s1 kernels on the real yolov5m layer shapes at batch 64: the planar kernel (aq_conv3x3_pl, every pixel-block
+count) against the implicit-GEMM / halo tile shapes (aq_conv2d with AQ_CONV_CFG).  Operands rotate through several buffers so
+nothing but the weights is cache resident.  Usage: python tools/time_conv3x3.py [--reps 20]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from aquaculture_amd import engine as E
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--old", default="21,30", help="aq_conv2d configs to time beside the planar kernel (21 = halo 192x256)")
+    a = ap.parse_args()
+    lib = E.load_library()
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    for (H, W, c) in ((40, 40, 192), (20, 20, 384)):
+        B = a.batch
+        g = torch.Generator().manual_seed(c)
+        w = torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5
+        b = torch.randn(c, generator=g) * 0.2
+        nbuf = 6
+        xs = [(torch.randn(B, H, W, c, generator=g) * 0.8).bfloat16().to(dev) for _ in range(nbuf)]
+        outs = [torch.randn(B, H, W, 2 * c, generator=g).bfloat16().to(dev) for _ in range(nbuf)]   # shortcut in place, slice of a concat buffer
+        wk = np.ascontiguousarray(w.permute(0, 2, 3, 1).float().numpy())
+        wp = wk.ctypes.data_as(C.POINTER(C.c_float))
+        n = C.c_size_t()
+        E._check(lib.aq_pack_conv3x3_pl(wp, c, c, None, C.byref(n), None))
+        wpl = torch.empty(n.value, dtype=torch.uint8, device=dev)
+        E._check(lib.aq_pack_conv3x3_pl(wp, c, c, wpl.data_ptr(), C.byref(n), st))
+        wold = E.pack_conv_weights(w, "bf16", dev)
+        bb = torch.zeros(c + 512, dtype=torch.float32, device=dev)
+        bb[:c] = b
+        zero = E._zero_page(dev)
+        flops = 2.0 * B * H * W * c * c * 9
+
+        def run_pl(i):
+            o = outs[i % nbuf]
+            E._check(lib.aq_conv3x3_pl(xs[i % nbuf].data_ptr(), c * 2, 16, c, o.data_ptr(), 2 * c, 0, c, o.data_ptr(), 2 * c, 0,
+                                       wpl.data_ptr(), bb.data_ptr(), B, H, W, 1, st))
+
+        def run_old(i):
+            o = outs[i % nbuf]
+            E._check(lib.aq_conv2d(xs[i % nbuf].data_ptr(), c, 0, c, o.data_ptr(), 2 * c, 0, c, o.data_ptr(), 2 * c, 0,
+                                   wold.data_ptr(), bb.data_ptr(), B, H, W, 3, 1, 1, 1, 0, 0, zero.data_ptr(), st))
+
+        def timeit(fn):
+            for i in range(3):
+                fn(i)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(a.reps):
+                fn(i)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / a.reps * 1e3
+
+        for nb in (13, 10, 7):
+            os.environ["AQ_PL_NB"] = str(nb)
+            try:
+                us = timeit(run_pl)
+                print(f"{c}ch {H}x{W} B{B}  planar NB={nb:2d}: {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
+            except RuntimeError as err:
+                print(f"{c}ch planar NB={nb}: {err}")
+        os.environ.pop("AQ_PL_NB", None)
+        us = timeit(run_pl)
+        print(f"{c}ch {H}x{W} B{B}  planar auto : {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
+        for cfg in [int(v) for v in a.old.split(",") if v]:
+            for flag in (0, E.CONV_CFG_ONE_TILE_PER_WG):
+                os.environ["AQ_CONV_CFG"] = str(cfg | flag)
+                try:
+                    us = timeit(run_old)
+                    print(f"{c}ch {H}x{W} B{B}  old cfg {cfg | flag:5d}: {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
+                except RuntimeError as err:
+                    print(f"{c}ch old cfg {cfg | flag}: {err}")
+        os.environ.pop("AQ_CONV_CFG", None)
+
+
+if __name__ == "__main__":
+    main()
