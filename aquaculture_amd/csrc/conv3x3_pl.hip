@@ -32,7 +32,7 @@ namespace {
 constexpr int PL_ROWS = 384;                 // region rows per plane: 6 LDS-DMA groups of 64 rows
 constexpr int PL_PS = PL_ROWS * 16;          // plane stride (a multiple of 256 B: keeps the 16-lane groups on distinct banks)
 constexpr int PL_CHUNK = 8 * PL_PS;          // one 64-channel chunk of the region
-constexpr int PL_BIAS = 3 * PL_CHUNK;        // bias follows the three ring buffers
+constexpr int PL_BIAS = 3 * PL_CHUNK;        // bias follows the three ring buffers (4 KB: 256 floats per wave)
 constexpr int PL_BM = 192;                   // M tile: 4 waves x 3 blocks of 16 rows
 constexpr int PL_STEP_B = 6 * 1024;          // weight bytes per (wave, tap-step): 2 k-steps x 3 M blocks x 1 KB
 
@@ -49,6 +49,7 @@ struct PlParams {
     int CC;                    // 64-channel chunks (Cin / 64)
     int n_mt, ntiles;
     float inv_hw, inv_w, inv_hpwp, inv_wp;
+    unsigned long long* debug;   // stamped diagnostic build (ABL & 16) only: 8 x uint64 per wave
 };
 
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -74,14 +75,18 @@ template <int OFF>
 __device__ __forceinline__ void pl_ldw(bf16x8& d, unsigned voff, const char* sbase) {
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
 }
-__device__ __forceinline__ void pl_ld8(u32x2& d, const char* addr) {
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(addr));
+template <int OFF>
+__device__ __forceinline__ void pl_ld8(u32x2& d, unsigned voff, const char* sbase) {
+    // destination in the accumulator half of the register file ("a"): 3 NB of these are in flight through a tile's last chunk, and
+    // the arch VGPRs are full of fragments there
+    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
 }
-__device__ __forceinline__ void pl_st8(char* addr, u32x2 v, unsigned long long mask) {
+template <int OFF>
+__device__ __forceinline__ void pl_st8(unsigned voff, char* sbase, u32x2 v, unsigned long long mask) {
     // always issued (vmcnt bookkeeping is by count); lanes outside `mask` are switched off
     unsigned long long save;
-    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx2 %2, %3, off\n\ts_nop 0\n\ts_mov_b64 exec, %0"
-                 : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx2 %2, %3, %4 offset:%5\n\ts_nop 0\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(mask), "v"(voff), "v"(v), "s"(sbase), "n"(OFF) : "memory");
 }
 // All but the wave's N youngest vector-memory operations are done.  The wait itself names no register, so that a wait chosen at run
 // time (two immediates behind a wave-uniform branch) does not make the compiler copy registers where the paths merge; pl_tie_a after
@@ -107,7 +112,10 @@ __device__ __forceinline__ void pl_wait_r(u32x2 (&r)[CNT]) {
     pl_tie<0, CNT>(r);
 }
 
-template <int NB, bool RES>
+// ABL: timing-only ablation builds (results are wrong): 1 = no weight loads in the chunk body, 2 = no LDS-DMA in the chunk body,
+// 4 = no B fragment reads, 8 = no epilogue arithmetic (tools/time_conv3x3.py --abl); 16 = stamped build (correct results): per-wave
+// cycle sums of 0 prologue, 1 chunk barrier, 2 element stream, 3 tile set-up, 4 epilogue, 5 chunk top; 6 = wave lifetime in cycles, 7 = in 100 MHz ticks
+template <int NB, bool RES, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_pl_kernel(const PlParams p) {
     constexpr int BN = NB * 16;
     constexpr int PD = 5;                        // B fragments in flight ahead of their MFMAs
@@ -119,7 +127,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_pl_kernel(const PlParams p) {
     const int G = gridDim.x;
     int tile = first_tile(G, blockIdx.x);
     if (tile >= p.ntiles) return;
-    for (int i = tid; i < p.cout; i += 256) sbias[i] = p.bias[i];
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_t = 0, ph_t0 = 0, ph_r0 = 0;
+    if constexpr (ABL & 16) { ph_t0 = ph_t = clock64(); ph_r0 = __builtin_amdgcn_s_memrealtime(); }
+    auto stamp = [&](int k) {
+        if constexpr (ABL & 16) {
+            const unsigned long long t = clock64();
+            ph[k] += t - ph_t;
+            ph_t = t;
+        }
+    };
 
     const int HW = p.H * p.W, Wp = p.W + 1, HpWp = (p.H + 1) * Wp, lead = p.W + 2;
     const unsigned smem_base = (unsigned)(uintptr_t)smem;
@@ -159,14 +175,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_pl_kernel(const PlParams p) {
     };
     auto no_rows = [&]() { static_for<6>([&](auto K) { prow[K] = -1; }); };
     // the two LDS-DMA instructions of slot k (0..5) of a chunk: planes 2 w and 2 w + 1, rows 64 k .. 64 k + 63
-    auto dma_pair = [&](auto K, int cd, int bd) {
+    auto dma_one = [&](auto K, auto S2, int cd, int bd) {
         const int P = prow[K];
-        static_for<2>([&](auto S2) {
-            const int s = 2 * wave + S2;
-            const long long goff = (long long)(8 * cd + s) * p.in_ss + (long long)max(P, 0) * p.in_sp;
-            const long long m = (long long)(P >> 31);                 // all ones for a padding row: take the zero page
-            pl_dma16(p.in + ((goff & ~m) | (zoff & m)), smem_base + bd * PL_CHUNK + s * PL_PS + K * 1024);
-        });
+        const int s = 2 * wave + S2;
+        const long long goff = (long long)(8 * cd + s) * p.in_ss + (long long)max(P, 0) * p.in_sp;
+        const long long m = (long long)(P >> 31);                 // all ones for a padding row: take the zero page
+        pl_dma16(p.in + ((goff & ~m) | (zoff & m)), smem_base + bd * PL_CHUNK + s * PL_PS + K * 1024);
+    };
+    auto dma_pair = [&](auto K, int cd, int bd) {
+        dma_one(K, std::integral_constant<int, 0>(), cd, bd);
+        dma_one(K, std::integral_constant<int, 1>(), cd, bd);
     };
     const unsigned aoff = lane * 16;
     auto a_base = [&](int t_, int c) -> const char* {     // weight stream of (this wave, M tile of tile t_, chunk c, tap 0), biased by 3 KB
@@ -184,11 +202,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_pl_kernel(const PlParams p) {
     u32x2 rA[NB], rB[NB];         // residual batches (one M block x NB pixel blocks each)
 
     // ---------------- prologue: chunks 0 and 1 of the first tile, weights of tap-steps 0 and 1 ----------------
+    load_a(A0, a_base(tile, 0));              // first: they depend on nothing
+    load_a(A1, a_base(tile, 0) + PL_STEP_B);
     region_rows(tile);
     static_for<6>([&](auto K) { dma_pair(K, 0, 0); });
-    load_a(A0, a_base(tile, 0));
-    load_a(A1, a_base(tile, 0) + PL_STEP_B);
+    {   // the bias, 256 floats per wave, by LDS-DMA as well (one instruction per wave: the counts below stay per-wave constants)
+        const int f0 = wave * 256 + lane * 4;
+        pl_dma16(f0 + 4 <= p.cout ? (const char*)(p.bias + f0) : p.zero, smem_base + PL_BIAS + wave * 1024);
+    }
     static_for<6>([&](auto K) { dma_pair(K, 1, 1); });
+    // all but chunk 1's LDS-DMA: chunk 0, the bias and the weights of taps 0 and 1 are in; the accumulators start from the bias
+    wait_vmcnt<12>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     bool first = true;
     int buf = 0;                  // ring buffer of the chunk being computed
 
@@ -205,17 +232,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_pl_kernel(const PlParams p) {
                 addr[J] = q * PL_PS + (pp_of(P) - rs - Wp - 1) * 16;
             });
         }
-        static_for<3 * NB>([&](auto IJ) { acc[IJ / NB][IJ % NB] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+        if (!first) stamp(4);
+        static_for<3>([&](auto I) {         // the accumulators start from the bias (one add per output less in the epilogue)
+            const f32x4 bv = *(const f32x4*)(sbias + cbase + 16 * I + 4 * q);
+            static_for<NB>([&](auto J) { acc[I][J] = bv; });
+        });
 
         for (int c = 0; c < p.CC; ++c) {
             const bool lastc = c + 1 == p.CC;
             // chunk c has landed in every wave's view (own DMA: covered by the counted waits of the previous chunk, or the
             // explicit one below for the very first chunk; other waves': the barrier), and every wave is done with the
             // buffer that chunk c + 2 will overwrite
-            if (first && c == 0) wait_vmcnt<12>();       // all but chunk 1's LDS-DMA: chunk 0 and the weights of taps 0 and 1 are in
+            if (c == 0 && !first) stamp(3);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            stamp(first && c == 0 ? 0 : 1);
             // target of this chunk's LDS-DMA: chunk c + 2 of this tile, or chunk c + 2 - CC of the next one
             int cd = c + 2, bd = buf + 2;
             if (bd >= 3) bd -= 3;
@@ -228,10 +260,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_pl_kernel(const PlParams p) {
             const int bufoff = buf * PL_CHUNK;
             if constexpr (RES) {
                 // residual batch 0, fetched at the top of EVERY chunk so that the wait counts of the chunk body are constants (the
-                // last chunk's copy is the one the epilogue reads; pl_keep below holds the registers until every copy has landed)
+                // last chunk's copy is the one the epilogue reads; pl_tie below holds the registers until every copy has landed:
+                // the destination of an asm load whose value is never read is free to the compiler from the next instruction on)
                 static_for<NB>([&](auto J) {
                     const int P = min(n0 + 16 * J + l15, p.npix - 1);
-                    pl_ld8(rA[J], p.res + (long long)P * p.res_ld_b + (cbase + 4 * q) * 2);
+                    pl_ld8<0>(rA[J], (unsigned)(P * p.res_ld_b + (cbase + 4 * q) * 2), p.res);
                 });
             }
             // One stream of 18 NB elements per chunk: element n = (tap t, k-step ks, pixel block j) is ONE B fragment read from the
@@ -250,81 +283,107 @@ __global__ __launch_bounds__(256, 1) void conv3x3_pl_kernel(const PlParams p) {
                 return *(const bf16x8*)(smem + (addr[j] + so[t]) + ks * 4 * PL_PS);
             };
             static_for<PD>([&](auto N_) { bq[N_] = b_read(N_); });
+            stamp(5);
             static_for<NE>([&](auto N_) {
                 constexpr int n = N_, h = n / NB, j = n - h * NB, t = h >> 1, ks = h & 1;
-                if constexpr (n + PD < NE) bq[(n + PD) % (PD + 1)] = b_read(std::integral_constant<int, n + PD>());
+                if constexpr (n + PD < NE && !(ABL & 4)) bq[(n + PD) % (PD + 1)] = b_read(std::integral_constant<int, n + PD>());
                 bf16x8 (&Acur)[6] = t % 3 == 0 ? A0 : (t % 3 == 1 ? A1 : A2);
-                if constexpr (j == 0 && ks == 0) {
-                    // ---- issue slot: LDS-DMA pair, residual batch 0 (last tap of the tile), weights of tap-step T + 2 ----
-                    if constexpr (t < 6) dma_pair(std::integral_constant<int, (t < 6 ? t : 0)>(), cd, bd);
-                    bf16x8 (&Anew)[6] = (t + 2) % 3 == 0 ? A0 : ((t + 2) % 3 == 1 ? A1 : A2);
-                    load_a(Anew, t + 2 < 9 ? a_cur + (t + 2) * PL_STEP_B : a_nxt + (t + 2 - 9) * PL_STEP_B);
-                    // ---- weights of this tap-step: younger operations = slot T - 1 and slot T (+ the epilogue's after a tile seam) ----
-                    // younger operations: slot T - 1 and slot T (6 weight loads + 2 LDS-DMA in taps 0..5 each) and, for taps 0 and 1,
-                    // the residual batch issued at the top of the chunk.  No count depends on a run-time condition: after a tile seam
-                    // the epilogue's loads and stores are younger too, and ignoring them only waits for a few of those stores.
-                    constexpr int kStd = 12 + (t >= 1 && t <= 6 ? 2 : 0) + (t < 6 ? 2 : 0) + (RES && t < 2 ? NB : 0);
-                    pl_wait<kStd>();
+                // The tap-step's vector-memory instructions go out ONE PER ELEMENT among the MFMAs (a burst of eight stalls the wave
+                // at the texture addresser's queue with the matrix pipe idle): element 0 waits for this tap's weights, elements
+                // 1, 3, .. 11 load one fragment each of tap-step T + 2, two later elements issue the LDS-DMA pair (taps 0..5).
+                constexpr int e = ks * NB + j;                       // element index inside the tap-step, 0 .. 2 NB - 1
+                constexpr int kD0 = 12, kD1 = 12 + (2 * NB - 12) / 2;
+                static_assert(2 * NB >= 14 && kD1 < 2 * NB && kD1 > kD0, "issue positions");
+                if constexpr (e == 0) {
+                    // younger than the fragments of tap T (issued in tap T - 2): that tap's LDS-DMA pair, tap T - 1's six loads and
+                    // pair, and for taps 0 and 1 the residual batch issued at the top of the chunk.  No count depends on a run-time
+                    // condition; after a tile seam the epilogue's loads and stores are younger too and ignoring them only waits longer.
+                    constexpr int kN = 6 + (t >= 2 && t <= 7 ? 2 : 0) + (t >= 1 && t <= 6 ? 2 : 0) + (RES && t < 2 ? NB : 0);
+                    if constexpr (ABL & 3) pl_wait<0>(); else pl_wait<kN>();
                     pl_tie_a(Acur);
                 }
+                if constexpr (e >= 1 && e <= 11 && (e & 1) && !(ABL & 1)) {
+                    constexpr int k = e >> 1;                        // fragment 0..5 of tap-step T + 2
+                    bf16x8 (&Anew)[6] = (t + 2) % 3 == 0 ? A0 : ((t + 2) % 3 == 1 ? A1 : A2);
+                    const char* sb = t + 2 < 9 ? a_cur + (t + 2) * PL_STEP_B : a_nxt + (t + 2 - 9) * PL_STEP_B;
+                    pl_ldw<1024 * k - 3072>(Anew[k], aoff, sb);
+                }
+                if constexpr (t < 6 && (e == kD0 || e == kD1) && !(ABL & 2)) dma_one(std::integral_constant<int, (t < 6 ? t : 0)>(), std::integral_constant<int, (e == kD0 ? 0 : 1)>(), cd, bd);
                 static_for<3>([&](auto I) {
                     acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Acur[3 * ks + I], bq[n % (PD + 1)], acc[I][j], 0, 0, 0);
                 });
                 __builtin_amdgcn_sched_barrier(0);      // keep this order: the read of element n + PD, the issue slot, three MFMAs
             });
+            if constexpr (ABL & 16) asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[2][NB - 1][3]));
+            stamp(2);
             if constexpr (RES) pl_tie<0, NB>(rA);      // landed by now (older than the last tap-steps' counted waits), and never free in between
             buf = buf == 2 ? 0 : buf + 1;
             first = false;
         }
 
-        // ---------------- epilogue: +bias, SiLU, (+residual), bf16, 8-byte stores; one M block (NB pixel blocks) at a time ----------------
+        // ---------------- epilogue: SiLU, (+residual), bf16, 8-byte stores; one M block (NB pixel blocks) at a time ----------------
+        // (the bias is already in the accumulators).  Addresses are a scalar base + a 32-bit per-lane offset + an immediate per block.
         unsigned long long omask[NB];
-        static_for<NB>([&](auto J) { omask[J] = __ballot(n0 + 16 * J + l15 < p.npix); });
-        static_for<3>([&](auto I) {
-            constexpr int i = I;
-            u32x2 (&rcur)[NB] = (i & 1) ? rB : rA;
-            u32x2 (&rnxt)[NB] = (i & 1) ? rA : rB;
-            if constexpr (RES) {
-                if constexpr (i < 2) {
-                    static_for<NB>([&](auto J) {
-                        const int P = min(n0 + 16 * J + l15, p.npix - 1);
-                        pl_ld8(rnxt[J], p.res + (long long)P * p.res_ld_b + (cbase + 16 * (i + 1) + 4 * q) * 2);
-                    });
-                }
-                // batch 0 landed during the last chunk; younger than batch 1: the stores of block 0 + batch 2; than batch 2: the stores of block 1
-                if constexpr (i == 1) pl_wait_r<2 * NB, NB>(rcur);
-                else if constexpr (i == 2) pl_wait_r<NB, NB>(rcur);
-            }
-            const f32x4 bv = *(const f32x4*)(sbias + cbase + 16 * i + 4 * q);
-            static_for<NB>([&](auto J) {
-                f32x4 v = acc[i][J] + bv;
-                if (p.act) {
-                    const f32x4 t = v * -1.44269504f;
-                    f32x4 d = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]), __builtin_amdgcn_exp2f(t[3])};
-                    d = d + 1.0f;
-                    const f32x4 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
-                    v = v * r;
-                }
-                if constexpr (RES) {
-                    const u32x2 rv = rcur[J];
-                    v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
-                    v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
-                }
-                const u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                const int P = min(n0 + 16 * J + l15, p.npix - 1);
-                pl_st8(p.out + (long long)P * p.out_ld_b + (cbase + 16 * i + 4 * q) * 2, o, omask[J]);
-            });
-            __builtin_amdgcn_sched_barrier(0);          // one M block at a time: do not pull all 3 NB accumulators into VGPRs up front
+        unsigned oo[NB], ro[NB];
+        static_for<NB>([&](auto J) {
+            omask[J] = __ballot(n0 + 16 * J + l15 < p.npix);
+            const int P = min(n0 + 16 * J + l15, p.npix - 1);
+            oo[J] = (unsigned)(P * p.out_ld_b + (cbase + 4 * q) * 2);
+            if constexpr (RES) ro[J] = (unsigned)(P * p.res_ld_b + (cbase + 4 * q) * 2);
         });
+        auto epilogue = [&](auto ACT) {
+            static_for<3>([&](auto I) {
+                constexpr int i = I;
+                u32x2 (&rcur)[NB] = (i & 1) ? rB : rA;
+                u32x2 (&rnxt)[NB] = (i & 1) ? rA : rB;
+                if constexpr (RES) {
+                    if constexpr (i < 2) static_for<NB>([&](auto J) { pl_ld8<32 * (i + 1)>(rnxt[J], ro[J], p.res); });
+                    // batch 0 landed during the last chunk; younger than batch 1: the stores of block 0 + batch 2; than batch 2: the stores of block 1
+                    if constexpr (i == 1) pl_wait_r<2 * NB, NB>(rcur);
+                    else if constexpr (i == 2) pl_wait_r<NB, NB>(rcur);
+                }
+                static_for<NB>([&](auto J) {
+                    f32x4 v = acc[i][J];
+                    if constexpr (decltype(ACT)::value && !(ABL & 8)) {
+                        const f32x4 t = v * -1.44269504f;
+                        f32x4 d = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]), __builtin_amdgcn_exp2f(t[3])};
+                        d = d + 1.0f;
+                        const f32x4 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
+                        v = v * r;
+                    }
+                    if constexpr (RES) {
+                        const u32x2 rv = rcur[J];
+                        v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
+                        v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
+                    }
+                    const u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    pl_st8<32 * i>(oo[J], p.out, o, omask[J]);
+                });
+                __builtin_amdgcn_sched_barrier(0);      // one M block at a time: do not pull all 3 NB accumulators into VGPRs up front
+            });
+        };
+        if (p.act) epilogue(std::true_type()); else epilogue(std::false_type());
         if (!has_next) break;
         tile = next_tile;
     }
     // the weight loads issued for a tile that does not exist must not outlive their registers: wait, THEN let the registers go
     wait_vmcnt<0>();
+    if constexpr (ABL & 16) {
+        stamp(4);
+        if (lane == 0 && p.debug) {
+            unsigned long long* d = p.debug + ((long long)blockIdx.x * 4 + wave) * 8;
+            for (int k = 0; k < 6; ++k) d[k] = ph[k];
+            d[6] = clock64() - ph_t0;
+            d[7] = __builtin_amdgcn_s_memrealtime() - ph_r0;
+        }
+    }
     pl_tie_a(A0); pl_tie_a(A1); pl_tie_a(A2);
 }
 
 struct PlKernel { int nb; void (*plain)(const PlParams); void (*res)(const PlParams); };
+struct PlAblation { int abl; void (*fn)(const PlParams); };
+#define PLA(A) { A, conv3x3_pl_kernel<13, true, A> }
+const PlAblation kPlAbl[] = { PLA(16) };
 #define PLK(NB) { NB, conv3x3_pl_kernel<NB, false>, conv3x3_pl_kernel<NB, true> }
 const PlKernel kPl[] = { PLK(13), PLK(10), PLK(7) };
 constexpr int kNumPl = sizeof(kPl) / sizeof(kPl[0]);
@@ -347,7 +406,7 @@ int pl_region_rows(int B, int H, int W, int bn) {
 }  // namespace
 
 extern "C" int aq_conv3x3_pl_supported(int cin, int cout) {
-    return cin >= 128 && cin % 64 == 0 && cout % PL_BM == 0 && cout <= 3840;
+    return cin >= 128 && cin % 64 == 0 && cout % PL_BM == 0 && cout <= 960;
 }
 
 // Packs fused fp32 weights KRSC (cout, 3, 3, cin) into per-wave A-fragment streams:
@@ -408,6 +467,8 @@ extern "C" int aq_conv3x3_pl(const void* in_dev, long long in_sp, long long in_s
     AQ_REQUIRE(in_sp % 16 == 0 && in_ss % 16 == 0 && out_ld % 4 == 0 && out_choff % 4 == 0 && out_choff + cout <= out_ld,
                "conv3x3_pl: slices must be 8-byte aligned and inside their rows");
     AQ_REQUIRE(!res_dev || (res_ld % 4 == 0 && res_choff % 4 == 0 && res_choff + cout <= res_ld), "conv3x3_pl: bad residual slice");
+    AQ_REQUIRE((long long)B * H * W * out_ld * 2 < (1LL << 31) && (long long)B * H * W * res_ld * 2 < (1LL << 31),
+               "conv3x3_pl: output / residual tensors beyond the 32-bit offset range");
     int dev = 0;
     AQ_CHECK_HIP(hipGetDevice(&dev));
     AQ_REQUIRE(dev >= 0 && dev < 64, "conv3x3_pl: device ordinal %d", dev);
@@ -440,8 +501,19 @@ extern "C" int aq_conv3x3_pl(const void* in_dev, long long in_sp, long long in_s
     AQ_REQUIRE(ntiles > 0 && ntiles < (1LL << 30), "conv3x3_pl: bad tile count");
     p.ntiles = (int)ntiles;
     auto fn = res_dev ? kPl[k].res : kPl[k].plain;
-    const size_t lds = (size_t)PL_BIAS + (size_t)cout * 4;
+    const char* abl = getenv("AQ_PL_ABL");                  // timing-only diagnostic builds (wrong results), NB = 13 with shortcut only
+    bool ablated = false;
+    if (abl && *abl && kPl[k].nb == 13 && res_dev)
+        for (const PlAblation& a : kPlAbl)
+            if (a.abl == atoi(abl)) { fn = a.fn; ablated = true; }
+    if (ablated) {
+        size_t sbytes = 0;
+        unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
+        if (sbuf && sbytes >= (size_t)g_pl_cus[dev] * 4 * 64) p.debug = sbuf;
+    }
+    const size_t lds = (size_t)PL_BIAS + 4096;
     AQ_REQUIRE(lds <= 160 * 1024, "conv3x3_pl: LDS");
+    if (ablated) AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (!g_pl_attr[dev][k][res_dev ? 1 : 0]) {
         AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         g_pl_attr[dev][k][res_dev ? 1 : 0] = true;

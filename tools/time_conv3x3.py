@@ -18,6 +18,9 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--old", default="21,30", help="aq_conv2d configs to time beside the planar kernel (21 = halo 192x256)")
+    ap.add_argument("--stamp", action="store_true", help="run the stamped build once and print per-phase cycle sums per wave")
+    ap.add_argument("--abl", default="", help="timing-only ablation builds of the planar kernel to time (comma list of AQ_PL_ABL values)")
+    ap.add_argument("--nbs", default="13,10,7", help="pixel-block counts of the planar kernel to time ('' = automatic choice only)")
     a = ap.parse_args()
     lib = E.load_library()
     dev = torch.device("cuda", 0)
@@ -64,7 +67,7 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / a.reps * 1e3
 
-        for nb in (13, 10, 7):
+        for nb in [int(v) for v in a.nbs.split(',') if v]:
             os.environ["AQ_PL_NB"] = str(nb)
             try:
                 us = timeit(run_pl)
@@ -72,6 +75,24 @@ def main():
             except RuntimeError as err:
                 print(f"{c}ch planar NB={nb}: {err}")
         os.environ.pop("AQ_PL_NB", None)
+        for sab in ([16] + [16 + int(v) for v in a.abl.split(",") if v] if a.stamp else []):
+            buf = torch.zeros(1 << 16, dtype=torch.int64, device=dev)
+            E._check(lib.aq_debug_conv_stamp(buf.data_ptr(), buf.numel() * 8))
+            os.environ["AQ_PL_ABL"] = str(sab)
+            for i in range(3):
+                run_pl(i)
+            torch.cuda.synchronize()
+            buf.zero_()
+            run_pl(3)
+            torch.cuda.synchronize()
+            lib.aq_debug_conv_stamp(None, 0)
+            os.environ.pop("AQ_PL_ABL", None)
+            t = buf.cpu().view(-1, 8).double()
+            t = t[t[:, 6] > 0]
+            names = ["prologue", "chunk-barrier", "stream", "tile-setup", "epilogue", "chunk-top"]
+            life, ticks = t[:, 6], t[:, 7]
+            print(f"{c}ch stamped ABL={sab - 16}: waves {t.shape[0]}  lifetime {life.mean():.0f} cycles (min {life.min():.0f} max {life.max():.0f}) = {ticks.mean() * 10:.0f} ns "
+                  f"-> clock {(life / ticks).median() * 100:.0f} MHz | " + " ".join(f"{n}={t[:, k].mean():.0f}" for k, n in enumerate(names)), flush=True)
         us = timeit(run_pl)
         print(f"{c}ch {H}x{W} B{B}  planar auto : {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
         for cfg in [int(v) for v in a.old.split(",") if v]:
