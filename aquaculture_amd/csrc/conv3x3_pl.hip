@@ -118,7 +118,7 @@ __device__ __forceinline__ void pl_wait_r(u32x2 (&r)[CNT]) {
 template <int NB, bool RES, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_pl_kernel(const PlParams p) {
     constexpr int BN = NB * 16;
-    constexpr int PD = 5;                        // B fragments in flight ahead of their MFMAs
+    constexpr int PD = 8;                        // B fragments in flight ahead of their MFMAs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

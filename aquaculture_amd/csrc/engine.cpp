@@ -457,8 +457,9 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
             }
             pw.direct_cfg = AQ_CONV_CFG_DIRECT3X3S2;
         }
+        const char* no_pl = getenv("AQ_DISABLE_PL3X3");      // A/B switch: keep the planar 3x3 kernel out of the candidate list
         if (d->precision == AQ_BF16 && op.k == 3 && op.stride == 1 && op.pad == 1 && e->tensors[op.dst.tensor].dtype == AQ_T_ACT &&
-            op.src.ch_off % 8 == 0 && aq_conv3x3_pl_supported(op.src.channels, op.dst.channels)) {
+            op.src.ch_off % 8 == 0 && aq_conv3x3_pl_supported(op.src.channels, op.dst.channels) && !(no_pl && *no_pl == '1')) {
             size_t nb = 0;
             if (aq_pack_conv3x3_pl(op.weight, op.src.channels, op.dst.channels, nullptr, &nb, nullptr) != AQ_OK ||
                 hipMalloc(&pw.w_direct, nb) != hipSuccess ||

@@ -65,3 +65,55 @@ def test_asm_loaded_shortcut_registers_are_untouched_until_the_wait(bottleneck_a
                 assert "ASMSTART" in body[i - 1], f"compiler-inserted {l.strip()} in a loop"
         checked += 1
     assert checked >= 1
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# conv3x3_pl.hip: EVERY vector-memory operation of the kernel is inline asm counted by hand, so the compiler must never (a) add a
+# vector-memory operation of its own (a scratch spill counts on vmcnt), (b) touch an asm-loaded register before the wait that covers it
+# (a copy or an AGPR spill there reads the old contents), (c) move accumulators around inside the MFMA stream.
+@pytest.fixture(scope="module")
+def planar_asm(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "conv3x3_pl.s"
+    src = os.path.join(ROOT, "aquaculture_amd", "csrc", "conv3x3_pl.hip")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{os.path.dirname(src)}", "--cuda-device-only",
+                    "-S", src, "-o", str(out)], check=True, capture_output=True)
+    return out.read_text()
+
+
+def test_planar_kernel_hand_counted_memory_operations(planar_asm):
+    import bisect
+    kernels = re.split(r"\n(?=_ZN\S*conv3x3_pl_kernel\S*:\s*; @)", planar_asm)[1:]
+    assert len(kernels) >= 6
+    for k in kernels:
+        name = k.split(":", 1)[0]
+        body = k.split(".Lfunc_end")[0].split("\n")
+        assert not [l for l in body if "scratch_" in l], f"{name}: scratch spill (a vector-memory operation the hand counts do not know)"
+        mf = [i for i, l in enumerate(body) if "v_mfma" in l]
+        lo, hi = mf[0], mf[-1]
+        assert not [l for l in body[lo:hi] if "v_accvgpr" in l], f"{name}: accumulator traffic inside the MFMA stream"
+        for l in body[lo:hi + 1]:
+            m = re.search(r"v_mfma\S+ (a\[\d+:\d+\]), v\[\d+:\d+\], v\[\d+:\d+\], (a\[\d+:\d+\])", l)
+            assert m is None or m.group(1) == m.group(2), f"{name}: {l.strip()} does not accumulate in place"
+        waits = [i for i, l in enumerate(body) if re.search(r"s_waitcnt vmcnt\(\d+\)\s*$", l) and "ASMSTART" in body[i - 1]]
+        # weight fragments (dwordx4, issued in tap T for tap T + 2): untouched until the second hand-written wait after them;
+        # residual loads (dwordx2): batch 0 at the chunk top until the third wait after it, the epilogue batches until the next wait
+        for i, l in enumerate(body):
+            m = re.search(r"global_load_dwordx([24]) v\[(\d+):(\d+)\]", l)
+            if not m or "ASMSTART" not in body[i - 1]:
+                continue
+            dest = set(range(int(m.group(2)), int(m.group(3)) + 1))
+            kth = bisect.bisect_right(waits, i)
+            if m.group(1) == "4":
+                if not lo <= i <= hi:
+                    continue                                 # prologue loads: waited for by the vmcnt(12) right behind them
+                end = min(waits[kth + 1], hi) if kth + 1 < len(waits) else hi
+            else:
+                end = waits[kth + 2] if i < lo else (waits[kth] if kth < len(waits) else len(body))
+            for j in range(i + 1, end):
+                line = body[j].split(";")[0]
+                if not line.strip() or "global_load_dwordx" in line:
+                    continue
+                assert not (_regs(line) & dest), f"{name}: '{line.strip()}' touches a register that '{l.strip()}' is still loading"

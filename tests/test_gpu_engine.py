@@ -322,7 +322,7 @@ def test_benchmark_configuration_nms_invariants(lib, synth_ck):
     d0, c0 = d0.cpu(), c0.cpu()
     eng = _engine(synth_ck, "bf16")
     cfgs = eng.autotune(x)
-    assert any(c >= 4096 for c in cfgs) or any(c in (1000, 1001) for c in cfgs)       # the tuner did pick non-default forms
+    assert any(c >= 4096 for c in cfgs) or any(c in (1000, 1001, 1002) for c in cfgs)       # the tuner did pick non-default forms
     dets, counts = eng.infer(x, conf_thres, iou_thres, max_det)
     dets, counts = dets.cpu(), counts.cpu()
     assert counts.shape == (64,) and int(counts.max()) <= max_det and int(counts.sum()) > 1000
@@ -334,13 +334,17 @@ def test_benchmark_configuration_nms_invariants(lib, synth_ck):
         assert (conf >= conf_thres).all() and (conf[:-1] >= conf[1:]).all() and ((cls >= 0) & (cls < 5) & (cls == cls.round())).all()
         assert (d[:, 2] >= d[:, 0]).all() and (d[:, 3] >= d[:, 1]).all()     # w = (2 sigmoid)^2 * anchor may underflow to a zero-width box
         if n > 1:
-            x1 = torch.maximum(d[:, None, 0], d[None, :, 0]); y1 = torch.maximum(d[:, None, 1], d[None, :, 1])
-            x2 = torch.minimum(d[:, None, 2], d[None, :, 2]); y2 = torch.minimum(d[:, None, 3], d[None, :, 3])
+            # IoU as the suppression itself sees it: on the class-offset boxes (box + cls * max_wh, max_wh = 7680 [UPSTREAM
+            # non_max_suppression]) in fp32.  At coordinates of up to 3e4 one fp32 ulp is 0.002-0.004 px, so the IoU of the raw boxes
+            # can sit 1e-4 away from the one that was thresholded; on the offset boxes the two agree to rounding.
+            bx = d[:, :4] + (cls * 7680.0)[:, None]
+            x1 = torch.maximum(bx[:, None, 0], bx[None, :, 0]); y1 = torch.maximum(bx[:, None, 1], bx[None, :, 1])
+            x2 = torch.minimum(bx[:, None, 2], bx[None, :, 2]); y2 = torch.minimum(bx[:, None, 3], bx[None, :, 3])
             inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
-            area = (d[:, 2] - d[:, 0]) * (d[:, 3] - d[:, 1])
+            area = (bx[:, 2] - bx[:, 0]) * (bx[:, 3] - bx[:, 1])
             iou = inter / (area[:, None] + area[None, :] - inter).clamp(min=1e-9)
             same = (cls[:, None] == cls[None, :]) & ~torch.eye(n, dtype=torch.bool)
-            assert float(iou[same].max()) <= iou_thres + 1e-5 if same.any() else True
+            assert float(iou[same].max()) <= iou_thres + 1e-5 if same.any() else True, (b, float(iou[same].max()))
     # tuned vs untuned kernels: same detections up to bf16 accumulation-order noise
     assert (counts - c0).abs().max() <= max(4, int(0.05 * int(c0.max())))
     assert abs(int(counts.sum()) - int(c0.sum())) <= 0.01 * int(c0.sum())
