@@ -146,7 +146,9 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     streams = [torch.cuda.Stream() for _ in range(depth)]
     slot_free = [threading.Semaphore(1) for _ in range(depth)]   # a slot's pinned result buffers are reused only after its writer is done
     stats = {"seen": 0, "labels": 0, "dets": 0, "t_post": 0.0}
-    gathered: List[torch.Tensor] = []
+    gather = aqdist.DetectionGather(dev, keep=False)      # rank 0 counts what arrives; the label files are the product
+    gather_lock = threading.Lock()
+    flush_every = 16                                       # batches between flushes of the detection gather
     q: "queue.Queue" = queue.Queue(maxsize=depth)
     err: List[BaseException] = []
 
@@ -176,8 +178,8 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                         s += postprocess.class_summary(det[:, 5], ck.names) if det.shape[0] else "(no detections), "
                         log(f"{s}{t_inf * 1e3 / len(paths):.1f}ms")
                     if world > 1 and det.shape[0]:
-                        idx = torch.full((det.shape[0],), gidx[b], dtype=torch.float32)
-                        gathered.append(aqdist.pack_rows(idx, torch.from_numpy(det.copy())))
+                        with gather_lock:
+                            gather.add(torch.full((det.shape[0],), gidx[b], dtype=torch.int32), aqdist.pack_rows(torch.from_numpy(det.copy())))
                 slot_free[slot_id].release()
                 with lock:
                     stats["seen"] += len(paths)
@@ -302,21 +304,24 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         t_pre += t1 - t0
         t_inf += t2 - t1
         k += 1
+        if world > 1 and k % flush_every == 0:         # bounded gather: rows leave the host lists every few batches (collective)
+            with gather_lock:
+                gather.flush(more=True, failed=bool(err))
     for _ in wts:
         q.put(None)
     for w_ in wts:
         w_.join()
+    if world > 1:                                      # collective tail; a failed rank takes the others down with it at once
+        gather.finish(failed=bool(err))
     if err:
         raise err[0]
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     seen, n_labels, n_dets, t_post = stats["seen"], stats["labels"], stats["dets"], stats["t_post"]
 
-    if world > 1:   # the one collective of the path: final detection gather over RCCL/xGMI
-        rows = torch.cat(gathered, 0) if gathered else torch.zeros((0, aqdist.ROW))
-        rows = aqdist.gather_rows(rows.to(dev))
+    if world > 1:   # the one collective of the path (detection gather over RCCL/xGMI) has run in bounded pieces; now the counters
         seen_all, labels_all, dets_all, elapsed = aqdist.reduce_counters(seen, n_labels, n_dets, elapsed, dev)
-        assert rows.shape[0] == dets_all, "gathered detection rows do not add up"
+        assert rank != 0 or gather.total == dets_all, "gathered detection rows do not add up"
     else:
         seen_all, labels_all, dets_all = seen, n_labels, n_dets
     if rank == 0:

@@ -40,13 +40,15 @@ def parse():
     p.add_argument("--size", type=int, default=640)
     p.add_argument("--variant", default="yolov5m")
     p.add_argument("--precision", default="bf16", choices=("bf16", "fp32"))
-    p.add_argument("--pool", type=int, default=2, help="distinct synthetic batches kept in HBM and cycled")
+    p.add_argument("--pool", type=int, default=8, help="distinct synthetic batches kept in HBM and cycled (8 x 64 tiles = 629 MB of input, "
+                                                       "beyond the 256 MB Infinity Cache)")
     p.add_argument("--roof-steps", type=int, default=10, help="steps of the single-stream HIP-event pass that feeds `roofline`")
     p.add_argument("--streams", type=int, default=int(os.environ.get("AQ_BENCH_STREAMS", 2)),
                    help="independent batches in flight (one HIP stream + workspace each)")
     p.add_argument("--two-kernel-bottleneck", action="store_true", help="A/B: 1x1 + 3x3 launches instead of the fused Bottleneck kernel")
     p.add_argument("--two-kernel-stem", action="store_true", help="A/B: preprocess + space-to-depth conv instead of the fused stem kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--parity-steps", type=int, default=3, help="steps of the fp32 parity-mode engine timed beside the bf16 metric (0 = skip)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle sample budget")
     p.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristic instead of timing configs")
     p.add_argument("--no-profile", action="store_true", help="skip per-op HIP events (roofline becomes null)")
@@ -133,11 +135,18 @@ def main() -> int:
             torch.cuda.current_stream().wait_stream(st)
 
     def gather_all():
-        # final detection gather: the path's one collective (RCCL over xGMI when world > 1)
-        keep = torch.arange(max_det, device=dev).view(1, 1, -1) < counts.view(K, B, 1)
-        rows = dets[keep]                                                   # [n, 6]
-        tile_id = (torch.arange(K * B, device=dev).view(K, B, 1) * world + rank).expand(K, B, max_det)[keep]
-        return aqdist.gather_rows(aqdist.pack_rows(tile_id, rows))
+        # final detection gather: the path's one collective (to rank 0; RCCL over xGMI when world > 1), in pieces of 8 steps so
+        # that neither the padding nor rank 0's receive buffers grow with the run
+        g = aqdist.DetectionGather(dev, keep=False)
+        for k0 in range(0, K, 8):
+            k1 = min(K, k0 + 8)
+            keep = torch.arange(max_det, device=dev).view(1, 1, -1) < counts[k0:k1].view(k1 - k0, B, 1)
+            tile_id = ((torch.arange(k0 * B, k1 * B, device=dev, dtype=torch.int32).view(k1 - k0, B, 1)) * world + rank).expand(k1 - k0, B, max_det)[keep]
+            g.add(tile_id, aqdist.pack_rows(dets[k0:k1][keep]))
+            g.flush(more=k1 < K)
+        g.finish()
+        t = torch.tensor([g.total if rank == 0 else int(counts.sum())], dtype=torch.int64)
+        return t
 
     cfgs = eng.autotune(tiles_dev[0], cache=os.environ.get("AQ_TUNE_CACHE")) if not a.no_autotune else None
     for k in range(max(W, a.streams)):
@@ -152,11 +161,11 @@ def main() -> int:
     for k in range(K):
         step(k, k)
     join()
-    rows = gather_all()
+    gathered = gather_all()
     torch.cuda.synchronize()
     aqdist.barrier()
     elapsed = time.perf_counter() - t0
-    n_dets_total = int(rows.shape[0])
+    n_dets_total = int(gathered[0])
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -219,16 +228,25 @@ def main() -> int:
                          f"(shape {shape} of {n_ig}, {'one workgroup per tile' if one_per_wg else 'persistent grid'})")
             single = {"config": cbest, "kernel": kname, "launches_per_step": len(ii), "avg_launch_ms": round(1e3 * tt / len(ii), 4),
                       "tflops": round(ff / tt / 1e12, 1), "frac": round(ff / tt / 1e12 / peak, 4)}
-        traffic = None                                       # PMC figure: only for the workload it was collected on
+        # PMC figure of a separate `rocprofv3 --pmc` pass (tools/profile_pmc.py): reported only for the workload AND the library build
+        # it was collected on, and labelled as what it is (this run measures no counters)
+        traffic, traffic_src = None, None
         try:
             with open(a.traffic_json) as f:
                 tj = json.load(f)
-            if a.variant == "yolov5m" and a.size == 640 and a.precision == "bf16" and int(tj.get("batch", -1)) == B:
+            with open(os.path.join(ROOT, "aquaculture_amd", "csrc", "libaqengine.so.sha256")) as f:
+                digest = f.read().strip()
+            same_cfgs = cfgs is None or not tj.get("conv3x3_configs") or any([int(cfgs[i]) for i in idx3] == v for v in tj["conv3x3_configs"].values())
+            if (a.variant == "yolov5m" and a.size == 640 and a.precision == "bf16" and int(tj.get("batch", -1)) == B
+                    and tj.get("library_source_digest") == digest and same_cfgs):
                 traffic = tj.get("bytes_per_launch")
+                traffic_src = f"{os.path.relpath(a.traffic_json, ROOT)} (separate rocprofv3 --pmc pass of this library build {digest[:12]}, same tuned 3x3 kernels)"
+            else:
+                traffic_src = f"null: {os.path.relpath(a.traffic_json, ROOT)} was collected on another build / workload / tuned table"
         except (OSError, ValueError):
             pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": f"conv3x3_pl_kernel / conv3x3_halo_kernel / conv_igemm_kernel / downblock_kernel (3x3 convs, kernel and tile shape autotuned per layer) on the {len(idx3)} 3x3 "
                           f"layers launched as plain convs ({len(idxb)} Bottlenecks run in bottleneck_kernel, reported separately)",
                 "launches_per_step": len(idx3), "avg_launch_ms": round(1e3 * t3 / len(idx3), 4),
@@ -254,6 +272,23 @@ def main() -> int:
                    "detections_gathered": n_dets_total},
         "roofline": roof,
     }
+    if world == 1 and a.precision == "bf16" and a.parity_steps > 0:
+        # what the 1e-4 parity gate costs: the same workload through the fp32 engine (exact-fp32 MFMA, 157 TFLOP/s peak), heuristic tile shapes
+        eng.close()
+        e32 = Engine(ck, "fp32", local)
+        d32 = torch.empty((B, max_det, 6), dtype=torch.float32, device=dev)
+        c32 = torch.zeros((B,), dtype=torch.int32, device=dev)
+        e32.infer(tiles_dev[0], 0.25, 0.45, max_det, out=(d32, c32))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(a.parity_steps):
+            e32.infer(tiles_dev[k % a.pool], 0.25, 0.45, max_det, out=(d32, c32))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.parity_steps
+        out["parity_mode"] = {"dtype": "fp32", "tiles_per_s": round(B / dt, 1), "ms_per_step": round(1e3 * dt, 2),
+                              "frac_of_157TF": round(fl["total"] * B / dt / 1e12 / PEAK_F32_TFLOPS, 4), "steps": a.parity_steps,
+                              "note": "fp32 engine (the --precision fp32 parity gate: boxes/conf within 1e-4 of the oracle), one batch in flight"}
+        e32.close()
     if world == 1 and not a.no_cpu_baseline:
         eng.close()
         out["cpu_baseline"] = cpu_baseline(ck, a.size, a.cpu_seconds)

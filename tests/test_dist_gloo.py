@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size 2 over gloo.  Shard -> per-rank detections -> one gather -> same table as 1 rank."""
+"""The N>1 path on CPU over gloo (world sizes 2 to 8).  Shard -> per-rank detections -> bounded gather to rank 0 -> same table as 1 rank."""
 import os
 import socket
 
@@ -17,41 +17,87 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _fake_dets(tile):
+def _fake_dets(tile, skew=False):
     rng = np.random.default_rng(tile)
     n = int(rng.integers(0, 6)) if tile % 3 else 0          # some tiles have no detections at all
+    if skew and tile % 37 == 5:
+        n = 3000 + tile                                     # a cage-dense coastal tile: thousands of rows on one rank
     return torch.from_numpy(rng.uniform(0, 640, (n, 6)).astype(np.float32))
 
 
-def _worker(rank, world, port, n_tiles, out):
+def _worker(rank, world, port, n_tiles, out, flush_every, skew):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r, w, _ = aqdist.init("gloo")
     assert (r, w) == (rank, world)
-    rows, seen = [], 0
-    for t in aqdist.shard_indices(n_tiles, rank, world):
-        d = _fake_dets(t)
+    g = aqdist.DetectionGather(torch.device("cpu"))
+    seen = ndet = 0
+    for k, t in enumerate(aqdist.shard_indices(n_tiles, rank, world)):
+        d = _fake_dets(t, skew)
         seen += 1
-        rows.append(aqdist.pack_rows(torch.full((d.shape[0],), t), d))
-    local = torch.cat(rows, 0) if rows else torch.zeros((0, aqdist.ROW))
-    allrows = aqdist.gather_rows(local)
-    tiles, labels, dets, elapsed = aqdist.reduce_counters(seen, seen // 2, local.shape[0], 1.0 + rank, torch.device("cpu"))
+        ndet += d.shape[0]
+        g.add(torch.full((d.shape[0],), t, dtype=torch.int32), aqdist.pack_rows(d))
+        if (k + 1) % flush_every == 0:
+            g.flush(more=True)
+    g.finish()
+    tiles, labels, dets, elapsed = aqdist.reduce_counters(seen, seen // 2, ndet, 1.0 + rank, torch.device("cpu"))
     aqdist.barrier()
     if rank == 0:
-        torch.save({"rows": allrows, "tiles": tiles, "dets": dets, "elapsed": elapsed}, out)
+        idx, rows = g.table()
+        torch.save({"idx": idx, "rows": rows, "tiles": tiles, "dets": dets, "elapsed": elapsed, "flushes": g.flushes, "peak": g.max_rows_per_flush}, out)
+    else:
+        assert g.total == 0                 # nobody but rank 0 receives rows
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world,n_tiles,flush_every,skew", [
+    (2, 23, 4, False), (4, 23, 2, False), (4, 3, 16, False), (3, 1, 1, False),   # incl. ranks without tiles / without detections / never a periodic flush
+    (8, 203, 3, True),                                                          # 8 ranks, skewed: a few tiles carry thousands of detections
+])
+def test_gather_equals_single_process(tmp_path, world, n_tiles, flush_every, skew):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(world, _free_port(), n_tiles, out, flush_every, skew), nprocs=world, join=True)
+    got = torch.load(out)
+    want_i = torch.cat([torch.full((_fake_dets(t, skew).shape[0],), t, dtype=torch.int32) for t in range(n_tiles)])
+    want_r = torch.cat([aqdist.pack_rows(_fake_dets(t, skew)) for t in range(n_tiles)], 0)
+    assert got["tiles"] == n_tiles and got["dets"] == want_r.shape[0] and got["elapsed"] == float(world)
+    assert got["idx"].dtype == torch.int32 and got["rows"].shape == want_r.shape
+    key = lambda i, r: r[torch.argsort(i.double() * 1e6 + r[:, 5].double() * 1e3 + r[:, 1].double(), stable=True)]
+    assert torch.equal(key(got["idx"], got["rows"]), key(want_i, want_r))
+    assert sorted(set(got["idx"].tolist())) == sorted(t for t in range(n_tiles) if _fake_dets(t, skew).shape[0])
+    # bounded: no flush carried more than the rows one rank produced between two of its flushes
+    per_flush = max(sum(_fake_dets(t, skew).shape[0] for t in list(aqdist.shard_indices(n_tiles, r, world))[k:k + flush_every])
+                    for r in range(world) for k in range(0, max(1, len(aqdist.shard_indices(n_tiles, r, world))), flush_every))
+    assert got["peak"] <= per_flush
+
+
+def _failing_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    aqdist.init("gloo")
+    g = aqdist.DetectionGather(torch.device("cpu"))
+    try:
+        if rank == 1:
+            g.finish(failed=True)           # what detect.py does when its writer thread raised
+        else:
+            for k in range(40):
+                g.add(torch.zeros(2, dtype=torch.int32), torch.ones(2, aqdist.ROW))
+                g.flush(more=True)
+            g.finish()
+        res = "finished"
+    except aqdist.RankFailed as e:
+        res = f"aborted after {g.flushes} flush(es): {e}"
+    with open(f"{out}.{rank}", "w") as f:
+        f.write(res)
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("world,n_tiles", [(2, 23), (4, 23), (4, 3), (3, 1)])     # incl. ranks without tiles / without detections
-def test_gather_equals_single_process(tmp_path, world, n_tiles):
-    out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker, args=(world, _free_port(), n_tiles, out), nprocs=world, join=True)
-    got = torch.load(out)
-    want = torch.cat([aqdist.pack_rows(torch.full((_fake_dets(t).shape[0],), t), _fake_dets(t)) for t in range(n_tiles)], 0)
-    assert got["tiles"] == n_tiles and got["dets"] == want.shape[0] and got["elapsed"] == float(world)
-    key = lambda r: r[torch.argsort(r[:, 0] * 1e6 + r[:, 6] * 1e3 + r[:, 2], stable=True)]
-    assert torch.equal(key(got["rows"]), key(want))
-    assert sorted(set(got["rows"][:, 0].int().tolist())) == sorted(t for t in range(n_tiles) if _fake_dets(t).shape[0])
+def test_failed_rank_aborts_the_others(tmp_path):
+    """A rank that failed reports it through the gather; the others stop at their next flush instead of hanging in a collective."""
+    out = str(tmp_path / "res")
+    mp.spawn(_failing_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    res = [open(f"{out}.{r}").read() for r in range(3)]
+    assert all(r.startswith("aborted after 1 flush") for r in res), res
 
 
 def test_shard_is_a_partition():
@@ -60,4 +106,7 @@ def test_shard_is_a_partition():
         assert sum(len(p) for p in parts) == n
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
     assert aqdist.env_rank_world() == (int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0)))
-    assert aqdist.gather_rows(torch.ones(3, aqdist.ROW)).shape == (3, aqdist.ROW)     # no process group: identity
+    g = aqdist.DetectionGather()                                   # no process group: everything stays local
+    g.add(torch.arange(3, dtype=torch.int32), torch.ones(3, aqdist.ROW))
+    g.finish()
+    assert g.total == 3 and g.table()[1].shape == (3, aqdist.ROW)
