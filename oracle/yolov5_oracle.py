@@ -45,6 +45,13 @@ def q_bf16(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+def q_bf16_f64(t: torch.Tensor) -> torch.Tensor:
+    """The same storage rounding with the arithmetic between two roundings carried in fp64: against ``q_bf16`` (fp32 accumulation in
+    PyTorch's summation order) it measures how far results move when ONLY the accumulation changes -- the floor any other
+    implementation of the same bf16 pipeline (the HIP engine: MFMA order, fp32) is entitled to (tests/test_gpu_bf16_deviation.py)."""
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
 # --------------------------------------------------------------------------------------
 # model
 # --------------------------------------------------------------------------------------
@@ -84,7 +91,8 @@ class OracleModel:
     def _wb(self, key):
         if key not in self._fused:
             w, b = fuse_conv_and_bn(self.state, key, self.eps)
-            self._fused[key] = (self.q(w), b)
+            w = self.q(w)
+            self._fused[key] = (w, b.to(w.dtype))
         return self._fused[key]
 
     def conv(self, x, key, k, s, p=None):
@@ -149,16 +157,15 @@ class OracleModel:
         z = []
         for i, x in enumerate(feats):
             w = self.q(self.state[f"model.24.m.{i}.weight"].float())
-            b = self.state[f"model.24.m.{i}.bias"].float()
+            b = self.state[f"model.24.m.{i}.bias"].float().to(w.dtype)
             x = F.conv2d(x, w, b)
             if self.taps is not None:
                 self.taps[f"model.24.m.{i}"] = x
             bs, _, ny, nx = x.shape
             x = x.view(bs, self.na, self.no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
-            yv, xv = torch.meshgrid(torch.arange(ny, dtype=torch.float32), torch.arange(nx, dtype=torch.float32),
-                                    indexing="ij")
+            yv, xv = torch.meshgrid(torch.arange(ny, dtype=x.dtype), torch.arange(nx, dtype=x.dtype), indexing="ij")
             grid = torch.stack((xv, yv), 2).expand(1, self.na, ny, nx, 2) - 0.5
-            anchor_grid = (self.anchors[i] * self.stride[i]).view(1, self.na, 1, 1, 2).expand(1, self.na, ny, nx, 2)
+            anchor_grid = (self.anchors[i] * self.stride[i]).to(x.dtype).view(1, self.na, 1, 1, 2).expand(1, self.na, ny, nx, 2)
             xy, wh, conf = x.sigmoid().split((2, 2, self.nc + 1), 4)
             xy = (xy * 2 + grid) * self.stride[i]
             wh = (wh * 2) ** 2 * anchor_grid

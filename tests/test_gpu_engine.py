@@ -113,10 +113,12 @@ def test_nms_kernel_bitexact_on_oracle_pred(lib, synth_ck, tiles_640):
 def test_infer_bf16_close_to_emulated_oracle(lib, synth_ck, tiles_640):
     """bf16 engine vs an oracle that rounds weights/activations to bf16 at the same points.
 
-    Measured on MI355X (round 1): |d conf| mean 6.8e-3, p99.9 4.9e-2, max 8.8e-2; |d box| mean 0.68 px;
-    post-NMS counts 312/363/348 vs 313/357/346.  The seeded synthetic checkpoint amplifies tiny spatial
-    feature variations ~60x in its calibrated head, so single-ulp bf16 rounding flips (summation order)
-    show up at this level; the fp32 mode is the 1e-4 parity gate, this test bounds what bf16 costs."""
+    Measured on MI355X (rounds 1 and 2): |d conf| mean 6.8e-3, p99.9 4.9e-2, max 8.8e-2; |d box| mean 0.68 px;
+    post-NMS counts 312/363/348 vs 313/357/346.  tests/test_gpu_bf16_deviation.py shows where it comes from: module by
+    module, for every kernel selection, the engine deviates from an fp64-accumulation oracle by 0.6-1.04x what
+    fp32-vs-fp64 accumulation alone causes inside the oracle (profiles/r02_bf16_deviation.json) -- accumulation-order
+    noise re-rounded to bf16 layer after layer and amplified by the synthetic head, not a kernel's own error.  The
+    bounds below are 1.5x the measured values; the fp32 mode is the 1e-4 parity gate."""
     from oracle import yolov5_oracle as O
     eng = _engine(synth_ck, "bf16")
     m = O.model_from_checkpoint(synth_ck, O.q_bf16)
@@ -124,13 +126,13 @@ def test_infer_bf16_close_to_emulated_oracle(lib, synth_ck, tiles_640):
     t = torch.from_numpy(tiles_640).cuda()
     pred = eng.forward_raw(t).cpu()
     d_conf = (pred[..., 4:] - ref[..., 4:]).abs().flatten()
-    assert d_conf.mean().item() <= 2e-2
-    assert d_conf.kthvalue(int(0.999 * d_conf.numel()))[0].item() <= 0.15
-    assert (pred[..., :4] - ref[..., :4]).abs().mean().item() <= 2.0
+    assert d_conf.mean().item() <= 1.04e-2
+    assert d_conf.kthvalue(int(0.999 * d_conf.numel()))[0].item() <= 7.3e-2
+    assert (pred[..., :4] - ref[..., :4]).abs().mean().item() <= 1.02
     ref_counts = [r.shape[0] for r in O.non_max_suppression(ref.numpy())]
     _, counts = eng.infer(t)
     for got, want in zip(counts.cpu().tolist(), ref_counts):
-        assert abs(got - want) <= max(3, 0.05 * want)
+        assert abs(got - want) <= 8            # measured: at most 5 of ~340 boxes per tile over the 16 golden tiles
 
 
 def test_infer_deterministic(lib, synth_ck, tiles_640):
