@@ -148,3 +148,79 @@ int ref_format_label(const float* row6, char* buf, int buflen) {
     return snprintf(buf, (size_t)buflen, "%g %g %g %g %g %g", (double)row6[0], (double)row6[1], (double)row6[2],
                     (double)row6[3], (double)row6[4], (double)row6[5]);
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Letterbox of the real 1024 x 1024 tiles (reference src/load_data/tile_tifs.py:13, src/utils.py:18-19) to the 640-px network input:
+ * [UPSTREAM utils/augmentations.py letterbox] = cv2.resize(im, new_unpad, interpolation=cv2.INTER_LINEAR) + cv2.copyMakeBorder(114).
+ * cv2 is not installed in this image, so what follows restates OpenCV's 8-bit bilinear resize from its published algorithm
+ * (modules/imgproc/src/resize.cpp, resizeGeneric_ with HResizeLinear / VResizeLinear<uchar, int, short, FixedPtCast>):
+ *   source coordinate  f = (d + 0.5) * (src / dst) - 0.5 computed in float, s = floor(f), f -= s;
+ *                      s < 0 -> (s, f) = (0, 0);  s >= src - 1 -> (s, f) = (src - 1, 0)
+ *   coefficients       short w1 = cvRound(f * 2048), w0 = cvRound((1 - f) * 2048)       (round half to even, fp32 products)
+ *   horizontal pass    int   row[x] = S[s] * w0 + S[s + 1] * w1                          (scale 2^11)
+ *   vertical pass      uchar dst = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2
+ * UNPINNED against OpenCV itself (none available); pinned against regressions by tests/golden/g9_letterbox.json. */
+static void ref_axis_coeffs(int src, int dst, int* s0, int* s1, int* w0, int* w1) {
+    const double scale = (double)src / (double)dst;
+    for (int d = 0; d < dst; ++d) {
+        float f = (float)(((double)d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (s < 0) { s = 0; f = 0.f; }
+        if (s >= src - 1) { s = src - 1; f = 0.f; }
+        s0[d] = s;
+        s1[d] = s + 1 < src ? s + 1 : src - 1;
+        w1[d] = (int)nearbyintf(f * 2048.f);
+        w0[d] = (int)nearbyintf((1.f - f) * 2048.f);
+    }
+}
+
+void ref_resize_linear_u8(const uint8_t* src, int h, int w, int c, uint8_t* dst, int nh, int nw) {
+    int* xs0 = (int*)malloc(sizeof(int) * 4 * (size_t)nw);
+    int* ys0 = (int*)malloc(sizeof(int) * 4 * (size_t)nh);
+    int *xs1 = xs0 + nw, *xa0 = xs1 + nw, *xa1 = xa0 + nw;
+    int *ys1 = ys0 + nh, *yb0 = ys1 + nh, *yb1 = yb0 + nh;
+    ref_axis_coeffs(w, nw, xs0, xs1, xa0, xa1);
+    ref_axis_coeffs(h, nh, ys0, ys1, yb0, yb1);
+    for (int y = 0; y < nh; ++y) {
+        const uint8_t* r0 = src + (size_t)ys0[y] * w * c;
+        const uint8_t* r1 = src + (size_t)ys1[y] * w * c;
+        for (int x = 0; x < nw; ++x)
+            for (int k = 0; k < c; ++k) {
+                const int h0 = r0[xs0[x] * c + k] * xa0[x] + r0[xs1[x] * c + k] * xa1[x];
+                const int h1 = r1[xs0[x] * c + k] * xa0[x] + r1[xs1[x] * c + k] * xa1[x];
+                int v = (((yb0[y] * (h0 >> 4)) >> 16) + ((yb1[y] * (h1 >> 4)) >> 16) + 2) >> 2;
+                dst[((size_t)y * nw + x) * c + k] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+    }
+    free(xs0);
+    free(ys0);
+}
+
+/* [UPSTREAM letterbox] geometry: out = {new_w, new_h, top, bottom, left, right}.  Python's round() is half-to-even = nearbyint. */
+void ref_letterbox_geometry(int h, int w, int new_h, int new_w, int auto_, int scaleup, int stride, int* out) {
+    double r = fmin((double)new_h / h, (double)new_w / w);
+    if (!scaleup) r = fmin(r, 1.0);
+    const int uw = (int)nearbyint(w * r), uh = (int)nearbyint(h * r);
+    double dw = new_w - uw, dh = new_h - uh;
+    if (auto_) { dw = fmod(dw, stride); dh = fmod(dh, stride); }
+    dw /= 2; dh /= 2;
+    out[0] = uw; out[1] = uh;
+    out[2] = (int)nearbyint(dh - 0.1); out[3] = (int)nearbyint(dh + 0.1);
+    out[4] = (int)nearbyint(dw - 0.1); out[5] = (int)nearbyint(dw + 0.1);
+}
+
+/* letterbox(im, new_shape, auto, scaleup, stride): returns the output size through out_hw; dst may be NULL to query it. */
+void ref_letterbox_u8(const uint8_t* src, int h, int w, int new_h, int new_w, int auto_, int scaleup, int stride, uint8_t* dst, int* out_hw) {
+    int g[6];
+    ref_letterbox_geometry(h, w, new_h, new_w, auto_, scaleup, stride, g);
+    const int H = g[1] + g[2] + g[3], W = g[0] + g[4] + g[5];
+    out_hw[0] = H; out_hw[1] = W;
+    if (!dst) return;
+    memset(dst, 114, (size_t)H * W * 3);
+    uint8_t* tmp = (uint8_t*)malloc((size_t)g[0] * g[1] * 3);
+    if (g[0] != w || g[1] != h) ref_resize_linear_u8(src, h, w, 3, tmp, g[1], g[0]);
+    else memcpy(tmp, src, (size_t)h * w * 3);
+    for (int y = 0; y < g[1]; ++y) memcpy(dst + ((size_t)(y + g[2]) * W + g[4]) * 3, tmp + (size_t)y * g[0] * 3, (size_t)g[0] * 3);
+    free(tmp);
+}

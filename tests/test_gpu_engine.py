@@ -203,16 +203,35 @@ def test_full_batch_is_batch_invariant(lib, synth_ck):
         assert torch.equal(d4[b, :c4[b]], d64[b, :c64[b]])
 
 
+def _oracle_letterbox(im):
+    """oracle/ref_kernels.c ref_letterbox_u8: the scalar C restatement of OpenCV's 8-bit INTER_LINEAR resize + border 114."""
+    import ctypes as C
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle")], check=True)
+    cl = C.CDLL(os.path.join(root, "oracle", "_build", "libref_kernels.so"))
+    im = np.ascontiguousarray(im)
+    hw = (C.c_int * 2)()
+    u8 = C.POINTER(C.c_uint8)
+    cl.ref_letterbox_u8(im.ctypes.data_as(u8), im.shape[0], im.shape[1], 640, 640, 1, 1, 32, None, hw)
+    out = np.empty((hw[0], hw[1], 3), np.uint8)
+    cl.ref_letterbox_u8(im.ctypes.data_as(u8), im.shape[0], im.shape[1], 640, 640, 1, 1, 32, out.ctypes.data_as(u8), hw)
+    return out
+
+
 @pytest.mark.parametrize("shape", [(1024, 1024), (640, 640), (500, 700), (1000, 600), (320, 480)])
-def test_device_letterbox_is_bit_exact_with_host_restatement(lib, shape):
-    """aq_letterbox_u8 vs dataloader.letterbox (numpy restatement of cv2.resize INTER_LINEAR + border 114): identical bytes.
-    (Both are unpinned against OpenCV itself: none is installed.)"""
+def test_device_letterbox_is_bit_exact_with_the_oracle(lib, shape):
+    """aq_letterbox_u8 vs the C oracle (oracle/ref_kernels.c ref_letterbox_u8, OpenCV's fixed-point INTER_LINEAR restated as scalar
+    loops + border 114): identical bytes; the product's host restatement (dataloader.letterbox) is held to the same oracle.
+    (The oracle is unpinned against OpenCV itself: none is installed; tests/golden/g9_letterbox.json pins it against regressions.)"""
     from aquaculture_amd import dataloader, engine
     rng = np.random.default_rng(shape[0] * 7 + shape[1])
     ims = rng.integers(0, 256, (3,) + shape + (3,), dtype=np.uint8)
-    want = np.stack([dataloader.letterbox(im) for im in ims], 0)
+    want = np.stack([_oracle_letterbox(im) for im in ims], 0)
     got = engine.letterbox_device(torch.from_numpy(ims).cuda()).cpu().numpy()
     assert got.shape == want.shape and np.array_equal(got, want)
+    assert np.array_equal(dataloader.letterbox(ims[0]), want[0])
 
 
 @pytest.mark.parametrize("shape,batch", [((384, 640), 1), ((640, 384), 3), ((32, 32), 2), ((96, 160), 5)])

@@ -141,3 +141,36 @@ def test_oracle_bf16_model_differs_only_by_rounding(synth_ck):
     b = O.model_from_checkpoint(synth_ck, O.q_bf16).forward(x)
     d = (a[..., 4:] - b[..., 4:]).abs()
     assert 0 < d.max() < 0.2 and d.mean() < 0.02
+
+
+def test_letterbox_oracle_matches_its_golden_fixture_and_the_host_restatement():
+    """oracle/ref_kernels.c ref_letterbox_u8 (OpenCV 8-bit INTER_LINEAR + border 114, restated; cv2 is not installed, so UNPINNED against
+    OpenCV) reproduces tests/golden/g9_letterbox.json, and the product's numpy restatement (aquaculture_amd/dataloader.py letterbox, used
+    by the CLI's generic path) agrees with it byte for byte on the fixture's cases and on odd sizes."""
+    import hashlib
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_letterbox_golden as G
+    from aquaculture_amd import dataloader
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_build", "libref_kernels.so"))
+    with open(os.path.join(GOLD, "g9_letterbox.json")) as f:
+        gold = json.load(f)
+    assert len(gold["cases"]) >= 5
+    for case in gold["cases"]:
+        im = G.seeded_image(case["h"], case["w"])
+        assert hashlib.sha256(im.tobytes()).hexdigest() == case["input_sha256"]
+        lb = G.oracle_letterbox(lib, im)
+        assert list(lb.shape) == case["out_shape"] and hashlib.sha256(lb.tobytes()).hexdigest() == case["sha256"]
+        for y, x, px in case["samples"]:
+            assert lb[y, x].tolist() == px
+        assert np.array_equal(dataloader.letterbox(im), lb)
+    for h, w in ((333, 777), (1024, 768), (31, 640), (641, 639)):
+        im = G.seeded_image(h, w)
+        assert np.array_equal(dataloader.letterbox(im), G.oracle_letterbox(lib, im)), (h, w)
+    # geometry restatement: [UPSTREAM letterbox] new_unpad and padding, half-to-even rounding included
+    g = (C.c_int * 6)()
+    for (h, w) in ((1024, 1024), (500, 700), (1000, 600), (97, 33), (720, 1280)):
+        lib.ref_letterbox_geometry(h, w, 640, 640, 1, 1, 32, g)
+        (nw, nh), (top, bottom, left, right) = dataloader.letterbox_geometry((h, w), (640, 640), True, True, 32)
+        assert list(g) == [nw, nh, top, bottom, left, right]
