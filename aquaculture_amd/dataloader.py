@@ -117,13 +117,19 @@ class LoadImages:
     keeps images ``i % world == rank`` (strided tile shard, one process per GPU)."""
 
     def __init__(self, source: str, img_size=640, stride=32, auto=True, shard: Tuple[int, int] = (0, 1), workers: int = 8,
-                 raw: bool = False):
-        """``raw``: yield the decoded image as is (the caller letterboxes on the device)."""
+                 raw: bool = False, skip_stems=None):
+        """``raw``: yield the decoded image as is (the caller letterboxes on the device).  ``skip_stems``: tiles a previous run of
+        the sweep has finished (manifest.DoneManifest); they keep their place in the global numbering and are simply not loaded."""
         self.raw = raw
         files = list_images(source)
         self.total = len(files)
         rank, world = shard
         self.indices = list(range(rank, len(files), world))
+        self.skipped = 0
+        if skip_stems:
+            keep = [i for i in self.indices if Path(files[i]).stem not in skip_stems]
+            self.skipped = len(self.indices) - len(keep)
+            self.indices = keep
         self.files = [files[i] for i in self.indices]
         self.img_size = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
         self.stride, self.auto = stride, auto
@@ -131,6 +137,24 @@ class LoadImages:
 
     def __len__(self):
         return len(self.files)
+
+    def scan_sizes(self) -> List[Tuple[int, int]]:
+        """(width, height) of every image of this shard from its header (no decode), in file order."""
+        from PIL import Image
+
+        def size(path):
+            with Image.open(path) as im:
+                return im.size
+        with ThreadPoolExecutor(self.workers) as ex:
+            return list(ex.map(size, self.files))
+
+    def subset(self, positions: Sequence[int]) -> "LoadImages":
+        """The same dataset restricted to some of its files (positions into ``files``); global indices travel with them."""
+        import copy
+        sub = copy.copy(self)
+        sub.files = [self.files[i] for i in positions]
+        sub.indices = [self.indices[i] for i in positions]
+        return sub
 
     def load(self, path: str):
         im0 = read_rgb(path)

@@ -90,6 +90,9 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
     p.add_argument("--autotune", choices=("auto", "on", "off"), default="auto",
                    help="time the conv kernels' tile configurations on the first full batch and keep the fastest per layer "
                         "(cached in $AQ_TUNE_CACHE or ~/.cache/aquaculture_amd/); auto = only for sweeps of >= 8 batches per GPU")
+    p.add_argument("--resume", action="store_true",
+                   help="continue an interrupted sweep in project/name (implies --exist-ok): tiles recorded in the run directory's "
+                        "done.rank*.txt manifests are skipped, also those that produced no label file")
     p.add_argument("--tile-scenes", nargs="?", type=int, const=1024, default=0, metavar="TILESIZE",
                    help="opt-in scene mode: --source holds whole scene rasters (*.tif); they are cut into TILESIZE (default 1024) tiles "
                         "on the GPU, in the order and with the names of reference src/load_data/tile_tifs.py, skipping its jpeg step")
@@ -101,7 +104,8 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
 def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_det=1000, device="",
         save_txt=False, save_conf=False, nosave=False, classes=None, agnostic_nms=False,
         project="runs/detect", name="exp", exist_ok=False, half=False, batch_size=64, precision=None,
-        workers=8, decode_threads=False, quiet=False, geocode_bboxes=None, geocode_out=None, tile_scenes=0, autotune="auto", log=print, **unsupported):
+        workers=8, decode_threads=False, quiet=False, geocode_bboxes=None, geocode_out=None, tile_scenes=0, autotune="auto", resume=False,
+        log=print, **unsupported):
     from .engine import Engine, format_label_rows, letterbox_device, letterbox_scene_tiles   # raises if the HIP library or the GPU is missing: there is no fallback
 
     for k in UNSUPPORTED:
@@ -119,14 +123,23 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     torch.cuda.set_device(dev)
 
     # directories: rank 0 picks the run directory, everyone uses it
+    if resume and tile_scenes:
+        raise NotImplementedError("--resume works on tile directories (the manifest records tile names), not with --tile-scenes")
     if rank == 0:
-        save_dir = increment_path(Path(project) / name, exist_ok=exist_ok)
+        save_dir = increment_path(Path(project) / name, exist_ok=exist_ok or resume)
         (save_dir / "labels" if save_txt else save_dir).mkdir(parents=True, exist_ok=True)
     if world > 1:
         box = [str(save_dir) if rank == 0 else None]
         torch.distributed.broadcast_object_list(box, src=0)
         save_dir = Path(box[0])
     labels_dir = str(save_dir / "labels")
+    # done-manifest: every rank records the tiles it has finished (fsync'd per batch); --resume skips what ANY rank of the
+    # interrupted run recorded (reference idiom: skip-if-exists, src/load_data/tile_tifs.py:40-41 -- which label files cannot express)
+    from .manifest import DoneManifest
+    done_before = DoneManifest.load(str(save_dir)) if resume else set()
+    manifest = DoneManifest(str(save_dir), rank)
+    if not tile_scenes:
+        manifest.open()
 
     ck = load_checkpoint(weights)
     eng = Engine(ck, precision, dev)
@@ -136,7 +149,10 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         from .scenes import SceneTiles
         dataset = SceneTiles(source, tilesize=int(tile_scenes), shard=(rank, world), workers=workers, batch_size=batch_size, pinned=True)
     else:
-        dataset = LoadImages(source, img_size=imgsz, stride=int(max(ck.stride)), auto=True, shard=(rank, world), workers=workers, raw=True)
+        dataset = LoadImages(source, img_size=imgsz, stride=int(max(ck.stride)), auto=True, shard=(rank, world), workers=workers, raw=True,
+                             skip_stems=done_before)
+        if resume:
+            log(f"resume: {len(done_before)} tiles recorded as done in {save_dir}; rank {rank} skips {dataset.skipped} of its share")
 
     # Pipeline: decode threads -> [main thread: H2D, letterbox, engine, async D2H] -> [writer thread: rescale, format, files].
     # Up to `depth` batches are in flight, each with its own workspace slot, pinned result buffers and stream.
@@ -170,7 +186,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                     ndet += det.shape[0]
                     rows = postprocess.detections_to_rows(det, (H, W), shapes0[b])
                     if save_txt and rows.shape[0]:       # no detections => no file (the consumer relies on it)
-                        with open(os.path.join(labels_dir, Path(p).stem + ".txt"), "ab") as f:
+                        with open(os.path.join(labels_dir, Path(p).stem + ".txt"), "wb") as f:     # "wb": a tile processed again after a crash leaves the same bytes
                             f.write(format_label_rows(rows, save_conf))
                         nlab += 1
                     if not quiet:
@@ -181,6 +197,9 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                         with gather_lock:
                             gather.add(torch.full((det.shape[0],), gidx[b], dtype=torch.int32), aqdist.pack_rows(torch.from_numpy(det.copy())))
                 slot_free[slot_id].release()
+                if not tile_scenes:
+                    with manifest_lock:
+                        manifest.add(Path(p).stem for p in paths)      # the batch's label files are closed: durable from here on
                 with lock:
                     stats["seen"] += len(paths)
                     stats["labels"] += nlab
@@ -195,6 +214,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                     return
 
     lock = threading.Lock()
+    manifest_lock = threading.Lock()
     n_writers = 4 if quiet else 1          # per-image log lines stay in order with a single writer
     depth_q = depth
     wts = [threading.Thread(target=writer, daemon=True) for _ in range(n_writers)]
@@ -205,15 +225,6 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     shape_str = ""
     pinned = [None] * depth
     k = 0
-    def batch_source():
-        """Uniform tile directories (the reference's case): zero-copy pinned batches; mixed sizes: the generic path."""
-        try:
-            for item in dataset.pinned_batches(batch_size, depth + 1, processes=0 if decode_threads else None):
-                yield item
-        except ValueError as e:
-            log(f"note: {e}")
-            raise
-
     def scene_source():
         """Scene mode: (tile names, ("scene", path, raster, origins, (h, w)), shapes, None, global tile indices) per batch."""
         for path, arr, stems, origins, hw, gids in dataset.batches():
@@ -221,27 +232,44 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
             yield names, ("scene", path, arr, origins, hw), [hw] * len(stems), None, gids
 
     def image_source():
-        try:
-            from PIL import Image
-            with Image.open(dataset.files[0]) as _im0:
-                _size0 = _im0.size
-            uniform = all(Image.open(f).size == _size0 for f in dataset.files[:: max(1, len(dataset.files) // 16)])
-        except Exception:
-            uniform = False
-        it = batch_source() if uniform and len(dataset) else ((p_, torch.from_numpy(b_).pin_memory(), s_, None)
-                                                              for p_, b_, s_ in dataset.batches(batch_size))
-        n_ = 0
-        for p_, h_, s_, bi_ in it:
-            yield p_, h_, s_, bi_, dataset.indices[n_: n_ + len(p_)]
-            n_ += len(p_)
+        """Every header is read once (no decode): the images of the most common size take the zero-copy pinned path, any others
+        (the reference's tiler cuts smaller edge tiles for scenes that are not a multiple of 1024, src/load_data/tile_tifs.py:35-36)
+        follow through the generic path, grouped by size -- a stray size can no longer end the sweep half way."""
+        parts = []
+        if len(dataset):
+            try:
+                sizes = dataset.scan_sizes()
+                common = max(set(sizes), key=sizes.count)
+                main = [i for i, sz in enumerate(sizes) if sz == common]
+                odd = [i for i, sz in enumerate(sizes) if sz != common]
+            except Exception as e:                       # unreadable header: let the generic path report the file
+                log(f"note: header scan failed ({e}); using the generic loader")
+                main, odd = [], list(range(len(dataset)))
+            if main:
+                parts.append((dataset.subset(main), True))
+            if odd:
+                log(f"note: {len(odd)} of {len(dataset)} images differ in size from the rest; they take the generic loader")
+                parts.append((dataset.subset(sorted(odd, key=lambda i: (sizes[i] if main else (0, 0), i))), False))
+        for sub, fast in parts:
+            if fast:
+                gen = sub.pinned_batches(batch_size, depth + 1, processes=0 if decode_threads else None)
+                release_of[0] = lambda i, sub=sub: sub.release(i)
+                it = gen
+            else:
+                it = ((p_, torch.from_numpy(b_).pin_memory(), s_, None) for p_, b_, s_ in sub.batches(batch_size))
+            n_ = 0
+            for p_, h_, s_, bi_ in it:
+                yield p_, h_, s_, bi_, sub.indices[n_: n_ + len(p_)]
+                n_ += len(p_)
 
+    release_of = [None]
     source_iter = scene_source() if tile_scenes else image_source()
     scene_dev, scene_path, scene_ev = None, None, None
     # Autotune on the first full batch (rank 0 times, every rank installs the same table: identical kernels on all GPUs of a run).
     per_rank = dataset.total // max(world, 1)
     tune = autotune == "on" or (autotune == "auto" and per_rank >= 8 * batch_size)
-    if tune and world > 1 and (dataset.n_scenes_total if tile_scenes else dataset.total) < world:
-        tune = False                                   # some rank has no batch to meet the broadcast with
+    if tune and world > 1 and ((dataset.n_scenes_total if tile_scenes else dataset.total) < world or resume):
+        tune = False                                   # some rank may have no batch to meet the broadcast with
     tune_cache = os.environ.get("AQ_TUNE_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "aquaculture_amd", "tune.json")
     copy_done = []
     for paths, host, shapes0, buf_i, gidx in source_iter:
@@ -300,7 +328,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         while copy_done and (copy_done[0][0].query() or len(copy_done) > depth):
             ev_, bi_ = copy_done.pop(0)
             ev_.synchronize()
-            dataset.release(bi_)
+            (release_of[0] or dataset.release)(bi_)
         t_pre += t1 - t0
         t_inf += t2 - t1
         k += 1
@@ -340,6 +368,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
             out = geocode_out or str(save_dir / "detections.geojson")
             table = geocode.geocode_label_dir(labels_dir, geocode_bboxes, out)
             log(f"{table['image'].shape[0]} detections geocoded to {out} in {time.perf_counter() - t_g:.2f}s")
+    manifest.close()
     eng.close()
     return save_dir
 

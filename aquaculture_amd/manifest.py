@@ -1,0 +1,58 @@
+"""Done-manifest of a tile sweep: which tiles have been fully processed, so that a restarted sweep skips them.
+
+The reference's only recovery mechanism is skip-if-exists on its outputs (reference src/load_data/tile_tifs.py:40-41, :73).  That
+idiom does not carry over to the label files of detect.py: a tile WITHOUT detections gets no file (the consumer relies on it,
+reference src/process_yolo/geocode_results.py:123), so the label directory cannot say whether such a tile was processed.  Each rank
+therefore appends the names of the tiles it has finished (label file written and closed, or known to have none) to its own text file
+in the run directory, fsync'd once per batch; `--resume` reads every rank's file (the world size may differ between the two runs) and
+drops those tiles from the listing before sharding.  A record is one line = one tile stem; a line cut short by a crash (no trailing
+newline) is ignored, so a tile is either recorded after its label file is complete or processed again (label files are written with
+"wb": processing a tile twice leaves the same bytes).
+"""
+from __future__ import annotations
+
+import glob
+import os
+from typing import Iterable, Set
+
+
+class DoneManifest:
+    def __init__(self, directory: str, rank: int = 0):
+        self.directory = directory
+        self.path = os.path.join(directory, f"done.rank{rank}.txt")
+        self._f = None
+
+    def open(self) -> None:
+        os.makedirs(self.directory, exist_ok=True)
+        if os.path.exists(self.path):          # a crash may have left a record cut short: drop it (a truncated name could be another tile's)
+            with open(self.path, "r+b") as r:
+                data = r.read()
+                r.truncate(data.rfind(b"\n") + 1)
+        self._f = open(self.path, "ab")
+
+    def add(self, stems: Iterable[str]) -> None:
+        """One batch: durable when this returns (the label files of these tiles must be closed before the call)."""
+        data = "".join(s + "\n" for s in stems).encode()
+        if not data:
+            return
+        self._f.write(data)
+        self._f.flush()
+        os.fsync(self._f.fileno())
+
+    def close(self) -> None:
+        if self._f is not None:
+            self._f.close()
+            self._f = None
+
+    @staticmethod
+    def load(directory: str) -> Set[str]:
+        """Union over every rank's manifest in ``directory``; ignores a trailing record without its newline."""
+        done: Set[str] = set()
+        for path in sorted(glob.glob(os.path.join(directory, "done.rank*.txt"))):
+            with open(path, "rb") as f:
+                data = f.read()
+            end = data.rfind(b"\n")
+            if end < 0:
+                continue
+            done.update(line for line in data[:end].decode(errors="replace").split("\n") if line)
+        return done

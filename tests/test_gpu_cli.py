@@ -235,3 +235,57 @@ def test_cli_autotune_keeps_the_labels(workdir, lib, tmp_path):
         near = d.min(1)
         assert near.max() <= 2.0 / 640 + 1e-4 and (near <= 1e-4).mean() >= 0.99, (f, near.max(), (near <= 1e-4).mean())
         assert open(on1 / f).read() == open(on2 / f).read()          # cached table = the same kernels again
+
+
+def test_cli_resume_skips_recorded_tiles(workdir, lib):
+    """`--resume` (missing item 4): a sweep whose manifests record part of the tiles -- here: a first run over a
+    directory holding only some of them, then a crash-cut record -- processes exactly the rest, and the label directory ends up
+    byte-identical to an uninterrupted sweep's.  Tiles without detections are skipped too (no label file says so; the manifest does)."""
+    import shutil
+    full_out, full = _run(workdir, "resume_full", extra=("--quiet",))
+    part = workdir / "jpegs_part"
+    part.mkdir(exist_ok=True)
+    names = sorted(os.listdir(workdir / "jpegs"))
+    for n in names[:6]:
+        shutil.copy(workdir / "jpegs" / n, part / n)
+    cmd = [sys.executable, os.path.join(ROOT, "yolov5", "detect.py"), "--weights", str(workdir / "multilabel_farms_synth.pt"),
+           "--source", str(part), "--nosave", "--save-txt", "--save-conf", "--project", str(workdir / "runs"), "--name", "resume_run", "--batch-size", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run = workdir / "runs" / "resume_run"
+    recorded = open(run / "done.rank0.txt").read().split()
+    assert sorted(recorded) == sorted(n[:-5] for n in names[:6])
+    with open(run / "done.rank0.txt", "ab") as f:
+        f.write(names[7][:-5].encode()[:-3])                 # a record cut short by a crash: must not count
+    out, labels = _run(workdir, "resume_run", extra=("--resume",))
+    assert f"skips 6 of its share" in out
+    processed = [l for l in out.splitlines() if l.startswith("image ")]
+    assert len(processed) == len(names) - 6 and not any(n[:-5] in l for l in processed for n in names[:6])
+    assert sorted(os.listdir(labels)) == sorted(os.listdir(full))
+    for f in os.listdir(full):
+        assert open(labels / f, "rb").read() == open(full / f, "rb").read(), f
+    assert sorted(open(run / "done.rank0.txt").read().split()) == sorted(n[:-5] for n in names)
+
+
+def test_cli_mixed_tile_sizes_do_not_end_the_sweep(tmp_path, lib, workdir):
+    """More than 17 tiles of one size plus one smaller edge tile (the reference's tiler cuts those for scenes that are not a multiple of
+    1024, reference src/load_data/tile_tifs.py:35-36), placed where a sampled size check does not look: every tile gets processed, the
+    odd one through the generic loader (the sweep used to abort midway with label files half written)."""
+    from PIL import Image
+    from aquaculture_amd import tiles
+    d = tmp_path / "mixed"
+    d.mkdir()
+    idx = list(range(40, 60))
+    tiles.write_synthetic_jpegs(str(d), idx, size=256)
+    names = sorted(os.listdir(d))
+    victim = names[11]                                        # not a multiple of len // 16: a sampling check misses it
+    im = Image.open(d / victim)
+    im.crop((0, 0, 160, 224)).save(d / victim, quality=90)
+    cmd = [sys.executable, os.path.join(ROOT, "yolov5", "detect.py"), "--weights", str(workdir / "multilabel_farms_synth.pt"), "--source", str(d),
+           "--nosave", "--save-txt", "--save-conf", "--project", str(tmp_path / "runs"), "--name", "mixed", "--batch-size", "8", "--imgsz", "256"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    assert "1 of 20 images differ in size" in r.stdout and "20 images," in r.stdout
+    processed = [l for l in r.stdout.splitlines() if l.startswith("image ")]
+    assert len(processed) == 20 and any(victim in l and "256x192" in l for l in processed)      # 224 x 160 letterboxed for --imgsz 256
+    assert sorted(open(tmp_path / "runs" / "mixed" / "done.rank0.txt").read().split()) == sorted(n[:-5] for n in names)
