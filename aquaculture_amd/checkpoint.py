@@ -220,11 +220,23 @@ class PackedConv:
     bias: np.ndarray     # float32 (cout,)
 
 
-def pack_plan_weights(ck: Checkpoint, plan: _spec.Plan) -> List[PackedConv]:
+def pack_plan_weights(ck: Checkpoint, plan: _spec.Plan, weight_format: str = "native") -> List[PackedConv]:
+    """``weight_format`` "fp8": every convolution's fused weights (not the Detect head's) are replaced by their OCP e4m3fn
+    quantisation with one power-of-two scale per output channel (quant.py) -- values that bf16 holds exactly, so the bf16 engine
+    computes the fp8-weight model (BASELINE.json configs[3]) with its ordinary kernels."""
+    from . import quant as _quant
+    assert weight_format in ("native", "fp8")
+
+    def wq(w: torch.Tensor) -> torch.Tensor:
+        if weight_format != "fp8":
+            return w
+        return torch.from_numpy(_quant.quantize_rows(w.numpy())[0])
+
     packed = []
     for op in plan.conv_ops():
         if op.kind == _spec.OP_DOWNBLOCK:    # wa = model.N (96,3,3,48) then wb = stacked cv1|cv2 (96,1,1,96), KRSC, back to back; bias ba | bb
             (wa, ba), (w1, b1), (w2, b2) = (fuse_conv_bn(ck.state, key, ck.bn_eps) for key in op.weight_keys)
+            wa, w1, w2 = wq(wa), wq(w1), wq(w2)
             wb, bb = torch.cat([w1, w2], 0), torch.cat([b1, b2], 0)
             assert tuple(wa.shape) == (96, 48, 3, 3) and tuple(wb.shape) == (96, 96, 1, 1), (op.name, wa.shape, wb.shape)
             flat = torch.cat([wa.permute(0, 2, 3, 1).reshape(-1), wb.permute(0, 2, 3, 1).reshape(-1)])
@@ -233,6 +245,7 @@ def pack_plan_weights(ck: Checkpoint, plan: _spec.Plan) -> List[PackedConv]:
             continue
         if op.kind == _spec.OP_BOTTLENECK:   # cv1 (C,1,1,C) then cv2 (C,3,3,C), KRSC, flattened back to back; bias b1 | b2
             (w1, b1), (w2, b2) = (fuse_conv_bn(ck.state, key, ck.bn_eps) for key in op.weight_keys)
+            w1, w2 = wq(w1), wq(w2)
             c_ = op.src.channels
             assert tuple(w1.shape) == (c_, c_, 1, 1) and tuple(w2.shape) == (c_, c_, 3, 3), (op.name, w1.shape, w2.shape)
             flat = torch.cat([w1.permute(0, 2, 3, 1).reshape(-1), w2.permute(0, 2, 3, 1).reshape(-1)])
@@ -245,6 +258,7 @@ def pack_plan_weights(ck: Checkpoint, plan: _spec.Plan) -> List[PackedConv]:
                 w, b = ck.state[f"{key}.weight"].float(), ck.state[f"{key}.bias"].float()
             else:
                 w, b = fuse_conv_bn(ck.state, key, ck.bn_eps)
+                w = wq(w)
             if op.meta.get("stem_s2d"):
                 w = stem_to_s2d(w)
             ws.append(w)

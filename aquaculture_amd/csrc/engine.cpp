@@ -154,7 +154,10 @@ int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStr
     p.npix = B * pd.h * pd.w;
     p.act = op.act;
     int cfg = force_cfg >= 0 ? force_cfg : e->conv_cfg[oi];
-    if (cfg < 0 && e->tuned_B == B && e->tuned_H == e->lay_H && e->tuned_W == e->lay_W) cfg = e->tuned_cfg[oi];
+    // The tuned table serves EVERY batch size of its tile geometry (a sweep's ragged last batch, a rank with fewer tiles): a kernel's
+    // accumulation order per output element does not depend on the batch, so a tile's result no longer depends on which batch it
+    // landed in (before, batches of another size fell back to the heuristic kernels and could round differently in bf16).
+    if (cfg < 0 && e->tuned_B > 0 && e->tuned_H == e->lay_H && e->tuned_W == e->lay_W) cfg = e->tuned_cfg[oi];
     if (cfg == AQ_CONV_CFG_DIRECT3X3S2) {
         if (pw.direct_cfg != cfg) { aq_set_error("conv op %d has no direct 3x3/s2 form", oi); return AQ_ERR_INVALID; }
         return aq_conv3x3s2_direct(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,

@@ -23,7 +23,9 @@ from . import spec as _spec
 from .checkpoint import Checkpoint, pack_plan_weights
 
 AQ_BF16, AQ_FP32 = 0, 1
-PRECISIONS = {"bf16": AQ_BF16, "fp32": AQ_FP32}
+PRECISIONS = {"bf16": AQ_BF16, "fp32": AQ_FP32, "fp8w": AQ_BF16}
+"""fp8w = fp8 (OCP e4m3fn) weights with per-output-channel power-of-two scales, bf16 activations (quant.py): values bf16 holds
+exactly, so the C engine runs it in its bf16 mode."""
 _DTYPE_CODE = {"act": 0, "f32": 1, "u8": 2}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaqengine.so")
@@ -162,14 +164,15 @@ class Engine:
         self.lib = load_library()
         self.ck = ck
         self.precision = PRECISIONS[precision]
+        self.precision_name = precision
         self.device = torch.device("cuda", device)
         if fused_bottleneck is None:
-            fused_bottleneck = precision == "bf16"
-        if fused_bottleneck and precision != "bf16":
+            fused_bottleneck = precision in ("bf16", "fp8w")
+        if fused_bottleneck and precision == "fp32":
             raise ValueError("the fused Bottleneck kernel is bf16 only")
         self.plan = _spec.build_plan(ck.variant, ck.nc, ck.na, fused_stem=fused_stem, fused_bottleneck=fused_bottleneck)
         self.no = ck.nc + 5
-        packed = pack_plan_weights(ck, self.plan)
+        packed = pack_plan_weights(ck, self.plan, "fp8" if precision == "fp8w" else "native")
         self._keep = packed   # host arrays must outlive aq_engine_create only, kept for debugging
         tens = (aq_tensor_desc * len(self.plan.tensors))()
         for i, t in enumerate(self.plan.tensors):

@@ -39,7 +39,8 @@ def parse():
     p.add_argument("--batch", type=int, default=64)
     p.add_argument("--size", type=int, default=640)
     p.add_argument("--variant", default="yolov5m")
-    p.add_argument("--precision", default="bf16", choices=("bf16", "fp32"))
+    p.add_argument("--precision", default="bf16", choices=("bf16", "fp32", "fp8w"),
+                   help="fp8w = BASELINE.json configs[3]: OCP e4m3 weights with per-channel power-of-two scales, bf16 activations and MFMA")
     p.add_argument("--pool", type=int, default=8, help="distinct synthetic batches kept in HBM and cycled (8 x 64 tiles = 629 MB of input, "
                                                        "beyond the 256 MB Infinity Cache)")
     p.add_argument("--roof-steps", type=int, default=10, help="steps of the single-stream HIP-event pass that feeds `roofline`")
@@ -115,7 +116,7 @@ def main() -> int:
 
     ck = checkpoint.synthetic_checkpoint(a.variant, 5)
     eng = Engine(ck, a.precision, local, fused_stem=not a.two_kernel_stem,
-                 fused_bottleneck=(a.precision == "bf16" and not a.two_kernel_bottleneck))
+                 fused_bottleneck=(a.precision in ("bf16", "fp8w") and not a.two_kernel_bottleneck))
     B, K, W = a.batch, a.steps, a.warmup
     tiles_dev = torch.from_numpy(make_tiles(rank, B, a.pool, a.size)).to(dev)
     max_det = 1000
@@ -196,7 +197,7 @@ def main() -> int:
         idxc = [i for i, o in enumerate(plan.ops) if o.kind in (spec.OP_CONV, spec.OP_STEM, spec.OP_BOTTLENECK, spec.OP_DOWNBLOCK)]
         t3 = float(ms[idx3].sum()) * 1e-3       # seconds per step in the 3x3 conv launches
         tc = float(ms[idxc].sum()) * 1e-3
-        peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_F32_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS      # fp8w: fp8 VALUES on the bf16 MFMA (quant.py), so the bf16 peak
         f3 = float(sum(plan.ops[i].flops_per_tile for i in idx3)) * B     # the 3x3 layers launched as implicit-GEMM convs
         idxb = [i for i, o in enumerate(plan.ops) if o.kind == spec.OP_BOTTLENECK]
         tb = float(ms[idxb].sum()) * 1e-3
@@ -237,7 +238,7 @@ def main() -> int:
             with open(os.path.join(ROOT, "aquaculture_amd", "csrc", "libaqengine.so.sha256")) as f:
                 digest = f.read().strip()
             same_cfgs = cfgs is None or not tj.get("conv3x3_configs") or any([int(cfgs[i]) for i in idx3] == v for v in tj["conv3x3_configs"].values())
-            if (a.variant == "yolov5m" and a.size == 640 and a.precision == "bf16" and int(tj.get("batch", -1)) == B
+            if (a.variant == "yolov5m" and a.size == 640 and a.precision in ("bf16", "fp8w") and int(tj.get("batch", -1)) == B
                     and tj.get("library_source_digest") == digest and same_cfgs):
                 traffic = tj.get("bytes_per_launch")
                 traffic_src = f"{os.path.relpath(a.traffic_json, ROOT)} (separate rocprofv3 --pmc pass of this library build {digest[:12]}, same tuned 3x3 kernels)"
@@ -264,10 +265,10 @@ def main() -> int:
                   else f"{a.size}px tiles/sec (whole node) {a.variant} {a.precision}",
         "value": round(value, 1), "unit": "tiles/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16 x fp8-e4m3 weights (bf16 MFMA)" if a.precision == "fp8w" else a.precision, "data": "synthetic",
         "config": {"workload": f"{a.variant} {a.precision}, 1xMI355X per rank, batch={B}, synthetic {a.size}x{a.size} ocean tiles "
                                f"resident in HBM ({a.pool} distinct batches cycled), seeded random-init weights nc=5 "
-                               f"(BASELINE.json configs[1])",
+                               f"(BASELINE.json configs[{3 if a.precision == 'fp8w' else 1}])",
                    "batch_per_gpu": B, "tile_px": a.size, "parallelism": f"tile-sharded dp{world}", "batches_in_flight": a.streams,
                    "detections_gathered": n_dets_total},
         "roofline": roof,

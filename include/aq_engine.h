@@ -123,8 +123,9 @@ int aq_engine_autotune(aq_engine* e, const uint8_t* tiles_dev, int B, int H, int
                        void* workspace_dev, size_t workspace_bytes, int reps, void* stream);
 int aq_engine_get_conv_config(aq_engine* e, int op);
 /* Install a table that aq_engine_autotune produced earlier (or on another rank) for the SAME engine and (B,H,W): cfgs[n_ops], one id per
- * op as aq_engine_get_conv_config returns them (-1 for ops that are not tuned).  Used only for batches of exactly that geometry; other
- * geometries keep the built-in heuristic.  Ids are validated per op. */
+ * op as aq_engine_get_conv_config returns them (-1 for ops that are not tuned).  Used for every batch of that tile geometry (H, W),
+ * whatever its size -- a ragged last batch runs the same kernels as the full ones --; other geometries keep the built-in heuristic.
+ * Ids are validated per op. */
 int aq_engine_set_tuned_table(aq_engine* e, int B, int H, int W, const int* cfgs, int n_ops);
 int aq_conv_num_configs(void);
 /* Diagnostics: arm (buf != NULL) or disarm a device buffer that the STAMPED builds of a few conv tile shapes fill with

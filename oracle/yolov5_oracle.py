@@ -45,6 +45,17 @@ def q_bf16(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+def wq_fp8_e4m3(w: torch.Tensor) -> torch.Tensor:
+    """The fp8w mode's weight quantiser, restated with torch's own float8 type: per output channel (dim 0) the smallest power of two s
+    with max|w| / s <= 448, then w -> float8_e4m3fn(w / s) * s (round to nearest even; OCP e4m3fn, the gfx950 fp8).  Independent of
+    aquaculture_amd/quant.py (numpy arithmetic), which the tests hold to it."""
+    flat = w.reshape(w.shape[0], -1).double()
+    amax = flat.abs().amax(1)
+    e = torch.where(amax > 0, torch.ceil(torch.log2(amax.clamp(min=1e-300) / 448.0)), torch.zeros_like(amax))
+    s = torch.pow(2.0, e).view(-1, *([1] * (w.dim() - 1)))
+    return ((w.double() / s).float().to(torch.float8_e4m3fn).float().double() * s).float()
+
+
 def q_bf16_f64(t: torch.Tensor) -> torch.Tensor:
     """The same storage rounding with the arithmetic between two roundings carried in fp64: against ``q_bf16`` (fp32 accumulation in
     PyTorch's summation order) it measures how far results move when ONLY the accumulation changes -- the floor any other
@@ -76,7 +87,7 @@ class OracleModel:
 
     def __init__(self, state: Dict[str, torch.Tensor], nc: int, anchors_grid: torch.Tensor,
                  stride: Sequence[float] = (8.0, 16.0, 32.0), bn_eps: float = 1e-3,
-                 quant: Callable[[torch.Tensor], torch.Tensor] = q_fp32):
+                 quant: Callable[[torch.Tensor], torch.Tensor] = q_fp32, wquant: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
         self.state = state
         self.nc, self.no = nc, nc + 5
         self.anchors = anchors_grid.float()          # (nl, na, 2) grid units
@@ -84,6 +95,7 @@ class OracleModel:
         self.na = int(self.anchors.shape[1])
         self.eps = bn_eps
         self.q = quant
+        self.wq = wquant          # weight-only quantiser of the conv layers (fp8w mode), applied to the fused weights before ``quant``
         self._fused: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.taps: Optional[Dict[str, torch.Tensor]] = None   # per-module outputs when tracing
 
@@ -91,6 +103,8 @@ class OracleModel:
     def _wb(self, key):
         if key not in self._fused:
             w, b = fuse_conv_and_bn(self.state, key, self.eps)
+            if self.wq is not None:
+                w = self.wq(w)
             w = self.q(w)
             self._fused[key] = (w, b.to(w.dtype))
         return self._fused[key]
@@ -313,6 +327,7 @@ def detect_tiles(model: OracleModel, tiles_u8_nhwc: np.ndarray, conf_thres=0.25,
     return dets
 
 
-def model_from_checkpoint(ck, quant=q_fp32) -> OracleModel:
-    """``ck``: any object with .state, .nc, .anchors (grid units), .stride, .bn_eps."""
-    return OracleModel(ck.state, ck.nc, ck.anchors, ck.stride, ck.bn_eps, quant)
+def model_from_checkpoint(ck, quant=q_fp32, wquant=None) -> OracleModel:
+    """``ck``: any object with .state, .nc, .anchors (grid units), .stride, .bn_eps.  ``wquant=wq_fp8_e4m3`` with ``quant=q_bf16`` is
+    the engine's fp8w mode."""
+    return OracleModel(ck.state, ck.nc, ck.anchors, ck.stride, ck.bn_eps, quant, wquant)

@@ -235,6 +235,25 @@ def test_cli_autotune_keeps_the_labels(workdir, lib, tmp_path):
         near = d.min(1)
         assert near.max() <= 2.0 / 640 + 1e-4 and (near <= 1e-4).mean() >= 0.99, (f, near.max(), (near <= 1e-4).mean())
         assert open(on1 / f).read() == open(on2 / f).read()          # cached table = the same kernels again
+    # the tuned table serves the ragged last batch too (10 tiles, batches of 4 -> 4, 4, 2): with another batch size every tile
+    # sits in a differently sized batch, and bf16 -- where a different kernel would round differently -- gives the same bytes
+    envh = {"AQ_TUNE_CACHE": str(tmp_path / "tune_half.json")}
+    _, h4 = _run(workdir, "tune_half4", extra=("--autotune", "on", "--half"), env=envh)
+    cmd3 = [sys.executable, os.path.join(ROOT, "yolov5", "detect.py"), "--weights", str(workdir / "multilabel_farms_synth.pt"), "--source",
+            str(workdir / "jpegs"), "--nosave", "--save-txt", "--save-conf", "--project", str(workdir / "runs"), "--name", "tune_half3",
+            "--batch-size", "3", "--autotune", "off", "--half"]
+    import json
+    table = json.load(open(envh["AQ_TUNE_CACHE"]))
+    (key, cfgs), = table.items()
+    table[key.replace(":4x640x640:", ":3x640x640:")] = cfgs          # the same kernels for batches of 3 (installed from the cache)
+    json.dump(table, open(envh["AQ_TUNE_CACHE"], "w"))
+    cmd3[cmd3.index("off")] = "on"
+    r = subprocess.run(cmd3, capture_output=True, text=True, timeout=420, env=dict(os.environ, **envh))
+    assert r.returncode == 0, r.stderr[-2000:]
+    h3 = workdir / "runs" / "tune_half3" / "labels"
+    assert sorted(os.listdir(h3)) == sorted(os.listdir(h4))
+    for f in os.listdir(h4):
+        assert open(h3 / f, "rb").read() == open(h4 / f, "rb").read(), f
 
 
 def test_cli_resume_skips_recorded_tiles(workdir, lib):
