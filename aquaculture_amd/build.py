@@ -43,12 +43,32 @@ def hipcc() -> str:
 def _digest() -> str:
     h = hashlib.sha256()
     for name in sorted(os.listdir(CSRC)):
-        if name.endswith((".hip", ".cpp", ".h")):
+        if name.endswith((".hip", ".cpp", ".h", "_asm.py")):
             h.update(name.encode())
             h.update(open(os.path.join(CSRC, name), "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "aq_engine.h"), "rb").read())
     h.update(repr((SOURCES, COMMON)).encode())
     return h.hexdigest()
+
+
+def _assemble_planar(verbose: bool) -> None:
+    """The hand-scheduled assembly build of the planar 3x3 kernel: generate the .s (gen_conv3x3_pl_asm.py), assemble and link it into a
+    gfx950 code object with the ROCm clang / lld, and write it as a byte list that conv3x3_pl.hip embeds (hipModuleLoadData)."""
+    llvm = "/opt/rocm/lib/llvm/bin"
+    src, obj, co = (os.path.join(CSRC, n) for n in ("conv3x3_pl_asm.s", "conv3x3_pl_asm.o", "conv3x3_pl_asm.hsaco"))
+    cmds = [[sys.executable, os.path.join(CSRC, "gen_conv3x3_pl_asm.py"), src],
+            [os.path.join(llvm, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-c", src, "-o", obj],
+            [os.path.join(llvm, "ld.lld"), "-shared", obj, "-o", co]]
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{cmd[0]} failed:\n{r.stdout}\n{r.stderr}")
+    data = open(co, "rb").read()
+    with open(os.path.join(CSRC, "conv3x3_pl_asm_hsaco.inc"), "w") as f:
+        for i in range(0, len(data), 32):
+            f.write(",".join(str(b) for b in data[i:i + 32]) + ",\n")
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -58,6 +78,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     cc = hipcc()
     objs = []
+    _assemble_planar(verbose)
 
     def compile_one(item):
         src, extra = item

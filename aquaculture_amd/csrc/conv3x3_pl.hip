@@ -380,6 +380,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_pl_kernel(const PlParams p) {
     pl_tie_a(A0); pl_tie_a(A1); pl_tie_a(A2);
 }
 
+// ---- the hand-scheduled assembly build of the same kernel (gen_conv3x3_pl_asm.py; NB = 13): code object embedded at build time ----
+struct PlAsmArgs {                 // must match ARG in gen_conv3x3_pl_asm.py
+    const char* in; long long in_sp, in_ss;
+    char* out; const char* res; const char* w; const float* bias; const char* zero;
+    int out_ld_b, res_ld_b, B, H, W, npix, cout, act;
+    int CC, mt_log2, ntiles, G;
+    float inv_hw, inv_w, inv_hpwp, inv_wp;
+    unsigned long long* debug;
+};
+static_assert(sizeof(PlAsmArgs) == 136, "kernel argument block");
+const unsigned char kPlAsmCode[] = {
+#include "conv3x3_pl_asm_hsaco.inc"
+};
+hipModule_t g_pl_asm_mod[64];
+hipFunction_t g_pl_asm_fn[64][2];
+
 struct PlKernel { int nb; void (*plain)(const PlParams); void (*res)(const PlParams); };
 struct PlAblation { int abl; void (*fn)(const PlParams); };
 #define PLA(A) { A, conv3x3_pl_kernel<13, true, A> }
@@ -520,6 +536,26 @@ extern "C" int aq_conv3x3_pl(const void* in_dev, long long in_sp, long long in_s
     }
     long long grid = g_pl_cus[dev];
     if (grid > ntiles) grid = ntiles;
+    // the assembly build: NB = 13, power-of-two M-tile count; AQ_PL_ASM=0 keeps the HIP-source kernel (A/B, fallback)
+    const char* use_asm = getenv("AQ_PL_ASM");
+    if (kPl[k].nb == 13 && !ablated && (p.n_mt & (p.n_mt - 1)) == 0 && in_sp < (1LL << 32) && in_ss < (1LL << 31) && !(use_asm && *use_asm == '0')) {
+        if (!g_pl_asm_mod[dev]) {
+            AQ_CHECK_HIP(hipModuleLoadData(&g_pl_asm_mod[dev], kPlAsmCode));
+            AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_asm_fn[dev][0], g_pl_asm_mod[dev], "conv3x3_pl_asm_nb13_res0"));
+            AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_asm_fn[dev][1], g_pl_asm_mod[dev], "conv3x3_pl_asm_nb13_res1"));
+        }
+        PlAsmArgs a{};
+        a.in = p.in; a.in_sp = p.in_sp; a.in_ss = p.in_ss; a.out = p.out; a.res = p.res; a.w = p.w; a.bias = p.bias; a.zero = p.zero;
+        a.out_ld_b = p.out_ld_b; a.res_ld_b = p.res_ld_b; a.B = p.B; a.H = p.H; a.W = p.W; a.npix = p.npix; a.cout = p.cout; a.act = p.act;
+        a.CC = p.CC; a.ntiles = p.ntiles; a.G = (int)grid;
+        a.mt_log2 = 0;
+        while ((1 << a.mt_log2) < p.n_mt) ++a.mt_log2;
+        a.inv_hw = p.inv_hw; a.inv_w = p.inv_w; a.inv_hpwp = p.inv_hpwp; a.inv_wp = p.inv_wp; a.debug = nullptr;
+        size_t asz = sizeof(a);
+        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+        AQ_CHECK_HIP(hipModuleLaunchKernel(g_pl_asm_fn[dev][res_dev ? 1 : 0], (unsigned)grid, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
+        return AQ_OK;
+    }
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;

@@ -1,0 +1,735 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled gfx950 assembly of the planar 3x3/s1 convolution (conv3x3_pl_asm_*).
+
+Same algorithm, data layout and LDS-DMA ring as the HIP-source kernel in conv3x3_pl.hip (read its header first) -- that kernel is the
+specification and the fallback.  Why assembly: in the HIP kernel every vector-memory operation is inline asm with hand-counted
+s_waitcnt, and the compiler's register allocator then sets the limits (it spills or copies registers that an asm load is still
+filling, tests/test_build_isa.py): the residual cannot be prefetched under the last chunk, waits cannot depend on run-time flags, and
+the epilogue waits for memory twice per tile (stamped build: epilogue 15 k of a tile's 75 k cycles, chunk tops 6 k).
+Here every register is assigned by hand:
+
+  a[0 : 12 NB)           accumulators, acc(i, j) = a[4 (3 j + i) : +4]  (M block i of the wave, pixel block j)
+  v[A]   72 registers    weight fragments of tap-steps T, T + 1, T + 2 (loaded two tap-steps ahead, straight from L2)
+  v[B]   4 (PD + 1)      rotating B fragments, read PD elements ahead of their MFMAs
+  v[R]   6 NB            the tile's whole residual, fetched at the top of its LAST chunk (lands under that chunk's MFMAs)
+  v[addr] NB             LDS byte address of this lane's B fragment per pixel block, advanced in place from tap to tap
+
+and every s_waitcnt vmcnt(N) is exact (N = vector-memory operations issued after the awaited one; the only run-time dependence, "+3 NB
+at taps 0 and 1 after an epilogue or a residual fetch", is a scalar branch between two immediates).
+
+Hazards the assembler does not pad (LLVM GCNHazardRecognizer, gfx940 family): s_mov m0 -> LDS-DMA 1 state; VALU write -> v_readfirstlane
+1; VALU-written SGPR -> VMEM 5 / -> VALU 2; transcendental -> consumer 1; MFMA result -> VALU read up to 19 (s_nop 15 twice before the
+epilogue); v_accvgpr_write -> MFMA 2.  Each is marked `hz:` where it is handled.
+
+Usage: python gen_conv3x3_pl_asm.py OUT.s   (aquaculture_amd/build.py assembles OUT.s with clang and embeds the code object)
+"""
+import sys
+
+NB = 13
+PD = 8
+NE = 18 * NB
+ROWS = 384
+PS = ROWS * 16
+CHUNK = 8 * PS
+BIAS_OFF = 3 * CHUNK
+STEP_B = 6 * 1024
+
+# ---- kernel argument block (must match PlAsmArgs in conv3x3_pl.hip) ----
+ARG = dict(inp=0, in_sp=8, in_ss=16, out=24, res=32, w=40, bias=48, zero=56, out_ld=64, res_ld=68, B=72, H=76, W=80, npix=84, cout=88, act=92,
+           CC=96, mt_log2=100, ntiles=104, G=108, inv_hw=112, inv_w=116, inv_hpwp=120, inv_wp=124, debug=128)
+ARG_BYTES = 136
+
+
+class Regs:
+    """Named register allocation; errors on overlap."""
+
+    def __init__(self, prefix, limit):
+        self.prefix, self.limit, self.next, self.names = prefix, limit, 0, {}
+
+    def alloc(self, name, n=1, align=1):
+        self.next = (self.next + align - 1) // align * align
+        base = self.next
+        self.next += n
+        assert self.next <= self.limit, f"out of {self.prefix} registers at {name}"
+        self.names[name] = (base, n)
+        return base
+
+
+V = Regs("v", 256)
+S = Regs("s", 100)
+
+# ---------------- SGPRs ----------------
+S.alloc("karg", 2)            # s[0:1]
+S.alloc("wg", 1)              # s2
+for nm in ("inp", "in_sp", "in_ss", "out", "res", "w", "bias", "zero"):
+    S.alloc(nm, 2, 2)
+for nm in ("out_ld", "res_ld", "B", "H", "W", "npix", "cout", "act", "CC", "mt_log2", "ntiles", "G", "inv_hw", "inv_w", "inv_hpwp", "inv_wp"):
+    S.alloc(nm)
+S.alloc("debug", 2, 2)
+for nm in ("HW", "Wp", "HpWp", "lead", "Hpad", "tile", "next_tile", "has_next", "nt", "mt", "n0", "cbase", "c", "buf", "cd", "bd", "lastc", "extra",
+           "rs", "rs_dma", "delta0", "dRow", "wave", "smem", "first", "tmp0", "tmp1", "tmp2", "tmp3", "dlds", "lim"):
+    S.alloc(nm)
+S.alloc("klog2e2", 2, 2)      # (-log2 e, -log2 e) for v_pk_mul_f32
+S.alloc("kone2", 2, 2)        # (1.0, 1.0)
+S.alloc("a_cur", 2, 2)
+S.alloc("a_nxt", 2, 2)
+S.alloc("a_ld", 2, 2)         # base of the weight loads being issued
+S.alloc("dbase", 2, 2)        # LDS-DMA: input base of (chunk, plane)
+S.alloc("t64", 2, 2)
+
+
+def s(name, i=0):
+    b, n = S.names[name]
+    assert i < n
+    return f"s{b + i}"
+
+
+def s2(name, i=0):
+    b, n = S.names[name]
+    return f"s[{b + i}:{b + i + 1}]"
+
+
+# ---------------- VGPRs ----------------
+V.alloc("tid")                # v0 on entry
+V.alloc("lane")
+V.alloc("l15")
+V.alloc("q")
+V.alloc("aoff")               # lane * 16
+V.alloc("qps")                # q * PS
+V.alloc("insp")               # in_sp (low 32 bits) as a VGPR operand of v_mad_u64_u32
+V.alloc("zero_lo")
+V.alloc("zero_hi")
+V.alloc("A", 72, 4)
+V.alloc("B", 4 * (PD + 1), 4)
+V.alloc("addr", NB)
+V.alloc("prow", 6)
+V.alloc("R", 6 * NB, 2)
+V.alloc("oo", NB)
+V.alloc("t", 24, 4)           # temporaries
+
+
+def v(name, i=0):
+    b, n = V.names[name]
+    assert i < n, (name, i)
+    return f"v{b + i}"
+
+
+def vr(name, i, cnt):
+    b, n = V.names[name]
+    assert i + cnt <= n, (name, i, cnt)
+    return f"v[{b + i}:{b + i + cnt - 1}]"
+
+
+def acc(i, j):
+    b = 4 * (3 * j + i)
+    return f"a[{b}:{b + 3}]"
+
+
+out = []
+
+
+def E(line="", comment=None):
+    out.append(("\t" + line if line and not line.endswith(":") else line) + (f"\t; {comment}" if comment else ""))
+
+
+def label(name):
+    out.append(f"{name}:")
+
+
+_uid = [0, ""]
+
+
+def uid(prefix):
+    _uid[0] += 1
+    return f".L{prefix}_{_uid[1]}_{_uid[0]}"
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# macros
+# ------------------------------------------------------------------------------------------------------------------------------
+def emit_pp_of(dst, src, t0, t1, t2, t3):
+    """dst = padded coordinate of pixel index src (VGPRs; dst may equal src): P + lead + b (H + W + 1) + y."""
+    E(f"v_cvt_f32_i32 {t0}, {src}")
+    E(f"v_mul_f32 {t0}, {s('inv_hw')}, {t0}")
+    E(f"v_cvt_i32_f32 {t0}, {t0}", "b")
+    E(f"v_mul_lo_u32 {t1}, {t0}, {s('HW')}")
+    E(f"v_sub_u32 {t1}, {src}, {t1}", "rem")
+    E(f"v_cmp_gt_i32 vcc, 0, {t1}")
+    E(f"v_cndmask_b32 {t2}, 0, -1, vcc", "rem < 0 -> -1")
+    E(f"v_cmp_le_i32 vcc, {s('HW')}, {t1}")
+    E(f"v_cndmask_b32 {t3}, 0, 1, vcc", "rem >= HW -> +1")
+    E(f"v_add_u32 {t2}, {t2}, {t3}", "correction of b")
+    E(f"v_add_u32 {t0}, {t0}, {t2}")
+    E(f"v_mul_lo_u32 {t2}, {t2}, {s('HW')}")
+    E(f"v_sub_u32 {t1}, {t1}, {t2}", "rem in [0, HW)")
+    E(f"v_cvt_f32_i32 {t2}, {t1}")
+    E(f"v_mul_f32 {t2}, {s('inv_w')}, {t2}")
+    E(f"v_cvt_i32_f32 {t2}, {t2}", "y")
+    E(f"v_mul_lo_u32 {t3}, {t2}, {s('W')}")
+    E(f"v_sub_u32 {t3}, {t1}, {t3}", "x")
+    E(f"v_cmp_gt_i32 vcc, 0, {t3}")
+    E(f"v_subbrev_co_u32 {t2}, vcc, 0, {t2}, vcc", "x < 0 -> y - 1")
+    E(f"v_cmp_le_i32 vcc, {s('W')}, {t3}")
+    E(f"v_addc_co_u32 {t2}, vcc, 0, {t2}, vcc", "x >= W -> y + 1 (x was >= 0, so at most one of the two fires)")
+    E(f"v_mul_lo_u32 {t0}, {t0}, {s('Hpad')}", "b (H + W + 1)")
+    E(f"v_add3_u32 {dst}, {src}, {t0}, {t2}")
+    E(f"v_add_u32 {dst}, {s('lead')}, {dst}")
+
+
+def emit_unpad(dst, src, t0, t1, t2, t3, t4):
+    """dst = pixel index of padded coordinate src, or -1 (padding / outside the batch)."""
+    E(f"v_subrev_u32 {t4}, {s('lead')}, {src}", "Pq")
+    E(f"v_cvt_f32_i32 {t0}, {t4}")
+    E(f"v_mul_f32 {t0}, {s('inv_hpwp')}, {t0}")
+    E(f"v_cvt_i32_f32 {t0}, {t0}", "b")
+    E(f"v_mul_lo_u32 {t1}, {t0}, {s('HpWp')}")
+    E(f"v_sub_u32 {t1}, {t4}, {t1}", "rem")
+    E(f"v_cmp_gt_i32 vcc, 0, {t1}")
+    E(f"v_cndmask_b32 {t2}, 0, -1, vcc")
+    E(f"v_cmp_le_i32 vcc, {s('HpWp')}, {t1}")
+    E(f"v_cndmask_b32 {t3}, 0, 1, vcc")
+    E(f"v_add_u32 {t2}, {t2}, {t3}")
+    E(f"v_add_u32 {t0}, {t0}, {t2}")
+    E(f"v_mul_lo_u32 {t2}, {t2}, {s('HpWp')}")
+    E(f"v_sub_u32 {t1}, {t1}, {t2}", "rem in [0, HpWp)")
+    E(f"v_cvt_f32_i32 {t2}, {t1}")
+    E(f"v_mul_f32 {t2}, {s('inv_wp')}, {t2}")
+    E(f"v_cvt_i32_f32 {t2}, {t2}", "y")
+    E(f"v_mul_lo_u32 {t3}, {t2}, {s('Wp')}")
+    E(f"v_sub_u32 {t3}, {t1}, {t3}", "x")
+    # x < 0 -> y -= 1, x += Wp ; x >= Wp -> y += 1, x -= Wp
+    E(f"v_cmp_gt_i32 vcc, 0, {t3}")
+    E(f"v_cndmask_b32 {t1}, 0, -1, vcc")
+    E(f"v_cmp_le_i32 vcc, {s('Wp')}, {t3}")
+    E(f"v_addc_co_u32 {t1}, vcc, 0, {t1}, vcc", "dy in {-1, 0, +1}")
+    E(f"v_add_u32 {t2}, {t2}, {t1}", "y")
+    E(f"v_mul_lo_u32 {t1}, {t1}, {s('Wp')}")
+    E(f"v_sub_u32 {t3}, {t3}, {t1}", "x in [0, Wp)")
+    # P = b HW + y W + x
+    E(f"v_mul_lo_u32 {t1}, {t0}, {s('HW')}")
+    E(f"v_mad_u32_u24 {t1}, {t2}, {s('W')}, {t1}")
+    E(f"v_add_u32 {dst}, {t1}, {t3}")
+    # valid: Pq >= 0 and b < B and x < W and y < H   (b >= 0 follows from Pq >= 0)
+    E(f"v_cmp_gt_i32 vcc, 0, {t4}")
+    E(f"v_cndmask_b32 {dst}, {dst}, -1, vcc")
+    E(f"v_cmp_le_i32 vcc, {s('B')}, {t0}")
+    E(f"v_cndmask_b32 {dst}, {dst}, -1, vcc")
+    E(f"v_cmp_le_i32 vcc, {s('W')}, {t3}")
+    E(f"v_cndmask_b32 {dst}, {dst}, -1, vcc")
+    E(f"v_cmp_le_i32 vcc, {s('H')}, {t2}")
+    E(f"v_cndmask_b32 {dst}, {dst}, -1, vcc")
+
+
+def emit_rs_of_tile(tile_s, dst_s):
+    """dst_s = pp_of(n0 of tile) - lead as an SGPR (n0 = (tile >> mt_log2) * BN)."""
+    T = [v("t", i) for i in range(6)]
+    E(f"s_lshr_b32 {s('tmp0')}, {tile_s}, {s('mt_log2')}")
+    E(f"s_mul_i32 {s('tmp0')}, {s('tmp0')}, {NB * 16}")
+    E(f"v_mov_b32 {T[4]}, {s('tmp0')}")
+    emit_pp_of(T[5], T[4], T[0], T[1], T[2], T[3])
+    E(f"v_subrev_u32 {T[5]}, {s('lead')}, {T[5]}")
+    E("s_nop 1", "hz: VALU write -> v_readfirstlane")
+    E(f"v_readfirstlane_b32 {dst_s}, {T[5]}")
+
+
+def emit_region_rows(tile_s):
+    """prow[k] = unpad(rs(tile) + 64 k + lane) for k = 0..5."""
+    emit_rs_of_tile(tile_s, s("rs_dma"))
+    T = [v("t", i) for i in range(6)]
+    for k in range(6):
+        E(f"v_add_u32 {T[5]}, {s('rs_dma')}, {v('lane')}")
+        if k:
+            E(f"v_add_u32 {T[5]}, {64 * k}, {T[5]}")
+        emit_unpad(v("prow", k), T[5], T[0], T[1], T[2], T[3], T[4])
+
+
+def emit_no_rows():
+    for k in range(6):
+        E(f"v_mov_b32 {v('prow', k)}, -1")
+
+
+def emit_dma(k, s2i, cd_s, bd_s):
+    """One LDS-DMA instruction: plane 2 wave + s2i of chunk cd, region rows 64 k .. 64 k + 63, into ring buffer bd."""
+    T = [v("t", i) for i in range(8, 12)]
+    # scalar: dbase = inp + (8 cd + 2 wave + s2i) * in_ss ; dlds = smem + bd * CHUNK + (2 wave + s2i) * PS + k * 1024
+    E(f"s_lshl_b32 {s('tmp0')}, {cd_s}, 3")
+    E(f"s_lshl_b32 {s('tmp1')}, {s('wave')}, 1")
+    E(f"s_add_u32 {s('tmp1')}, {s('tmp1')}, {s2i}")
+    E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {s('tmp1')}", "slot")
+    E(f"s_mul_i32 {s('tmp2')}, {s('tmp0')}, {s('in_ss')}")
+    E(f"s_mul_hi_u32 {s('tmp3')}, {s('tmp0')}, {s('in_ss')}")
+    E(f"s_add_u32 {s('dbase')}, {s('inp')}, {s('tmp2')}")
+    E(f"s_addc_u32 {s('dbase', 1)}, {s('inp', 1)}, {s('tmp3')}")
+    E(f"s_mul_i32 {s('tmp2')}, {bd_s}, {CHUNK}")
+    E(f"s_mul_i32 {s('tmp1')}, {s('tmp1')}, {PS}")
+    E(f"s_add_u32 {s('dlds')}, {s('smem')}, {s('tmp2')}")
+    E(f"s_add_u32 {s('dlds')}, {s('dlds')}, {s('tmp1')}")
+    E(f"s_add_u32 {s('dlds')}, {s('dlds')}, {k * 1024}")
+    E(f"v_max_i32 {T[2]}, 0, {v('prow', k)}")
+    E(f"v_mad_u64_u32 v[{V.names['t'][0] + 8}:{V.names['t'][0] + 9}], vcc, {T[2]}, {v('insp')}, {s2('dbase')}")
+    E(f"v_cmp_gt_i32 vcc, 0, {v('prow', k)}")
+    E(f"v_cndmask_b32 {T[0]}, {T[0]}, {v('zero_lo')}, vcc")
+    E(f"v_cndmask_b32 {T[1]}, {T[1]}, {v('zero_hi')}, vcc")
+    E(f"s_mov_b32 m0, {s('dlds')}")
+    E("s_nop 0", "hz: s_mov m0 -> LDS-DMA")
+    E(f"global_load_lds_dwordx4 v[{V.names['t'][0] + 8}:{V.names['t'][0] + 9}], off")
+
+
+def emit_load_a(set_idx, k, base_s2, extra_off):
+    """fragment k (0..5) of a tap-step into A set set_idx: 1 KB at base + extra_off + 1024 k (base is the tap-step's stream + 3072)."""
+    off = 1024 * k - 3072 + extra_off
+    assert -4096 <= off <= 4095
+    E(f"global_load_dwordx4 {vr('A', 24 * set_idx + 4 * k, 4)}, {v('aoff')}, {base_s2} offset:{off}")
+
+
+def emit_set_a_base(dst, tap):
+    """dst (SGPR pair) = stream address (+3072) of tap-step `tap` of this chunk (0..8) or of the next chunk / tile (9, 10)."""
+    if tap < 9:
+        E(f"s_add_u32 {s(dst)}, {s('a_cur')}, {tap * STEP_B}")
+        E(f"s_addc_u32 {s(dst, 1)}, {s('a_cur', 1)}, 0")
+    else:
+        E(f"s_add_u32 {s(dst)}, {s('a_nxt')}, {(tap - 9) * STEP_B}")
+        E(f"s_addc_u32 {s(dst, 1)}, {s('a_nxt', 1)}, 0")
+
+
+def emit_a_stream_base(dst, tile_s, c_s):
+    """dst = w + (((mt * 4 + wave) * CC + c) * 9) * STEP_B + 3072, mt = tile & ((1 << mt_log2) - 1)."""
+    E(f"s_lshl_b32 {s('tmp0')}, 1, {s('mt_log2')}")
+    E(f"s_sub_u32 {s('tmp0')}, {s('tmp0')}, 1")
+    E(f"s_and_b32 {s('tmp0')}, {tile_s}, {s('tmp0')}", "mt")
+    E(f"s_lshl_b32 {s('tmp0')}, {s('tmp0')}, 2")
+    E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {s('wave')}")
+    E(f"s_mul_i32 {s('tmp0')}, {s('tmp0')}, {s('CC')}")
+    E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {c_s}")
+    E(f"s_mul_i32 {s('tmp1')}, {s('tmp0')}, {9 * STEP_B}")
+    E(f"s_mul_hi_u32 {s('tmp2')}, {s('tmp0')}, {9 * STEP_B}")
+    E(f"s_add_u32 {s('tmp1')}, {s('tmp1')}, 3072")
+    E(f"s_addc_u32 {s('tmp2')}, {s('tmp2')}, 0")
+    E(f"s_add_u32 {s(dst)}, {s('w')}, {s('tmp1')}")
+    E(f"s_addc_u32 {s(dst, 1)}, {s('w', 1)}, {s('tmp2')}")
+
+
+def emit_barrier():
+    E("s_waitcnt lgkmcnt(0)")
+    E("s_barrier")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# kernel
+# ------------------------------------------------------------------------------------------------------------------------------
+def gen_kernel(name, RES):
+    global out
+    out = []
+    _uid[0], _uid[1] = 0, name[-9:].replace("_", "")
+    E(f"; conv3x3_pl assembly, NB = {NB}, RES = {int(RES)}: generated by gen_conv3x3_pl_asm.py -- do not edit")
+    label(name)
+    # ---- arguments ----
+    E(f"s_load_dwordx8 s[{S.names['inp'][0]}:{S.names['inp'][0] + 7}], {s2('karg')}, 0x0", "inp, in_sp, in_ss, out")
+    E(f"s_load_dwordx8 s[{S.names['res'][0]}:{S.names['res'][0] + 7}], {s2('karg')}, 0x20", "res, w, bias, zero")
+    E(f"s_load_dwordx8 s[{S.names['out_ld'][0]}:{S.names['out_ld'][0] + 7}], {s2('karg')}, 0x40", "out_ld .. act")
+    E(f"s_load_dwordx8 s[{S.names['CC'][0]}:{S.names['CC'][0] + 7}], {s2('karg')}, 0x60", "CC .. inv_wp")
+    E(f"s_load_dwordx2 {s2('debug')}, {s2('karg')}, 0x80")
+    assert S.names['in_sp'][0] == S.names['inp'][0] + 2 and S.names['out'][0] == S.names['inp'][0] + 6
+    assert S.names['zero'][0] == S.names['res'][0] + 6 and S.names['act'][0] == S.names['out_ld'][0] + 7
+    assert S.names['inv_wp'][0] == S.names['CC'][0] + 7 and S.names['inp'][0] % 4 == 0 and S.names['res'][0] % 4 == 0
+    E(f"v_and_b32 {v('lane')}, 63, {v('tid')}")
+    E(f"v_lshrrev_b32 {v('t', 0)}, 6, {v('tid')}")
+    E("s_nop 1", "hz: VALU write -> v_readfirstlane")
+    E(f"v_readfirstlane_b32 {s('wave')}, {v('t', 0)}")
+    E(f"v_and_b32 {v('l15')}, 15, {v('lane')}")
+    E(f"v_lshrrev_b32 {v('q')}, 4, {v('lane')}")
+    E(f"v_lshlrev_b32 {v('aoff')}, 4, {v('lane')}")
+    E(f"v_mul_u32_u24 {v('qps')}, {PS}, {v('q')}")
+    E("s_waitcnt lgkmcnt(0)")
+    E(f"v_mov_b32 {v('insp')}, {s('in_sp')}")
+    E(f"v_mov_b32 {v('zero_lo')}, {s('zero')}")
+    E(f"v_mov_b32 {v('zero_hi')}, {s('zero', 1)}")
+    E(f"s_mul_i32 {s('HW')}, {s('H')}, {s('W')}")
+    E(f"s_add_u32 {s('Wp')}, {s('W')}, 1")
+    E(f"s_add_u32 {s('tmp0')}, {s('H')}, 1")
+    E(f"s_mul_i32 {s('HpWp')}, {s('tmp0')}, {s('Wp')}")
+    E(f"s_add_u32 {s('lead')}, {s('W')}, 2")
+    E(f"s_add_u32 {s('Hpad')}, {s('tmp0')}, {s('W')}", "H + W + 1")
+    E(f"s_lshl_b32 {s('tmp0')}, {s('Wp')}, 4")
+    E(f"s_sub_u32 {s('dRow')}, {s('tmp0')}, 32", "tap (r, 2) -> (r + 1, 0): (Wp - 2) * 16 bytes")
+    E(f"s_mov_b32 {s('smem')}, 0", "dynamic LDS starts at 0 (no static LDS)")
+    E(f"s_mov_b32 {s('klog2e2')}, 0xbfb8aa3b", "-log2(e)")
+    E(f"s_mov_b32 {s('klog2e2', 1)}, 0xbfb8aa3b")
+    E(f"s_mov_b32 {s('kone2')}, 1.0")
+    E(f"s_mov_b32 {s('kone2', 1)}, 1.0")
+    # ---- first tile: XCD-aware bijective map (blocks sharing an XCD get consecutive tiles) ----
+    E(f"s_lshr_b32 {s('tmp0')}, {s('G')}, 3", "q")
+    E(f"s_and_b32 {s('tmp1')}, {s('G')}, 7", "r")
+    E(f"s_and_b32 {s('tmp2')}, {s('wg')}, 7", "xcd")
+    E(f"s_add_u32 {s('tmp3')}, {s('tmp0')}, 1", "q + 1")
+    E(f"s_cmp_lt_u32 {s('tmp2')}, {s('tmp1')}")
+    E(f"s_cselect_b32 {s('tile')}, {s('tmp2')}, {s('tmp1')}", "min(xcd, r)")
+    E(f"s_mul_i32 {s('tile')}, {s('tile')}, {s('tmp3')}", "min(xcd, r) * (q + 1)")
+    E(f"s_sub_u32 {s('tmp3')}, {s('tmp2')}, {s('tmp1')}", "xcd - r")
+    E(f"s_cselect_b32 {s('tmp3')}, 0, {s('tmp3')}", "max(xcd - r, 0)   (scc still: xcd < r)")
+    E(f"s_mul_i32 {s('tmp3')}, {s('tmp3')}, {s('tmp0')}")
+    E(f"s_add_u32 {s('tile')}, {s('tile')}, {s('tmp3')}")
+    E(f"s_lshr_b32 {s('tmp3')}, {s('wg')}, 3")
+    E(f"s_add_u32 {s('tile')}, {s('tile')}, {s('tmp3')}")
+    E(f"s_cmp_ge_u32 {s('tile')}, {s('ntiles')}")
+    E("s_cbranch_scc1 .Lend_" + name)
+    # ---- prologue: weights of taps 0 and 1, chunks 0 and 1 of the region, the bias ----
+    E(f"s_mov_b32 {s('c')}, 0")
+    emit_a_stream_base("a_cur", s("tile"), s("c"))
+    for k in range(6):
+        emit_load_a(0, k, s2("a_cur"), 0)
+    # tap-step 1 = a_cur + STEP_B: offsets exceed the immediate range, so move the base
+    E(f"s_add_u32 {s('a_ld')}, {s('a_cur')}, {STEP_B}")
+    E(f"s_addc_u32 {s('a_ld', 1)}, {s('a_cur', 1)}, 0")
+    for k in range(6):
+        emit_load_a(1, k, s2("a_ld"), 0)
+    emit_region_rows(s("tile"))
+    E(f"s_mov_b32 {s('cd')}, 0")
+    E(f"s_mov_b32 {s('bd')}, 0")
+    for k in range(6):
+        for s2i in range(2):
+            emit_dma(k, s2i, s("cd"), s("bd"))
+    # bias: 256 floats per wave by LDS-DMA (lane: floats wave * 256 + 4 lane .. + 3, or zeros beyond cout)
+    T = [v("t", i) for i in range(8)]
+    E(f"s_lshl_b32 {s('tmp0')}, {s('wave')}, 8")
+    E(f"v_lshl_add_u32 {T[2]}, {v('lane')}, 2, {s('tmp0')}", "f0")
+    E(f"v_add_u32 {T[3]}, 4, {T[2]}")
+    E(f"v_lshlrev_b32 {T[2]}, 2, {T[2]}", "byte offset")
+    E(f"v_mov_b32 {T[4]}, {s('bias')}")
+    E(f"v_mov_b32 {T[5]}, {s('bias', 1)}")
+    E(f"v_add_co_u32 {T[4]}, vcc, {T[4]}, {T[2]}")
+    E(f"v_addc_co_u32 {T[5]}, vcc, 0, {T[5]}, vcc")
+    E(f"v_cmp_lt_u32 vcc, {s('cout')}, {T[3]}", "f0 + 4 > cout")
+    E(f"v_cndmask_b32 {T[4]}, {T[4]}, {v('zero_lo')}, vcc")
+    E(f"v_cndmask_b32 {T[5]}, {T[5]}, {v('zero_hi')}, vcc")
+    E(f"s_lshl_b32 {s('tmp0')}, {s('wave')}, 10")
+    E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {BIAS_OFF}")
+    E(f"s_mov_b32 m0, {s('tmp0')}")
+    E("s_nop 0", "hz: s_mov m0 -> LDS-DMA")
+    E(f"global_load_lds_dwordx4 v[{V.names['t'][0] + 4}:{V.names['t'][0] + 5}], off")
+    E(f"s_mov_b32 {s('cd')}, 1")
+    E(f"s_mov_b32 {s('bd')}, 1")
+    for k in range(6):
+        for s2i in range(2):
+            emit_dma(k, s2i, s("cd"), s("bd"))
+    E("s_waitcnt vmcnt(12)", "all but chunk 1's LDS-DMA: weights of taps 0 and 1, chunk 0, the bias")
+    emit_barrier()
+    E(f"s_mov_b32 {s('buf')}, 0")
+    E(f"s_mov_b32 {s('first')}, 1")
+
+    # =========================================== tile loop ===========================================
+    label(".Ltile_" + name)
+    E(f"s_lshr_b32 {s('nt')}, {s('tile')}, {s('mt_log2')}")
+    E(f"s_lshl_b32 {s('tmp0')}, {s('nt')}, {s('mt_log2')}")
+    E(f"s_sub_u32 {s('mt')}, {s('tile')}, {s('tmp0')}")
+    E(f"s_mul_i32 {s('n0')}, {s('nt')}, {NB * 16}")
+    E(f"s_add_u32 {s('next_tile')}, {s('tile')}, {s('G')}")
+    E(f"s_cmp_lt_u32 {s('next_tile')}, {s('ntiles')}")
+    E(f"s_cselect_b32 {s('has_next')}, 1, 0")
+    E(f"s_mul_i32 {s('cbase')}, {s('mt')}, 192")
+    E(f"s_mul_i32 {s('tmp0')}, {s('wave')}, 48")
+    E(f"s_add_u32 {s('cbase')}, {s('cbase')}, {s('tmp0')}")
+    emit_rs_of_tile(s("tile"), s("rs"))
+    # addr[j] = q PS + (pp_of(P_j) - rs - Wp - 1) * 16 + buf * CHUNK ;  oo[j] = P_j * out_ld + (cbase + 4 q) * 2 ; omask[j]
+    E(f"s_sub_u32 {s('tmp1')}, {s('npix')}, 1")
+    E(f"s_add_u32 {s('tmp2')}, {s('rs')}, {s('Wp')}")
+    E(f"s_add_u32 {s('tmp2')}, {s('tmp2')}, 1", "rs + Wp + 1")
+    E(f"s_mul_i32 {s('tmp3')}, {s('buf')}, {CHUNK}")
+    E(f"v_lshl_add_u32 {T[7]}, {v('q')}, 2, {s('cbase')}", "cbase + 4 q")
+    E(f"v_lshlrev_b32 {T[7]}, 1, {T[7]}", "bytes")
+    for j in range(NB):
+        E(f"v_add_u32 {T[4]}, {s('n0')}, {v('l15')}")
+        if j:
+            E(f"v_add_u32 {T[4]}, {16 * j}, {T[4]}")
+        E(f"v_min_i32 {T[4]}, {s('tmp1')}, {T[4]}", "clamp")
+        E(f"v_mul_lo_u32 {v('oo', j)}, {T[4]}, {s('out_ld')}")
+        E(f"v_add_u32 {v('oo', j)}, {v('oo', j)}, {T[7]}")
+        emit_pp_of(T[5], T[4], T[0], T[1], T[2], T[3])
+        E(f"v_subrev_u32 {T[5]}, {s('tmp2')}, {T[5]}")
+        E(f"v_lshl_add_u32 {v('addr', j)}, {T[5]}, 4, {v('qps')}")
+        E(f"v_add_u32 {v('addr', j)}, {s('tmp3')}, {v('addr', j)}")
+    # accumulators start from the bias
+    for i in range(3):
+        E(f"v_lshl_add_u32 {T[6]}, {v('q')}, 2, {s('cbase')}")
+        E(f"v_lshlrev_b32 {T[6]}, 2, {T[6]}")
+        E(f"v_add_u32 {T[6]}, {BIAS_OFF}, {T[6]}", "the bias sits behind the ring (beyond the 16-bit DS offset)")
+        E(f"ds_read_b128 {vr('t', 0, 4)}, {T[6]} offset:{64 * i}")
+        E("s_waitcnt lgkmcnt(0)")
+        for j in range(NB):
+            for e in range(4):
+                E(f"v_accvgpr_write_b32 a{4 * (3 * j + i) + e}, {v('t', e)}")
+    E(f"s_mov_b32 {s('c')}, 0")
+    E(f"s_mov_b32 {s('delta0')}, 0", "the first chunk of a tile starts at tap 0 of its own buffer")
+
+    # =========================================== chunk loop ===========================================
+    label(".Lchunk_" + name)
+    emit_barrier()
+    E(f"s_add_u32 {s('tmp0')}, {s('c')}, 1")
+    E(f"s_cmp_eq_u32 {s('tmp0')}, {s('CC')}")
+    E(f"s_cselect_b32 {s('lastc')}, 1, 0")
+    # DMA target: chunk c + 2 of this tile or c + 2 - CC of the next one, into buffer (buf + 2) % 3
+    E(f"s_add_u32 {s('cd')}, {s('c')}, 2")
+    E(f"s_add_u32 {s('bd')}, {s('buf')}, 2")
+    E(f"s_cmp_ge_u32 {s('bd')}, 3")
+    E(f"s_cselect_b32 {s('tmp0')}, 3, 0")
+    E(f"s_sub_u32 {s('bd')}, {s('bd')}, {s('tmp0')}")
+    lskip = uid("cd")
+    E(f"s_cmp_lt_u32 {s('cd')}, {s('CC')}")
+    E(f"s_cbranch_scc1 {lskip}")
+    E(f"s_sub_u32 {s('cd')}, {s('cd')}, {s('CC')}")
+    E(f"s_cmp_lg_u32 {s('cd')}, 0")
+    E(f"s_cbranch_scc1 {lskip}")
+    lno, ldone = uid("norows"), uid("rowsdone")
+    E(f"s_cmp_eq_u32 {s('has_next')}, 0")
+    E(f"s_cbranch_scc1 {lno}")
+    emit_region_rows(s("next_tile"))
+    E(f"s_branch {ldone}")
+    label(lno)
+    emit_no_rows()
+    label(ldone)
+    label(lskip)
+    # weight stream of this chunk and of the next (chunk c + 1, or chunk 0 of the next tile; the own tile again when there is none)
+    emit_a_stream_base("a_cur", s("tile"), s("c"))
+    lnx, lnd = uid("anxt"), uid("anxtd")
+    E(f"s_cmp_eq_u32 {s('lastc')}, 1")
+    E(f"s_cbranch_scc1 {lnx}")
+    E(f"s_add_u32 {s('tmp3')}, {s('c')}, 1")
+    emit_a_stream_base("a_nxt", s("tile"), s("tmp3"))
+    E(f"s_branch {lnd}")
+    label(lnx)
+    E(f"s_cmp_eq_u32 {s('has_next')}, 1")
+    E(f"s_cselect_b32 {s('t64')}, {s('next_tile')}, {s('tile')}")
+    E(f"s_mov_b32 {s('tmp3')}, 0")
+    emit_a_stream_base("a_nxt", s("t64"), s("tmp3"))
+    label(lnd)
+    # extra = 3 NB vector-memory operations younger than the weights of taps 0 and 1: the epilogue's stores (first chunk of a tile
+    # that is not the wave's first) or the residual loads just below (last chunk, RES)
+    E(f"s_cmp_eq_u32 {s('c')}, 0")
+    E(f"s_cselect_b32 {s('extra')}, 1, 0")
+    E(f"s_cmp_eq_u32 {s('first')}, 1")
+    E(f"s_cselect_b32 {s('extra')}, 0, {s('extra')}")
+    if RES:
+        E(f"s_or_b32 {s('extra')}, {s('extra')}, {s('lastc')}")
+        lnr = uid("nores")
+        E(f"s_cmp_eq_u32 {s('lastc')}, 0")
+        E(f"s_cbranch_scc1 {lnr}")
+        # the tile's whole residual: lands under this chunk's MFMAs
+        E(f"s_sub_u32 {s('tmp1')}, {s('npix')}, 1")
+        E(f"v_lshl_add_u32 {T[7]}, {v('q')}, 2, {s('cbase')}")
+        E(f"v_lshlrev_b32 {T[7]}, 1, {T[7]}")
+        for j in range(NB):
+            E(f"v_add_u32 {T[4]}, {s('n0')}, {v('l15')}")
+            if j:
+                E(f"v_add_u32 {T[4]}, {16 * j}, {T[4]}")
+            E(f"v_min_i32 {T[4]}, {s('tmp1')}, {T[4]}")
+            E(f"v_mul_lo_u32 {T[4]}, {T[4]}, {s('res_ld')}")
+            E(f"v_add_u32 {T[4]}, {T[4]}, {T[7]}")
+            for i in range(3):
+                E(f"global_load_dwordx2 {vr('R', 2 * (3 * j + i), 2)}, {T[4]}, {s2('res')} offset:{32 * i}")
+        label(lnr)
+    # first B fragments
+    def b_read(n):
+        h, j = divmod(n, NB)
+        t, ks = divmod(h, 2)
+        if ks == 0:
+            # advance this pixel block's address to tap t
+            if t == 0:
+                E(f"v_add_u32 {v('addr', j)}, {s('delta0')}, {v('addr', j)}")
+            elif t % 3 == 0:
+                E(f"v_add_u32 {v('addr', j)}, {s('dRow')}, {v('addr', j)}")
+            else:
+                E(f"v_add_u32 {v('addr', j)}, 16, {v('addr', j)}")
+        E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)}" + (f" offset:{4 * PS}" if ks else ""))
+
+    for n in range(PD):
+        b_read(n)
+    # ---- the element stream ----
+    kD0, kD1 = 12, 12 + (2 * NB - 12) // 2
+    for n in range(NE):
+        h, j = divmod(n, NB)
+        t, ks = divmod(h, 2)
+        e = ks * NB + j
+        if n + PD < NE:
+            b_read(n + PD)
+        if e == 0:
+            kN = 6 + (2 if 2 <= t <= 7 else 0) + (2 if 1 <= t <= 6 else 0)
+            if t < 2:
+                lx, ld = uid("wx"), uid("wd")
+                E(f"s_cmp_eq_u32 {s('extra')}, 1")
+                E(f"s_cbranch_scc1 {lx}")
+                E(f"s_waitcnt vmcnt({kN})")
+                E(f"s_branch {ld}")
+                label(lx)
+                E(f"s_waitcnt vmcnt({min(63, kN + 3 * NB)})")
+                label(ld)
+            else:
+                E(f"s_waitcnt vmcnt({kN})", f"weights of tap {t}")
+        if 1 <= e <= 11 and e % 2 == 1:
+            k = e // 2
+            if k == 0:
+                emit_set_a_base("a_ld", t + 2)
+            emit_load_a((t + 2) % 3, k, s2("a_ld"), 0)
+        if t < 6 and e in (kD0, kD1):
+            emit_dma(t, 0 if e == kD0 else 1, s("cd"), s("bd"))
+        allowed = min(PD, NE - 1 - n)
+        E(f"s_waitcnt lgkmcnt({allowed})")
+        for i in range(3):
+            E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {vr('A', 24 * (t % 3) + 4 * (3 * ks + i), 4)}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
+    # ---- chunk end ----
+    # next chunk: delta0 = (next buffer - this buffer) * CHUNK - (2 Wp + 2) * 16
+    E(f"s_add_u32 {s('tmp0')}, {s('buf')}, 1")
+    E(f"s_cmp_ge_u32 {s('tmp0')}, 3")
+    E(f"s_cselect_b32 {s('tmp0')}, 0, {s('tmp0')}", "next buffer")
+    E(f"s_sub_i32 {s('tmp1')}, {s('tmp0')}, {s('buf')}")
+    E(f"s_mul_i32 {s('tmp1')}, {s('tmp1')}, {CHUNK}")
+    E(f"s_lshl_b32 {s('tmp2')}, {s('Wp')}, 5")
+    E(f"s_add_u32 {s('tmp2')}, {s('tmp2')}, 32", "(2 Wp + 2) * 16")
+    E(f"s_sub_i32 {s('delta0')}, {s('tmp1')}, {s('tmp2')}")
+    E(f"s_mov_b32 {s('buf')}, {s('tmp0')}")
+    E(f"s_mov_b32 {s('first')}, 0")
+    E(f"s_add_u32 {s('c')}, {s('c')}, 1")
+    E(f"s_cmp_lt_u32 {s('c')}, {s('CC')}")
+    E(f"s_cbranch_scc1 .Lchunk_{name}")
+
+    # =========================================== epilogue ===========================================
+    E("s_nop 15", "hz: MFMA result -> VALU read")
+    E("s_nop 15")
+    if RES:
+        E(f"s_waitcnt vmcnt(12)", "the residual (older than the 12 weight loads of the next tile's first taps)")
+    lact, lepd = uid("noact"), uid("epd")
+    for ACT in (True, False):
+        if ACT:
+            E(f"s_cmp_eq_u32 {s('act')}, 0")
+            E(f"s_cbranch_scc1 {lact}")
+        else:
+            label(lact)
+        for i in range(3):
+            for j in range(NB):
+                a0 = 4 * (3 * j + i)
+                X = V.names["t"][0] + 0      # x[0:3]
+                Y = V.names["t"][0] + 4      # work
+                Rr = V.names["t"][0] + 8     # residual as f32
+                E(f"s_sub_i32 {s('lim')}, {s('npix')}, {s('n0')}")
+                E(f"s_sub_i32 {s('lim')}, {s('lim')}, {16 * j}", "pixels of this block inside the batch")
+                for e in range(4):
+                    E(f"v_accvgpr_read_b32 v{X + e}, a{a0 + e}")
+                if ACT:
+                    E(f"v_pk_mul_f32 v[{Y}:{Y + 1}], v[{X}:{X + 1}], {s2('klog2e2')}")
+                    E(f"v_pk_mul_f32 v[{Y + 2}:{Y + 3}], v[{X + 2}:{X + 3}], {s2('klog2e2')}")
+                    for e in range(4):
+                        E(f"v_exp_f32 v{Y + e}, v{Y + e}")
+                    E(f"v_pk_add_f32 v[{Y}:{Y + 1}], v[{Y}:{Y + 1}], {s2('kone2')}")       # hz: 3 instructions after the exp that wrote v[Y]
+                    E(f"v_pk_add_f32 v[{Y + 2}:{Y + 3}], v[{Y + 2}:{Y + 3}], {s2('kone2')}")
+                    for e in range(4):
+                        E(f"v_rcp_f32 v{Y + e}, v{Y + e}")
+                    if RES:       # independent work between the rcp and its consumer (hz: transcendental -> consumer)
+                        r0 = V.names["R"][0] + 2 * (3 * j + i)
+                        E(f"v_lshlrev_b32 v{Rr}, 16, v{r0}")
+                        E(f"v_and_b32 v{Rr + 1}, 0xffff0000, v{r0}")
+                        E(f"v_lshlrev_b32 v{Rr + 2}, 16, v{r0 + 1}")
+                        E(f"v_and_b32 v{Rr + 3}, 0xffff0000, v{r0 + 1}")
+                    else:
+                        E("s_nop 0")
+                    E(f"v_pk_mul_f32 v[{X}:{X + 1}], v[{X}:{X + 1}], v[{Y}:{Y + 1}]")
+                    E(f"v_pk_mul_f32 v[{X + 2}:{X + 3}], v[{X + 2}:{X + 3}], v[{Y + 2}:{Y + 3}]")
+                elif RES:
+                    r0 = V.names["R"][0] + 2 * (3 * j + i)
+                    E(f"v_lshlrev_b32 v{Rr}, 16, v{r0}")
+                    E(f"v_and_b32 v{Rr + 1}, 0xffff0000, v{r0}")
+                    E(f"v_lshlrev_b32 v{Rr + 2}, 16, v{r0 + 1}")
+                    E(f"v_and_b32 v{Rr + 3}, 0xffff0000, v{r0 + 1}")
+                if RES:
+                    E(f"v_pk_add_f32 v[{X}:{X + 1}], v[{X}:{X + 1}], v[{Rr}:{Rr + 1}]")
+                    E(f"v_pk_add_f32 v[{X + 2}:{X + 3}], v[{X + 2}:{X + 3}], v[{Rr + 2}:{Rr + 3}]")
+                E(f"v_cvt_pk_bf16_f32 v{Y}, v{X}, v{X + 1}")
+                E(f"v_cvt_pk_bf16_f32 v{Y + 1}, v{X + 2}, v{X + 3}")
+                E(f"v_cmp_gt_i32 vcc, {s('lim')}, {v('l15')}", "pixel n0 + 16 j + l15 inside the batch?") if i == 0 or True else None
+                E("s_nop 1", "hz: VALU-written VCC read by SALU")
+                E("s_mov_b64 exec, vcc")
+                E(f"global_store_dwordx2 {v('oo', j)}, v[{Y}:{Y + 1}], {s2('out')} offset:{32 * i}")
+                E("s_mov_b64 exec, -1")
+        if ACT:
+            E(f"s_branch {lepd}")
+    label(lepd)
+    E(f"s_cmp_eq_u32 {s('has_next')}, 0")
+    E(f"s_cbranch_scc1 .Lend_{name}")
+    E(f"s_mov_b32 {s('tile')}, {s('next_tile')}")
+    E(f"s_branch .Ltile_{name}")
+    label(".Lend_" + name)
+    E("s_waitcnt vmcnt(0)")
+    E("s_endpgm")
+    return list(out)
+
+
+def descriptor(name):
+    return f"""
+	.rodata
+	.p2align 6
+	.amdhsa_kernel {name}
+		.amdhsa_group_segment_fixed_size 151552
+		.amdhsa_private_segment_fixed_size 0
+		.amdhsa_kernarg_size {ARG_BYTES}
+		.amdhsa_user_sgpr_count 2
+		.amdhsa_user_sgpr_kernarg_segment_ptr 1
+		.amdhsa_system_sgpr_workgroup_id_x 1
+		.amdhsa_system_vgpr_workitem_id 0
+		.amdhsa_next_free_vgpr 512
+		.amdhsa_next_free_sgpr {S.next}
+		.amdhsa_accum_offset 256
+		.amdhsa_reserve_vcc 1
+		.amdhsa_float_denorm_mode_32 3
+		.amdhsa_float_denorm_mode_16_64 3
+		.amdhsa_dx10_clamp 1
+		.amdhsa_ieee_mode 1
+	.end_amdhsa_kernel
+	.text
+"""
+
+
+def metadata(names):
+    ks = "".join(f"""  - .agpr_count:     256
+    .args:
+      - .offset:         0
+        .size:           {ARG_BYTES}
+        .value_kind:     by_value
+    .group_segment_fixed_size: 151552
+    .kernarg_segment_align: 8
+    .kernarg_segment_size: {ARG_BYTES}
+    .max_flat_workgroup_size: 256
+    .name:           {n}
+    .private_segment_fixed_size: 0
+    .sgpr_count:     {S.next + 6}
+    .symbol:         {n}.kd
+    .vgpr_count:     512
+    .wavefront_size: 64
+""" for n in names)
+    return f"""	.amdgpu_metadata
+---
+amdhsa.kernels:
+{ks}amdhsa.target:   amdgcn-amd-amdhsa--gfx950
+amdhsa.version:
+  - 1
+  - 2
+...
+	.end_amdgpu_metadata
+"""
+
+
+def main():
+    path = sys.argv[1] if len(sys.argv) > 1 else "conv3x3_pl_asm.s"
+    text = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.text"]
+    names = []
+    for RES in (False, True):
+        name = f"conv3x3_pl_asm_nb{NB}_res{int(RES)}"
+        names.append(name)
+        text += [f"\t.globl\t{name}", "\t.p2align\t8", f"\t.type\t{name},@function"]
+        text += gen_kernel(name, RES)
+        text += [f".Lfend_{name}:", f"\t.size\t{name}, .Lfend_{name}-{name}", descriptor(name)]
+    text.append(metadata(names))
+    with open(path, "w") as f:
+        f.write("\n".join(text) + "\n")
+    print(f"wrote {path}: {sum(1 for l in text if 'v_mfma' in l)} MFMAs, VGPRs used {V.next}, SGPRs used {S.next}")
+
+
+if __name__ == "__main__":
+    main()

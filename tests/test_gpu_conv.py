@@ -300,16 +300,21 @@ PL_CASES = [
     (2, 36, 44, 256, 384, "inplace", True),    # four chunks, two M tiles, odd sizes
     (40, 40, 40, 192, 192, "inplace", True),   # more tiles than CUs: persistent workgroups walk several tiles (prefetch across the tile seam)
     (70, 20, 20, 384, 384, "sep", True),       # the same with two M tiles
+    (3, 10, 10, 768, 768, "sep", True),        # model.9-sized: four M tiles, twelve chunks
+    (4, 12, 12, 128, 576, None, True),         # three M tiles (not a power of two: the HIP-source kernel for every NB)
 ]
 
 
 @pytest.mark.parametrize("case", PL_CASES)
-@pytest.mark.parametrize("nb", [13, 10, 7])
+@pytest.mark.parametrize("nb", ["13asm", 13, 10, 7])
 def test_planar_conv3x3_matches_reference(lib, case, nb, monkeypatch):
     """aq_conv3x3_pl vs F.conv2d on bf16-rounded operands; input, output and shortcut are channel slices of wider tensors; every
-    pixel-block count of the kernel, tiles that end inside images, at image seams and past the end of the batch."""
+    pixel-block count of the kernel, tiles that end inside images, at image seams and past the end of the batch.  "13asm" is the
+    hand-scheduled assembly build of the NB = 13 kernel (gen_conv3x3_pl_asm.py), the plain numbers the HIP-source kernel."""
     from aquaculture_amd import engine
     B, H, W, cin, c, resmode, act = case
+    monkeypatch.setenv("AQ_PL_ASM", "1" if nb == "13asm" else "0")
+    nb = 13 if nb == "13asm" else nb
     monkeypatch.setenv("AQ_PL_NB", str(nb))
     g = torch.Generator().manual_seed(c * 7 + H * 3 + nb)
     xw = (torch.randn(B, H, W, cin + 16, generator=g) * 0.8).bfloat16().cuda()
