@@ -394,7 +394,7 @@ const unsigned char kPlAsmCode[] = {
 #include "conv3x3_pl_asm_hsaco.inc"
 };
 hipModule_t g_pl_asm_mod[64];
-hipFunction_t g_pl_asm_fn[64][2];
+hipFunction_t g_pl_asm_fn[64][3];
 
 struct PlKernel { int nb; void (*plain)(const PlParams); void (*res)(const PlParams); };
 struct PlAblation { int abl; void (*fn)(const PlParams); };
@@ -543,6 +543,7 @@ extern "C" int aq_conv3x3_pl(const void* in_dev, long long in_sp, long long in_s
             AQ_CHECK_HIP(hipModuleLoadData(&g_pl_asm_mod[dev], kPlAsmCode));
             AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_asm_fn[dev][0], g_pl_asm_mod[dev], "conv3x3_pl_asm_nb13_res0"));
             AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_asm_fn[dev][1], g_pl_asm_mod[dev], "conv3x3_pl_asm_nb13_res1"));
+            AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_asm_fn[dev][2], g_pl_asm_mod[dev], "conv3x3_pl_asm_nb13_res1_stamped"));
         }
         PlAsmArgs a{};
         a.in = p.in; a.in_sp = p.in_sp; a.in_ss = p.in_ss; a.out = p.out; a.res = p.res; a.w = p.w; a.bias = p.bias; a.zero = p.zero;
@@ -551,9 +552,15 @@ extern "C" int aq_conv3x3_pl(const void* in_dev, long long in_sp, long long in_s
         a.mt_log2 = 0;
         while ((1 << a.mt_log2) < p.n_mt) ++a.mt_log2;
         a.inv_hw = p.inv_hw; a.inv_w = p.inv_w; a.inv_hpwp = p.inv_hpwp; a.inv_wp = p.inv_wp; a.debug = nullptr;
+        int which = res_dev ? 1 : 0;
+        if (use_asm && *use_asm == '2' && res_dev) {        // stamped diagnostic build (tools/time_conv3x3.py --stamp): per-wave phase cycle sums
+            size_t sbytes = 0;
+            unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
+            if (sbuf && sbytes >= (size_t)grid * 4 * 64) { a.debug = sbuf; which = 2; }
+        }
         size_t asz = sizeof(a);
         void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
-        AQ_CHECK_HIP(hipModuleLaunchKernel(g_pl_asm_fn[dev][res_dev ? 1 : 0], (unsigned)grid, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
+        AQ_CHECK_HIP(hipModuleLaunchKernel(g_pl_asm_fn[dev][which], (unsigned)grid, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
         return AQ_OK;
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);

@@ -76,6 +76,9 @@ S.alloc("a_nxt", 2, 2)
 S.alloc("a_ld", 2, 2)         # base of the weight loads being issued
 S.alloc("dbase", 2, 2)        # LDS-DMA: input base of (chunk, plane)
 S.alloc("t64", 2, 2)
+S.alloc("st_acc", 12, 2)      # stamped build only: cycle sums of six phases
+S.alloc("st_last", 2, 2)
+S.alloc("st_rt0", 2, 2)
 
 
 def s(name, i=0):
@@ -314,13 +317,28 @@ def emit_barrier():
     E("s_barrier")
 
 
-# ------------------------------------------------------------------------------------------------------------------------------
-# kernel
-# ------------------------------------------------------------------------------------------------------------------------------
-def gen_kernel(name, RES):
+STAMPED = [False]
+PH_PROLOGUE, PH_BARRIER, PH_STREAM, PH_SETUP, PH_EPILOGUE, PH_TOP = range(6)
+
+
+def stamp(k):
+    """Stamped build: add the shader clocks since the previous stamp to phase k's sum (t64, tmp0, tmp1 are dead at every stamp point)."""
+    if not STAMPED[0]:
+        return
+    E(f"s_memtime {s2('t64')}")
+    E("s_waitcnt lgkmcnt(0)")
+    E(f"s_sub_u32 {s('tmp0')}, {s('t64')}, {s('st_last')}")
+    E(f"s_subb_u32 {s('tmp1')}, {s('t64', 1)}, {s('st_last', 1)}")
+    E(f"s_add_u32 {s('st_acc', 2 * k)}, {s('st_acc', 2 * k)}, {s('tmp0')}")
+    E(f"s_addc_u32 {s('st_acc', 2 * k + 1)}, {s('st_acc', 2 * k + 1)}, {s('tmp1')}")
+    E(f"s_mov_b64 {s2('st_last')}, {s2('t64')}")
+
+
+def gen_kernel(name, RES, stamped=False):
     global out
     out = []
-    _uid[0], _uid[1] = 0, name[-9:].replace("_", "")
+    STAMPED[0] = stamped
+    _uid[0], _uid[1] = 0, name.split("asm_", 1)[1].replace("_", "")
     E(f"; conv3x3_pl assembly, NB = {NB}, RES = {int(RES)}: generated by gen_conv3x3_pl_asm.py -- do not edit")
     label(name)
     # ---- arguments ----
@@ -357,6 +375,12 @@ def gen_kernel(name, RES):
     E(f"s_mov_b32 {s('klog2e2', 1)}, 0xbfb8aa3b")
     E(f"s_mov_b32 {s('kone2')}, 1.0")
     E(f"s_mov_b32 {s('kone2', 1)}, 1.0")
+    if stamped:
+        for k in range(12):
+            E(f"s_mov_b32 {s('st_acc', k)}, 0")
+        E(f"s_memrealtime {s2('st_rt0')}")
+        E(f"s_memtime {s2('st_last')}")
+        E("s_waitcnt lgkmcnt(0)")
     # ---- first tile: XCD-aware bijective map (blocks sharing an XCD get consecutive tiles) ----
     E(f"s_lshr_b32 {s('tmp0')}, {s('G')}, 3", "q")
     E(f"s_and_b32 {s('tmp1')}, {s('G')}, 7", "r")
@@ -414,6 +438,7 @@ def gen_kernel(name, RES):
             emit_dma(k, s2i, s("cd"), s("bd"))
     E("s_waitcnt vmcnt(12)", "all but chunk 1's LDS-DMA: weights of taps 0 and 1, chunk 0, the bias")
     emit_barrier()
+    stamp(PH_PROLOGUE)
     E(f"s_mov_b32 {s('buf')}, 0")
     E(f"s_mov_b32 {s('first')}, 1")
 
@@ -460,10 +485,12 @@ def gen_kernel(name, RES):
                 E(f"v_accvgpr_write_b32 a{4 * (3 * j + i) + e}, {v('t', e)}")
     E(f"s_mov_b32 {s('c')}, 0")
     E(f"s_mov_b32 {s('delta0')}, 0", "the first chunk of a tile starts at tap 0 of its own buffer")
+    stamp(PH_SETUP)
 
     # =========================================== chunk loop ===========================================
     label(".Lchunk_" + name)
     emit_barrier()
+    stamp(PH_BARRIER)
     E(f"s_add_u32 {s('tmp0')}, {s('c')}, 1")
     E(f"s_cmp_eq_u32 {s('tmp0')}, {s('CC')}")
     E(f"s_cselect_b32 {s('lastc')}, 1, 0")
@@ -527,6 +554,8 @@ def gen_kernel(name, RES):
             for i in range(3):
                 E(f"global_load_dwordx2 {vr('R', 2 * (3 * j + i), 2)}, {T[4]}, {s2('res')} offset:{32 * i}")
         label(lnr)
+    stamp(PH_TOP)
+
     # first B fragments
     def b_read(n):
         h, j = divmod(n, NB)
@@ -576,6 +605,7 @@ def gen_kernel(name, RES):
         for i in range(3):
             E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {vr('A', 24 * (t % 3) + 4 * (3 * ks + i), 4)}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
     # ---- chunk end ----
+    stamp(PH_STREAM)
     # next chunk: delta0 = (next buffer - this buffer) * CHUNK - (2 Wp + 2) * 16
     E(f"s_add_u32 {s('tmp0')}, {s('buf')}, 1")
     E(f"s_cmp_ge_u32 {s('tmp0')}, 3")
@@ -651,12 +681,36 @@ def gen_kernel(name, RES):
         if ACT:
             E(f"s_branch {lepd}")
     label(lepd)
+    if stamped:
+        E("s_waitcnt vmcnt(0)", "stamped build: the stores' drain belongs to the epilogue")
+    stamp(PH_EPILOGUE)
     E(f"s_cmp_eq_u32 {s('has_next')}, 0")
     E(f"s_cbranch_scc1 .Lend_{name}")
     E(f"s_mov_b32 {s('tile')}, {s('next_tile')}")
     E(f"s_branch .Ltile_{name}")
     label(".Lend_" + name)
     E("s_waitcnt vmcnt(0)")
+    if stamped:
+        # row (wg * 4 + wave) of the stamp buffer: six phase sums, their total, elapsed 100 MHz ticks
+        E(f"s_memrealtime {s2('t64')}")
+        E("s_waitcnt lgkmcnt(0)")
+        E(f"s_sub_u32 {s('st_rt0')}, {s('t64')}, {s('st_rt0')}")
+        E(f"s_subb_u32 {s('st_rt0', 1)}, {s('t64', 1)}, {s('st_rt0', 1)}")
+        E(f"s_mov_b64 {s2('st_last')}, 0")
+        for k in range(6):
+            E(f"s_add_u32 {s('st_last')}, {s('st_last')}, {s('st_acc', 2 * k)}")
+            E(f"s_addc_u32 {s('st_last', 1)}, {s('st_last', 1)}, {s('st_acc', 2 * k + 1)}")
+        E(f"s_lshl_b32 {s('tmp0')}, {s('wg')}, 2")
+        E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {s('wave')}")
+        E(f"s_lshl_b32 {s('tmp0')}, {s('tmp0')}, 6")
+        E(f"v_mov_b32 {v('t', 2)}, {s('tmp0')}")
+        E("s_mov_b64 exec, 1")
+        vals = [(s('st_acc', 2 * k), s('st_acc', 2 * k + 1)) for k in range(6)] + [(s('st_last'), s('st_last', 1)), (s('st_rt0'), s('st_rt0', 1))]
+        for k, (lo, hi) in enumerate(vals):
+            E(f"v_mov_b32 {v('t', 0)}, {lo}")
+            E(f"v_mov_b32 {v('t', 1)}, {hi}")
+            E(f"global_store_dwordx2 {v('t', 2)}, {vr('t', 0, 2)}, {s2('debug')} offset:{8 * k}")
+            E("s_waitcnt vmcnt(0)")
     E("s_endpgm")
     return list(out)
 
@@ -719,11 +773,11 @@ def main():
     path = sys.argv[1] if len(sys.argv) > 1 else "conv3x3_pl_asm.s"
     text = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.text"]
     names = []
-    for RES in (False, True):
-        name = f"conv3x3_pl_asm_nb{NB}_res{int(RES)}"
+    for RES, stamped in ((False, False), (True, False), (True, True)):
+        name = f"conv3x3_pl_asm_nb{NB}_res{int(RES)}" + ("_stamped" if stamped else "")
         names.append(name)
         text += [f"\t.globl\t{name}", "\t.p2align\t8", f"\t.type\t{name},@function"]
-        text += gen_kernel(name, RES)
+        text += gen_kernel(name, RES, stamped)
         text += [f".Lfend_{name}:", f"\t.size\t{name}, .Lfend_{name}-{name}", descriptor(name)]
     text.append(metadata(names))
     with open(path, "w") as f:
