@@ -393,8 +393,12 @@ static_assert(sizeof(PlAsmArgs) == 136, "kernel argument block");
 const unsigned char kPlAsmCode[] = {
 #include "conv3x3_pl_asm_hsaco.inc"
 };
+// families of the assembly build: pixel blocks per tile, region rows of its LDS planes, workgroups per CU (gen_conv3x3_pl_asm.py CONFIGS)
+struct PlAsmFamily { int nb, rows, occ; };
+const PlAsmFamily kPlAsm[] = {{13, 384, 1}, {7, 256, 2}, {8, 256, 2}};
+constexpr int kNumPlAsm = sizeof(kPlAsm) / sizeof(kPlAsm[0]);
 hipModule_t g_pl_asm_mod[64];
-hipFunction_t g_pl_asm_fn[64][3];
+hipFunction_t g_pl_asm_fn[64][kNumPlAsm][3];
 
 struct PlKernel { int nb; void (*plain)(const PlParams); void (*res)(const PlParams); };
 struct PlAblation { int abl; void (*fn)(const PlParams); };
@@ -504,20 +508,66 @@ extern "C" int aq_conv3x3_pl(const void* in_dev, long long in_sp, long long in_s
     p.CC = cin / 64; p.n_mt = cout / PL_BM;
     p.inv_hw = 1.0f / (float)(H * W); p.inv_w = 1.0f / (float)W;
     p.inv_hpwp = 1.0f / (float)((H + 1) * (W + 1)); p.inv_wp = 1.0f / (float)(W + 1);
+    // tile shape: AQ_PL_NB forces the pixel-block count; the assembly build of that count is used when it exists and fits
+    // (AQ_PL_ASM=0: HIP-source kernels only -- A/B and fallback; =2: the stamped assembly build when a stamp buffer is armed)
     int rows = 0, k = pl_pick(B, H, W, p.n_mt, g_pl_cus[dev], &rows);
     const char* forced = getenv("AQ_PL_NB");
+    const char* use_asm = getenv("AQ_PL_ASM");
+    const char* abl = getenv("AQ_PL_ABL");                  // timing-only diagnostic builds (wrong results), NB = 13 with shortcut only
+    int nb = k >= 0 ? kPl[k].nb : 0;
     if (forced && *forced) {
+        nb = atoi(forced);
         k = -1;
         for (int i = 0; i < kNumPl; ++i)
-            if (kPl[i].nb == atoi(forced) && pl_region_rows(B, H, W, kPl[i].nb * 16) <= PL_ROWS) k = i;
+            if (kPl[i].nb == nb && pl_region_rows(B, H, W, nb * 16) <= PL_ROWS) k = i;
     }
-    AQ_REQUIRE(k >= 0, "conv3x3_pl: no tile of this kernel fits a %d-wide image in its %d region rows", W, PL_ROWS);
-    const int bn = kPl[k].nb * 16;
+    int fam = -1;
+    if (!(use_asm && *use_asm == '0') && !(abl && *abl) && (p.n_mt & (p.n_mt - 1)) == 0 && in_sp < (1LL << 32) && in_ss < (1LL << 31))
+        for (int i = 0; i < kNumPlAsm; ++i)
+            if (kPlAsm[i].nb == nb && pl_region_rows(B, H, W, nb * 16) <= kPlAsm[i].rows) fam = i;
+    AQ_REQUIRE(k >= 0 || fam >= 0, "conv3x3_pl: no tile of this kernel fits a %d-wide image in its region rows", W);
+    const int bn = nb * 16;
     const long long ntiles = ((long long)p.npix + bn - 1) / bn * p.n_mt;
     AQ_REQUIRE(ntiles > 0 && ntiles < (1LL << 30), "conv3x3_pl: bad tile count");
     p.ntiles = (int)ntiles;
+    if (fam >= 0) {
+        if (!g_pl_asm_mod[dev]) {
+            AQ_CHECK_HIP(hipModuleLoadData(&g_pl_asm_mod[dev], kPlAsmCode));
+            for (int i = 0; i < kNumPlAsm; ++i)
+                for (int v = 0; v < 3; ++v) {
+                    char name[64];
+                    snprintf(name, sizeof name, "conv3x3_pl_asm_nb%d_res%d%s", kPlAsm[i].nb, v ? 1 : 0, v == 2 ? "_stamped" : "");
+                    AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_asm_fn[dev][i][v], g_pl_asm_mod[dev], name));
+                }
+        }
+        long long grid = (long long)g_pl_cus[dev] * kPlAsm[fam].occ;
+        if (grid > ntiles) grid = ntiles;
+        PlAsmArgs a{};
+        a.in = p.in; a.in_sp = p.in_sp; a.in_ss = p.in_ss; a.out = p.out; a.res = p.res; a.w = p.w; a.bias = p.bias; a.zero = p.zero;
+        a.out_ld_b = p.out_ld_b; a.res_ld_b = p.res_ld_b; a.B = p.B; a.H = p.H; a.W = p.W; a.npix = p.npix; a.cout = p.cout; a.act = p.act;
+        a.CC = p.CC; a.ntiles = p.ntiles; a.G = (int)grid;
+        a.mt_log2 = 0;
+        while ((1 << a.mt_log2) < p.n_mt) ++a.mt_log2;
+        a.inv_hw = p.inv_hw; a.inv_w = p.inv_w; a.inv_hpwp = p.inv_hpwp; a.inv_wp = p.inv_wp; a.debug = nullptr;
+        int which = res_dev ? 1 : 0;
+        if (use_asm && *use_asm == '2' && res_dev) {        // stamped diagnostic build (tools/time_conv3x3.py --stamp): per-wave phase cycle sums
+            size_t sbytes = 0;
+            unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
+            if (sbuf && sbytes >= (size_t)grid * 4 * 64) { a.debug = sbuf; which = 2; }
+        }
+        hipFunction_t fn_asm = g_pl_asm_fn[dev][fam][which];
+        const char* asm_abl = getenv("AQ_PL_ASM_ABL");      // timing-only ablations of the stamped build (wrong results)
+        if (which == 2 && asm_abl && *asm_abl) {
+            char name[80];
+            snprintf(name, sizeof name, "conv3x3_pl_asm_nb%d_res1_stamped_abl%d", nb, atoi(asm_abl));
+            AQ_CHECK_HIP(hipModuleGetFunction(&fn_asm, g_pl_asm_mod[dev], name));
+        }
+        size_t asz = sizeof(a);
+        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+        AQ_CHECK_HIP(hipModuleLaunchKernel(fn_asm, (unsigned)grid, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
+        return AQ_OK;
+    }
     auto fn = res_dev ? kPl[k].res : kPl[k].plain;
-    const char* abl = getenv("AQ_PL_ABL");                  // timing-only diagnostic builds (wrong results), NB = 13 with shortcut only
     bool ablated = false;
     if (abl && *abl && kPl[k].nb == 13 && res_dev)
         for (const PlAblation& a : kPlAbl)
@@ -536,33 +586,6 @@ extern "C" int aq_conv3x3_pl(const void* in_dev, long long in_sp, long long in_s
     }
     long long grid = g_pl_cus[dev];
     if (grid > ntiles) grid = ntiles;
-    // the assembly build: NB = 13, power-of-two M-tile count; AQ_PL_ASM=0 keeps the HIP-source kernel (A/B, fallback)
-    const char* use_asm = getenv("AQ_PL_ASM");
-    if (kPl[k].nb == 13 && !ablated && (p.n_mt & (p.n_mt - 1)) == 0 && in_sp < (1LL << 32) && in_ss < (1LL << 31) && !(use_asm && *use_asm == '0')) {
-        if (!g_pl_asm_mod[dev]) {
-            AQ_CHECK_HIP(hipModuleLoadData(&g_pl_asm_mod[dev], kPlAsmCode));
-            AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_asm_fn[dev][0], g_pl_asm_mod[dev], "conv3x3_pl_asm_nb13_res0"));
-            AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_asm_fn[dev][1], g_pl_asm_mod[dev], "conv3x3_pl_asm_nb13_res1"));
-            AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_asm_fn[dev][2], g_pl_asm_mod[dev], "conv3x3_pl_asm_nb13_res1_stamped"));
-        }
-        PlAsmArgs a{};
-        a.in = p.in; a.in_sp = p.in_sp; a.in_ss = p.in_ss; a.out = p.out; a.res = p.res; a.w = p.w; a.bias = p.bias; a.zero = p.zero;
-        a.out_ld_b = p.out_ld_b; a.res_ld_b = p.res_ld_b; a.B = p.B; a.H = p.H; a.W = p.W; a.npix = p.npix; a.cout = p.cout; a.act = p.act;
-        a.CC = p.CC; a.ntiles = p.ntiles; a.G = (int)grid;
-        a.mt_log2 = 0;
-        while ((1 << a.mt_log2) < p.n_mt) ++a.mt_log2;
-        a.inv_hw = p.inv_hw; a.inv_w = p.inv_w; a.inv_hpwp = p.inv_hpwp; a.inv_wp = p.inv_wp; a.debug = nullptr;
-        int which = res_dev ? 1 : 0;
-        if (use_asm && *use_asm == '2' && res_dev) {        // stamped diagnostic build (tools/time_conv3x3.py --stamp): per-wave phase cycle sums
-            size_t sbytes = 0;
-            unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
-            if (sbuf && sbytes >= (size_t)grid * 4 * 64) { a.debug = sbuf; which = 2; }
-        }
-        size_t asz = sizeof(a);
-        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
-        AQ_CHECK_HIP(hipModuleLaunchKernel(g_pl_asm_fn[dev][which], (unsigned)grid, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
-        return AQ_OK;
-    }
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;

@@ -25,14 +25,36 @@ Usage: python gen_conv3x3_pl_asm.py OUT.s   (aquaculture_amd/build.py assembles 
 """
 import sys
 
-NB = 13
-PD = 8
-NE = 18 * NB
-ROWS = 384
-PS = ROWS * 16
-CHUNK = 8 * PS
-BIAS_OFF = 3 * CHUNK
+# Two families.  "nb13": one workgroup per CU (one wave per SIMD, the whole register file), three ring buffers, the residual in its own
+# registers fetched under the last chunk.  "nb7" / "nb8": TWO workgroups per CU (<= 256 registers per wave, <= 80 KB LDS), so that one
+# workgroup's chunk tops, epilogue and prologue run under the other's MFMAs; two ring buffers of 256 region rows, and the residual is
+# fetched at the start of the epilogue into registers the stream has finished with (weight set 2 and the B ring).
+# LOOK = how many taps ahead the weights are loaded (LOOK + 1 fragment sets of 24 registers).  Loads return in order, so every LDS-DMA or
+# residual load (HBM / MALL latency) holds back the weight loads issued behind it: with LOOK = 2 such a load has two taps (2.5 k cycles)
+# before it stalls the stream, and the stamped builds showed exactly that stall; the one-workgroup family keeps its FOUR sets in the
+# accumulator half of the register file (100 AGPRs are free there), which also frees 72 VGPRs for a deeper B ring.
+CONFIGS = {
+    13: dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False),
+    7: dict(NB=7, PD=8, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False),
+    8: dict(NB=8, PD=7, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False),
+}
 STEP_B = 6 * 1024
+
+
+def configure(nb):
+    """Sets the module-level tile constants and (re)allocates the registers of one family."""
+    g = globals()
+    g.update(CONFIGS[nb])
+    g["NE"] = 18 * NB
+    g["NG"] = ROWS // 64
+    g["PS"] = ROWS * 16
+    g["CHUNK"] = 8 * PS
+    g["BIAS_OFF"] = RING * CHUNK
+    g["LDS_BYTES"] = BIAS_OFF + 4096
+    assert ROWS % 64 == 0 and NB >= 6 and NG + 2 <= 8
+    assert 9 % (LOOK + 1) == 0, "a chunk has 9 taps: the weight sets must come round at its end"
+    allocate_registers()
+
 
 # ---- kernel argument block (must match PlAsmArgs in conv3x3_pl.hip) ----
 ARG = dict(inp=0, in_sp=8, in_ss=16, out=24, res=32, w=40, bias=48, zero=56, out_ld=64, res_ld=68, B=72, H=76, W=80, npix=84, cout=88, act=92,
@@ -55,30 +77,54 @@ class Regs:
         return base
 
 
-V = Regs("v", 256)
-S = Regs("s", 100)
+V = S = None
 
-# ---------------- SGPRs ----------------
-S.alloc("karg", 2)            # s[0:1]
-S.alloc("wg", 1)              # s2
-for nm in ("inp", "in_sp", "in_ss", "out", "res", "w", "bias", "zero"):
-    S.alloc(nm, 2, 2)
-for nm in ("out_ld", "res_ld", "B", "H", "W", "npix", "cout", "act", "CC", "mt_log2", "ntiles", "G", "inv_hw", "inv_w", "inv_hpwp", "inv_wp"):
-    S.alloc(nm)
-S.alloc("debug", 2, 2)
-for nm in ("HW", "Wp", "HpWp", "lead", "Hpad", "tile", "next_tile", "has_next", "nt", "mt", "n0", "cbase", "c", "buf", "cd", "bd", "lastc", "extra",
-           "rs", "rs_dma", "delta0", "dRow", "wave", "smem", "first", "tmp0", "tmp1", "tmp2", "tmp3", "dlds", "lim"):
-    S.alloc(nm)
-S.alloc("klog2e2", 2, 2)      # (-log2 e, -log2 e) for v_pk_mul_f32
-S.alloc("kone2", 2, 2)        # (1.0, 1.0)
-S.alloc("a_cur", 2, 2)
-S.alloc("a_nxt", 2, 2)
-S.alloc("a_ld", 2, 2)         # base of the weight loads being issued
-S.alloc("dbase", 2, 2)        # LDS-DMA: input base of (chunk, plane)
-S.alloc("t64", 2, 2)
-S.alloc("st_acc", 12, 2)      # stamped build only: cycle sums of six phases
-S.alloc("st_last", 2, 2)
-S.alloc("st_rt0", 2, 2)
+
+def allocate_registers():
+    global V, S
+    V = Regs("v", 256)
+    S = Regs("s", 102)
+
+    # ---------------- SGPRs ----------------
+    S.alloc("karg", 2)            # s[0:1]
+    S.alloc("wg", 1)              # s2
+    for nm in ("inp", "in_sp", "in_ss", "out", "res", "w", "bias", "zero"):
+        S.alloc(nm, 2, 2)
+    for nm in ("out_ld", "res_ld", "B", "H", "W", "npix", "cout", "act", "CC", "mt_log2", "ntiles", "G", "inv_hw", "inv_w", "inv_hpwp", "inv_wp"):
+        S.alloc(nm)
+    S.alloc("debug", 2, 2)
+    for nm in ("HW", "Wp", "HpWp", "lead", "Hpad", "tile", "next_tile", "has_next", "n0", "cbase", "c", "buf", "cd", "bd", "lastc", "extra",
+               "rs", "rs_dma", "delta0", "dRow", "wave", "first", "tmp0", "tmp1", "tmp2", "tmp3", "dlds", "lim", "par", "rlim"):
+        S.alloc(nm)
+    S.alloc("klog2e2", 2, 2)      # (-log2 e, -log2 e) for v_pk_mul_f32
+    S.alloc("kone2", 2, 2)        # (1.0, 1.0)
+    S.alloc("a_cur", 2, 2)
+    S.alloc("a_nxt", 2, 2)
+    S.alloc("a_ld", 2, 2)         # base of the weight loads being issued
+    S.alloc("dbase", 2, 2)        # LDS-DMA: input base of (chunk, plane)
+    S.alloc("t64", 2, 2)
+    S.alloc("st_acc", 12, 2)      # stamped build only: cycle sums of six phases
+    S.alloc("st_last", 2, 2)
+    S.alloc("st_rt0", 2, 2)
+    # ---------------- VGPRs ----------------
+    V.alloc("tid")                # v0 on entry
+    V.alloc("lane")
+    V.alloc("l15")
+    V.alloc("q")
+    V.alloc("aoff")               # lane * 16
+    V.alloc("qps")                # q * PS
+    V.alloc("insp")               # in_sp (low 32 bits) as a VGPR operand of v_mad_u64_u32
+    V.alloc("zero_lo")
+    V.alloc("zero_hi")
+    if not A_IN_ACC:
+        V.alloc("A", 24 * (LOOK + 1), 4)
+    V.alloc("B", 4 * (PD + 1), 4)
+    V.alloc("addr", NB)
+    V.alloc("prow", NG)
+    if RES_EARLY:
+        V.alloc("R", 6 * NB, 2)
+    V.alloc("oo", NB)
+    V.alloc("t", 24, 4)           # temporaries
 
 
 def s(name, i=0):
@@ -92,25 +138,6 @@ def s2(name, i=0):
     return f"s[{b + i}:{b + i + 1}]"
 
 
-# ---------------- VGPRs ----------------
-V.alloc("tid")                # v0 on entry
-V.alloc("lane")
-V.alloc("l15")
-V.alloc("q")
-V.alloc("aoff")               # lane * 16
-V.alloc("qps")                # q * PS
-V.alloc("insp")               # in_sp (low 32 bits) as a VGPR operand of v_mad_u64_u32
-V.alloc("zero_lo")
-V.alloc("zero_hi")
-V.alloc("A", 72, 4)
-V.alloc("B", 4 * (PD + 1), 4)
-V.alloc("addr", NB)
-V.alloc("prow", 6)
-V.alloc("R", 6 * NB, 2)
-V.alloc("oo", NB)
-V.alloc("t", 24, 4)           # temporaries
-
-
 def v(name, i=0):
     b, n = V.names[name]
     assert i < n, (name, i)
@@ -121,6 +148,27 @@ def vr(name, i, cnt):
     b, n = V.names[name]
     assert i + cnt <= n, (name, i, cnt)
     return f"v[{b + i}:{b + i + cnt - 1}]"
+
+
+def rreg(b):
+    """First register of residual pair b (0 .. 3 NB - 1): its own block, or (two-workgroup families) weight set 2 and then the B ring."""
+    if RES_EARLY:
+        return V.names["R"][0] + 2 * b
+    assert 3 * NB <= 12 + 2 * (PD + 1) and LOOK == 2 and not A_IN_ACC
+    return V.names["A"][0] + 48 + 2 * b if b < 12 else V.names["B"][0] + 2 * (b - 12)
+
+
+def areg(set_idx, k):
+    """The four registers of fragment k (0 .. 5) of weight set set_idx."""
+    assert 0 <= set_idx <= LOOK and 0 <= k < 6
+    if A_IN_ACC:
+        b = 12 * NB + 24 * set_idx + 4 * k
+        return f"a[{b}:{b + 3}]"
+    return vr("A", 24 * set_idx + 4 * k, 4)
+
+
+def n_acc():
+    return 12 * NB + (24 * (LOOK + 1) if A_IN_ACC else 0)
 
 
 def acc(i, j):
@@ -236,10 +284,10 @@ def emit_rs_of_tile(tile_s, dst_s):
 
 
 def emit_region_rows(tile_s):
-    """prow[k] = unpad(rs(tile) + 64 k + lane) for k = 0..5."""
+    """prow[k] = unpad(rs(tile) + 64 k + lane) for k = 0 .. NG - 1."""
     emit_rs_of_tile(tile_s, s("rs_dma"))
     T = [v("t", i) for i in range(6)]
-    for k in range(6):
+    for k in range(NG):
         E(f"v_add_u32 {T[5]}, {s('rs_dma')}, {v('lane')}")
         if k:
             E(f"v_add_u32 {T[5]}, {64 * k}, {T[5]}")
@@ -247,7 +295,7 @@ def emit_region_rows(tile_s):
 
 
 def emit_no_rows():
-    for k in range(6):
+    for k in range(NG):
         E(f"v_mov_b32 {v('prow', k)}, -1")
 
 
@@ -265,7 +313,7 @@ def emit_dma(k, s2i, cd_s, bd_s):
     E(f"s_addc_u32 {s('dbase', 1)}, {s('inp', 1)}, {s('tmp3')}")
     E(f"s_mul_i32 {s('tmp2')}, {bd_s}, {CHUNK}")
     E(f"s_mul_i32 {s('tmp1')}, {s('tmp1')}, {PS}")
-    E(f"s_add_u32 {s('dlds')}, {s('smem')}, {s('tmp2')}")
+    E(f"s_mov_b32 {s('dlds')}, {s('tmp2')}", "the ring starts at LDS address 0")
     E(f"s_add_u32 {s('dlds')}, {s('dlds')}, {s('tmp1')}")
     E(f"s_add_u32 {s('dlds')}, {s('dlds')}, {k * 1024}")
     E(f"v_max_i32 {T[2]}, 0, {v('prow', k)}")
@@ -282,7 +330,7 @@ def emit_load_a(set_idx, k, base_s2, extra_off):
     """fragment k (0..5) of a tap-step into A set set_idx: 1 KB at base + extra_off + 1024 k (base is the tap-step's stream + 3072)."""
     off = 1024 * k - 3072 + extra_off
     assert -4096 <= off <= 4095
-    E(f"global_load_dwordx4 {vr('A', 24 * set_idx + 4 * k, 4)}, {v('aoff')}, {base_s2} offset:{off}")
+    E(f"global_load_dwordx4 {areg(set_idx, k)}, {v('aoff')}, {base_s2} offset:{off}")
 
 
 def emit_set_a_base(dst, tap):
@@ -334,12 +382,14 @@ def stamp(k):
     E(f"s_mov_b64 {s2('st_last')}, {s2('t64')}")
 
 
-def gen_kernel(name, RES, stamped=False):
+def gen_kernel(name, RES, stamped=False, abl=0):
+    """abl: timing-only ablations of the stamped build (wrong results): 1 = no weight loads in the stream, 2 = no LDS-DMA in the stream,
+    4 = no B fragment reads, 8 = no MFMAs."""
     global out
     out = []
     STAMPED[0] = stamped
     _uid[0], _uid[1] = 0, name.split("asm_", 1)[1].replace("_", "")
-    E(f"; conv3x3_pl assembly, NB = {NB}, RES = {int(RES)}: generated by gen_conv3x3_pl_asm.py -- do not edit")
+    E(f"; conv3x3_pl assembly, NB = {NB}, {OCC} workgroup(s) per CU, RES = {int(RES)}: generated by gen_conv3x3_pl_asm.py -- do not edit")
     label(name)
     # ---- arguments ----
     E(f"s_load_dwordx8 s[{S.names['inp'][0]}:{S.names['inp'][0] + 7}], {s2('karg')}, 0x0", "inp, in_sp, in_ss, out")
@@ -350,6 +400,8 @@ def gen_kernel(name, RES, stamped=False):
     assert S.names['in_sp'][0] == S.names['inp'][0] + 2 and S.names['out'][0] == S.names['inp'][0] + 6
     assert S.names['zero'][0] == S.names['res'][0] + 6 and S.names['act'][0] == S.names['out_ld'][0] + 7
     assert S.names['inv_wp'][0] == S.names['CC'][0] + 7 and S.names['inp'][0] % 4 == 0 and S.names['res'][0] % 4 == 0
+    if OCC > 1:
+        E(f"s_getreg_b32 {s('par')}, hwreg(HW_REG_HW_ID, 0, 1)", "parity of this wave's slot on its SIMD: differs between the two co-resident waves")
     E(f"v_and_b32 {v('lane')}, 63, {v('tid')}")
     E(f"v_lshrrev_b32 {v('t', 0)}, 6, {v('tid')}")
     E("s_nop 1", "hz: VALU write -> v_readfirstlane")
@@ -370,7 +422,6 @@ def gen_kernel(name, RES, stamped=False):
     E(f"s_add_u32 {s('Hpad')}, {s('tmp0')}, {s('W')}", "H + W + 1")
     E(f"s_lshl_b32 {s('tmp0')}, {s('Wp')}, 4")
     E(f"s_sub_u32 {s('dRow')}, {s('tmp0')}, 32", "tap (r, 2) -> (r + 1, 0): (Wp - 2) * 16 bytes")
-    E(f"s_mov_b32 {s('smem')}, 0", "dynamic LDS starts at 0 (no static LDS)")
     E(f"s_mov_b32 {s('klog2e2')}, 0xbfb8aa3b", "-log2(e)")
     E(f"s_mov_b32 {s('klog2e2', 1)}, 0xbfb8aa3b")
     E(f"s_mov_b32 {s('kone2')}, 1.0")
@@ -400,17 +451,14 @@ def gen_kernel(name, RES, stamped=False):
     # ---- prologue: weights of taps 0 and 1, chunks 0 and 1 of the region, the bias ----
     E(f"s_mov_b32 {s('c')}, 0")
     emit_a_stream_base("a_cur", s("tile"), s("c"))
-    for k in range(6):
-        emit_load_a(0, k, s2("a_cur"), 0)
-    # tap-step 1 = a_cur + STEP_B: offsets exceed the immediate range, so move the base
-    E(f"s_add_u32 {s('a_ld')}, {s('a_cur')}, {STEP_B}")
-    E(f"s_addc_u32 {s('a_ld', 1)}, {s('a_cur', 1)}, 0")
-    for k in range(6):
-        emit_load_a(1, k, s2("a_ld"), 0)
+    for tap in range(LOOK):                        # offsets beyond a tap-step exceed the immediate range, so move the base
+        emit_set_a_base("a_ld", tap)
+        for k in range(6):
+            emit_load_a(tap, k, s2("a_ld"), 0)
     emit_region_rows(s("tile"))
     E(f"s_mov_b32 {s('cd')}, 0")
     E(f"s_mov_b32 {s('bd')}, 0")
-    for k in range(6):
+    for k in range(NG):
         for s2i in range(2):
             emit_dma(k, s2i, s("cd"), s("bd"))
     # bias: 256 floats per wave by LDS-DMA (lane: floats wave * 256 + 4 lane .. + 3, or zeros beyond cout)
@@ -431,12 +479,15 @@ def gen_kernel(name, RES, stamped=False):
     E(f"s_mov_b32 m0, {s('tmp0')}")
     E("s_nop 0", "hz: s_mov m0 -> LDS-DMA")
     E(f"global_load_lds_dwordx4 v[{V.names['t'][0] + 4}:{V.names['t'][0] + 5}], off")
-    E(f"s_mov_b32 {s('cd')}, 1")
-    E(f"s_mov_b32 {s('bd')}, 1")
-    for k in range(6):
-        for s2i in range(2):
-            emit_dma(k, s2i, s("cd"), s("bd"))
-    E("s_waitcnt vmcnt(12)", "all but chunk 1's LDS-DMA: weights of taps 0 and 1, chunk 0, the bias")
+    if RING == 3:
+        E(f"s_mov_b32 {s('cd')}, 1")
+        E(f"s_mov_b32 {s('bd')}, 1")
+        for k in range(NG):
+            for s2i in range(2):
+                emit_dma(k, s2i, s("cd"), s("bd"))
+        E(f"s_waitcnt vmcnt({2 * NG})", "all but chunk 1's LDS-DMA: weights of taps 0 and 1, chunk 0, the bias")
+    else:
+        E("s_waitcnt vmcnt(0)", "weights of taps 0 and 1, chunk 0, the bias")
     emit_barrier()
     stamp(PH_PROLOGUE)
     E(f"s_mov_b32 {s('buf')}, 0")
@@ -444,14 +495,14 @@ def gen_kernel(name, RES, stamped=False):
 
     # =========================================== tile loop ===========================================
     label(".Ltile_" + name)
-    E(f"s_lshr_b32 {s('nt')}, {s('tile')}, {s('mt_log2')}")
-    E(f"s_lshl_b32 {s('tmp0')}, {s('nt')}, {s('mt_log2')}")
-    E(f"s_sub_u32 {s('mt')}, {s('tile')}, {s('tmp0')}")
-    E(f"s_mul_i32 {s('n0')}, {s('nt')}, {NB * 16}")
+    E(f"s_lshr_b32 {s('tmp1')}, {s('tile')}, {s('mt_log2')}")
+    E(f"s_lshl_b32 {s('tmp0')}, {s('tmp1')}, {s('mt_log2')}")
+    E(f"s_sub_u32 {s('tmp2')}, {s('tile')}, {s('tmp0')}")
+    E(f"s_mul_i32 {s('n0')}, {s('tmp1')}, {NB * 16}")
     E(f"s_add_u32 {s('next_tile')}, {s('tile')}, {s('G')}")
     E(f"s_cmp_lt_u32 {s('next_tile')}, {s('ntiles')}")
     E(f"s_cselect_b32 {s('has_next')}, 1, 0")
-    E(f"s_mul_i32 {s('cbase')}, {s('mt')}, 192")
+    E(f"s_mul_i32 {s('cbase')}, {s('tmp2')}, 192")
     E(f"s_mul_i32 {s('tmp0')}, {s('wave')}, 48")
     E(f"s_add_u32 {s('cbase')}, {s('cbase')}, {s('tmp0')}")
     emit_rs_of_tile(s("tile"), s("rs"))
@@ -494,11 +545,11 @@ def gen_kernel(name, RES, stamped=False):
     E(f"s_add_u32 {s('tmp0')}, {s('c')}, 1")
     E(f"s_cmp_eq_u32 {s('tmp0')}, {s('CC')}")
     E(f"s_cselect_b32 {s('lastc')}, 1, 0")
-    # DMA target: chunk c + 2 of this tile or c + 2 - CC of the next one, into buffer (buf + 2) % 3
-    E(f"s_add_u32 {s('cd')}, {s('c')}, 2")
-    E(f"s_add_u32 {s('bd')}, {s('buf')}, 2")
-    E(f"s_cmp_ge_u32 {s('bd')}, 3")
-    E(f"s_cselect_b32 {s('tmp0')}, 3, 0")
+    # DMA target: chunk c + RING - 1 of this tile or c + RING - 1 - CC of the next one, into buffer (buf + RING - 1) % RING
+    E(f"s_add_u32 {s('cd')}, {s('c')}, {RING - 1}")
+    E(f"s_add_u32 {s('bd')}, {s('buf')}, {RING - 1}")
+    E(f"s_cmp_ge_u32 {s('bd')}, {RING}")
+    E(f"s_cselect_b32 {s('tmp0')}, {RING}, 0")
     E(f"s_sub_u32 {s('bd')}, {s('bd')}, {s('tmp0')}")
     lskip = uid("cd")
     E(f"s_cmp_lt_u32 {s('cd')}, {s('CC')}")
@@ -529,31 +580,44 @@ def gen_kernel(name, RES, stamped=False):
     E(f"s_mov_b32 {s('tmp3')}, 0")
     emit_a_stream_base("a_nxt", s("t64"), s("tmp3"))
     label(lnd)
-    # extra = 3 NB vector-memory operations younger than the weights of taps 0 and 1: the epilogue's stores (first chunk of a tile
-    # that is not the wave's first) or the residual loads just below (last chunk, RES)
+    # extra = vector-memory operations younger than the weights of taps 0 and 1: the epilogue's stores (and, two-workgroup families,
+    # its residual loads) in the first chunk of a tile that is not the wave's first
     E(f"s_cmp_eq_u32 {s('c')}, 0")
     E(f"s_cselect_b32 {s('extra')}, 1, 0")
     E(f"s_cmp_eq_u32 {s('first')}, 1")
     E(f"s_cselect_b32 {s('extra')}, 0, {s('extra')}")
-    if RES:
-        E(f"s_or_b32 {s('extra')}, {s('extra')}, {s('lastc')}")
-        lnr = uid("nores")
-        E(f"s_cmp_eq_u32 {s('lastc')}, 0")
-        E(f"s_cbranch_scc1 {lnr}")
-        # the tile's whole residual: lands under this chunk's MFMAs
-        E(f"s_sub_u32 {s('tmp1')}, {s('npix')}, 1")
+    n_extra = 3 * NB if (RES_EARLY or not RES) else 6 * NB
+    if RES and RES_EARLY:
+        # The tile's whole residual rides in the LAST chunk's stream (3 loads per pixel block, spread over taps 0 .. 6, landing under
+        # the MFMAs); the other chunks branch over the loads, and every weight wait of the stream picks between two hand-counted
+        # immediates on `lastc`.  (Issuing them in every chunk with EXEC = 0 keeps one immediate per wait, and is correct -- an
+        # instruction without active lanes still counts -- but each still costs its issue slot: + 4 k cycles per six chunks.)
+        E(f"s_sub_u32 {s('rlim')}, {s('npix')}, 1")
         E(f"v_lshl_add_u32 {T[7]}, {v('q')}, 2, {s('cbase')}")
-        E(f"v_lshlrev_b32 {T[7]}, 1, {T[7]}")
-        for j in range(NB):
-            E(f"v_add_u32 {T[4]}, {s('n0')}, {v('l15')}")
-            if j:
-                E(f"v_add_u32 {T[4]}, {16 * j}, {T[4]}")
-            E(f"v_min_i32 {T[4]}, {s('tmp1')}, {T[4]}")
-            E(f"v_mul_lo_u32 {T[4]}, {T[4]}, {s('res_ld')}")
-            E(f"v_add_u32 {T[4]}, {T[4]}, {T[7]}")
-            for i in range(3):
-                E(f"global_load_dwordx2 {vr('R', 2 * (3 * j + i), 2)}, {T[4]}, {s2('res')} offset:{32 * i}")
-        label(lnr)
+        E(f"v_lshlrev_b32 {T[7]}, 1, {T[7]}", "t7 = (cbase + 4 q) * 2: lives through the stream")
+    if OCC > 1:
+        # Issue priority against the co-resident workgroup: the wave in the later half of its tile wins (ties: slot parity), so that
+        # the two workgroups of a CU fall out of step -- one streams MFMAs at full rate while the other is in its epilogue / tile
+        # set-up / chunk top -- instead of sharing the MFMA pipe evenly and then idling it together.
+        l_late, l_p1, l_p3, l_pd = uid("plate"), uid("p1"), uid("p3"), uid("pd")
+        E(f"s_lshl_b32 {s('tmp0')}, {s('c')}, 1")
+        E(f"s_cmp_ge_u32 {s('tmp0')}, {s('CC')}")
+        E(f"s_cbranch_scc1 {l_late}")
+        E(f"s_cmp_eq_u32 {s('par')}, 1")
+        E(f"s_cbranch_scc1 {l_p1}")
+        E("s_setprio 0")
+        E(f"s_branch {l_pd}")
+        label(l_p1)
+        E("s_setprio 1")
+        E(f"s_branch {l_pd}")
+        label(l_late)
+        E(f"s_cmp_eq_u32 {s('par')}, 1")
+        E(f"s_cbranch_scc1 {l_p3}")
+        E("s_setprio 2")
+        E(f"s_branch {l_pd}")
+        label(l_p3)
+        E("s_setprio 3")
+        label(l_pd)
     stamp(PH_TOP)
 
     # first B fragments
@@ -568,47 +632,105 @@ def gen_kernel(name, RES, stamped=False):
                 E(f"v_add_u32 {v('addr', j)}, {s('dRow')}, {v('addr', j)}")
             else:
                 E(f"v_add_u32 {v('addr', j)}, 16, {v('addr', j)}")
-        E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)}" + (f" offset:{4 * PS}" if ks else ""))
+        if not abl & 4:
+            E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)}" + (f" offset:{4 * PS}" if ks else ""))
 
     for n in range(PD):
         b_read(n)
+    cold = []                             # out-of-line waits: (label, immediate, label to return to)
     # ---- the element stream ----
+    # Vector-memory operations of one tap, in issue order: (element, kind, ...).  Weights of tap t + 2 at the odd elements 1 .. 11,
+    # two LDS-DMA instructions in the first NG taps, residual loads (one or two pixel blocks of three) in taps 0 .. 6.
     kD0, kD1 = 12, 12 + (2 * NB - 12) // 2
+    in_stream_res = RES and RES_EARLY
+    res_groups = []                       # res_groups[t] = pixel blocks whose residual is loaded in tap t
+    if in_stream_res:
+        nxt = 0
+        for t in range(9):
+            cnt = min(NB - nxt, -(-(NB - nxt) // (7 - t))) if t < 7 else 0
+            res_groups.append(list(range(nxt, nxt + cnt)))
+            nxt += cnt
+        assert nxt == NB and kD1 + 2 < 2 * NB
+
+    def tap_ops(t, last=True):
+        ops = [(2 * k + 1, "A", (t + LOOK) % 9, k) for k in range(6) if not abl & 1]
+        if t < NG and not abl & 2:
+            ops += [(kD0, "D", t, 0), (kD1, "D", t, 1)]
+        if in_stream_res and last:
+            for g, j in enumerate(res_groups[t]):
+                ops += [((kD0, kD1)[g] + 2, "R", j, i) for i in range(3)]
+        return sorted(ops, key=lambda o: o[0])
+
+    def younger_than(t, k_last, e_wait, last):
+        """Vector-memory operations issued after weight load k_last of tap t's set and before element e_wait of tap t, in a tile's
+        last chunk (with the residual loads) or another one; the chunk before is never a last chunk that matters: its residual loads
+        are older than the weights of taps 0 and 1."""
+        seq = [o for tt in range(9) for o in tap_ops(tt, False)] + [o for tt in range(t) for o in tap_ops(tt, last)]
+        seq += [o for o in tap_ops(t, last) if o[0] < e_wait]
+        idx = max(i for i, o in enumerate(seq) if o[1] == "A" and o[2] == t and o[3] == k_last)
+        return len(seq) - 1 - idx
+
+    def wait_weights(t, half):
+        """First (k-step 0) or second (k-step 1) three fragments of tap t's weights."""
+        if abl & 1:
+            return
+        kN = younger_than(t, 2 + 3 * half, half * NB, False)
+        kL = younger_than(t, 2 + 3 * half, half * NB, True)
+        assert kN <= kL <= 63
+        cases = []                                        # (flag register, immediate)
+        if kL != kN:
+            cases.append((s("lastc"), kL))
+        if t < LOOK:
+            cases.append((s("extra"), min(63, kN + n_extra)))
+        # the common case falls through (a taken branch costs the wave its instruction buffer); the others wait out of line
+        ld = uid("wd")
+        for flag, imm in cases:
+            lx = uid("wx")
+            E(f"s_cmp_eq_u32 {flag}, 1")
+            E(f"s_cbranch_scc1 {lx}")
+            cold.append((lx, imm, ld))
+        E(f"s_waitcnt vmcnt({kN})", f"weights of tap {t}, k-step {half}")
+        label(ld)
+
     for n in range(NE):
         h, j = divmod(n, NB)
         t, ks = divmod(h, 2)
         e = ks * NB + j
         if n + PD < NE:
             b_read(n + PD)
-        if e == 0:
-            kN = 6 + (2 if 2 <= t <= 7 else 0) + (2 if 1 <= t <= 6 else 0)
-            if t < 2:
-                lx, ld = uid("wx"), uid("wd")
-                E(f"s_cmp_eq_u32 {s('extra')}, 1")
+        if j == 0:
+            wait_weights(t, ks)
+        for op in tap_ops(t):
+            if op[0] != e:
+                continue
+            if op[1] == "A":
+                if op[3] == 0:
+                    emit_set_a_base("a_ld", t + LOOK)
+                emit_load_a((t + LOOK) % (LOOK + 1), op[3], s2("a_ld"), 0)
+            elif op[1] == "D":
+                emit_dma(t, op[3], s("cd"), s("bd"))
+            elif op[1] == "R" and op[3] == 0:
+                # out of line as well: only a tile's last chunk takes the branch
+                jr = op[2]
+                lx, ld = uid("res"), uid("resd")
+                E(f"s_cmp_eq_u32 {s('lastc')}, 1")
                 E(f"s_cbranch_scc1 {lx}")
-                E(f"s_waitcnt vmcnt({kN})")
-                E(f"s_branch {ld}")
-                label(lx)
-                E(f"s_waitcnt vmcnt({min(63, kN + 3 * NB)})")
                 label(ld)
-            else:
-                E(f"s_waitcnt vmcnt({kN})", f"weights of tap {t}")
-        if 1 <= e <= 11 and e % 2 == 1:
-            k = e // 2
-            if k == 0:
-                emit_set_a_base("a_ld", t + 2)
-            emit_load_a((t + 2) % 3, k, s2("a_ld"), 0)
-        if t < 6 and e in (kD0, kD1):
-            emit_dma(t, 0 if e == kD0 else 1, s("cd"), s("bd"))
+                body = [f"v_add_u32 {T[4]}, {s('n0')}, {v('l15')}"]
+                if jr:
+                    body.append(f"v_add_u32 {T[4]}, {16 * jr}, {T[4]}")
+                body += [f"v_min_i32 {T[4]}, {s('rlim')}, {T[4]}", f"v_mul_lo_u32 {T[4]}, {T[4]}, {s('res_ld')}", f"v_add_u32 {T[4]}, {T[4]}, {T[7]}"]
+                body += [f"global_load_dwordx2 v[{rreg(3 * jr + i)}:{rreg(3 * jr + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}" for i in range(3)]
+                cold.append((lx, body, ld))
         allowed = min(PD, NE - 1 - n)
         E(f"s_waitcnt lgkmcnt({allowed})")
-        for i in range(3):
-            E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {vr('A', 24 * (t % 3) + 4 * (3 * ks + i), 4)}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
+        for i in range(3 if not abl & 8 else 0):
+            E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {areg(t % (LOOK + 1), 3 * ks + i)}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
     # ---- chunk end ----
     stamp(PH_STREAM)
     # next chunk: delta0 = (next buffer - this buffer) * CHUNK - (2 Wp + 2) * 16
     E(f"s_add_u32 {s('tmp0')}, {s('buf')}, 1")
-    E(f"s_cmp_ge_u32 {s('tmp0')}, 3")
+    E(f"s_cmp_ge_u32 {s('tmp0')}, {RING}")
     E(f"s_cselect_b32 {s('tmp0')}, 0, {s('tmp0')}", "next buffer")
     E(f"s_sub_i32 {s('tmp1')}, {s('tmp0')}, {s('buf')}")
     E(f"s_mul_i32 {s('tmp1')}, {s('tmp1')}, {CHUNK}")
@@ -622,27 +744,57 @@ def gen_kernel(name, RES, stamped=False):
     E(f"s_cbranch_scc1 .Lchunk_{name}")
 
     # =========================================== epilogue ===========================================
-    E("s_nop 15", "hz: MFMA result -> VALU read")
-    E("s_nop 15")
-    if RES:
-        E(f"s_waitcnt vmcnt(12)", "the residual (older than the 12 weight loads of the next tile's first taps)")
+    if OCC > 1:
+        E("s_setprio 3", "short instructions that free the way: ahead of the other workgroup's MFMA stream")
+    if RES and not RES_EARLY:
+        # the tile's residual, into registers the stream has finished with (every MFMA that read them has issued)
+        E(f"s_sub_u32 {s('tmp1')}, {s('npix')}, 1")
+        E(f"v_lshl_add_u32 {T[7]}, {v('q')}, 2, {s('cbase')}")
+        E(f"v_lshlrev_b32 {T[7]}, 1, {T[7]}")
+        for j in range(NB):
+            E(f"v_add_u32 {T[4]}, {s('n0')}, {v('l15')}")
+            if j:
+                E(f"v_add_u32 {T[4]}, {16 * j}, {T[4]}")
+            E(f"v_min_i32 {T[4]}, {s('tmp1')}, {T[4]}")
+            E(f"v_mul_lo_u32 {T[4]}, {T[4]}, {s('res_ld')}")
+            E(f"v_add_u32 {T[4]}, {T[4]}, {T[7]}")
+            for i in range(3):
+                E(f"global_load_dwordx2 v[{rreg(3 * j + i)}:{rreg(3 * j + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}")
+    else:
+        E("s_nop 15", "hz: MFMA result -> VALU read")
+        E("s_nop 15")
+    if RES and RES_EARLY:
+        tail = [o for tt in range(9) for o in tap_ops(tt, True)]
+        k_res = len(tail) - 1 - max(i for i, o in enumerate(tail) if o[1] == "R")
+        E(f"s_waitcnt vmcnt({k_res})", "the residual (only weight loads of the next tile's first taps are younger)")
     lact, lepd = uid("noact"), uid("epd")
+    X = V.names["t"][0] + 0      # x[0:3]
+    Y = V.names["t"][0] + 4      # work
+    Rr = V.names["t"][0] + 8     # residual as f32
     for ACT in (True, False):
         if ACT:
             E(f"s_cmp_eq_u32 {s('act')}, 0")
             E(f"s_cbranch_scc1 {lact}")
         else:
             label(lact)
-        for i in range(3):
-            for j in range(NB):
+        for j in range(NB):
+            E(f"s_sub_i32 {s('lim')}, {s('npix')}, {s('n0')}")
+            E(f"s_sub_i32 {s('lim')}, {s('lim')}, {16 * j}", "pixels of this block inside the batch")
+            E(f"v_cmp_gt_i32 {s2('t64')}, {s('lim')}, {v('l15')}", "pixel n0 + 16 j + l15 inside the batch?")
+            for i in range(3):
                 a0 = 4 * (3 * j + i)
-                X = V.names["t"][0] + 0      # x[0:3]
-                Y = V.names["t"][0] + 4      # work
-                Rr = V.names["t"][0] + 8     # residual as f32
-                E(f"s_sub_i32 {s('lim')}, {s('npix')}, {s('n0')}")
-                E(f"s_sub_i32 {s('lim')}, {s('lim')}, {16 * j}", "pixels of this block inside the batch")
+                r0 = rreg(3 * j + i)
                 for e in range(4):
                     E(f"v_accvgpr_read_b32 v{X + e}, a{a0 + e}")
+                if RES and not RES_EARLY:
+                    E(f"s_waitcnt vmcnt({3 * NB - 1})", "this block's residual: the younger loads and the stores issued so far stay in flight")
+
+                def unpack_residual():
+                    E(f"v_lshlrev_b32 v{Rr}, 16, v{r0}")
+                    E(f"v_and_b32 v{Rr + 1}, 0xffff0000, v{r0}")
+                    E(f"v_lshlrev_b32 v{Rr + 2}, 16, v{r0 + 1}")
+                    E(f"v_and_b32 v{Rr + 3}, 0xffff0000, v{r0 + 1}")
+
                 if ACT:
                     E(f"v_pk_mul_f32 v[{Y}:{Y + 1}], v[{X}:{X + 1}], {s2('klog2e2')}")
                     E(f"v_pk_mul_f32 v[{Y + 2}:{Y + 3}], v[{X + 2}:{X + 3}], {s2('klog2e2')}")
@@ -653,29 +805,19 @@ def gen_kernel(name, RES, stamped=False):
                     for e in range(4):
                         E(f"v_rcp_f32 v{Y + e}, v{Y + e}")
                     if RES:       # independent work between the rcp and its consumer (hz: transcendental -> consumer)
-                        r0 = V.names["R"][0] + 2 * (3 * j + i)
-                        E(f"v_lshlrev_b32 v{Rr}, 16, v{r0}")
-                        E(f"v_and_b32 v{Rr + 1}, 0xffff0000, v{r0}")
-                        E(f"v_lshlrev_b32 v{Rr + 2}, 16, v{r0 + 1}")
-                        E(f"v_and_b32 v{Rr + 3}, 0xffff0000, v{r0 + 1}")
+                        unpack_residual()
                     else:
                         E("s_nop 0")
                     E(f"v_pk_mul_f32 v[{X}:{X + 1}], v[{X}:{X + 1}], v[{Y}:{Y + 1}]")
                     E(f"v_pk_mul_f32 v[{X + 2}:{X + 3}], v[{X + 2}:{X + 3}], v[{Y + 2}:{Y + 3}]")
                 elif RES:
-                    r0 = V.names["R"][0] + 2 * (3 * j + i)
-                    E(f"v_lshlrev_b32 v{Rr}, 16, v{r0}")
-                    E(f"v_and_b32 v{Rr + 1}, 0xffff0000, v{r0}")
-                    E(f"v_lshlrev_b32 v{Rr + 2}, 16, v{r0 + 1}")
-                    E(f"v_and_b32 v{Rr + 3}, 0xffff0000, v{r0 + 1}")
+                    unpack_residual()
                 if RES:
                     E(f"v_pk_add_f32 v[{X}:{X + 1}], v[{X}:{X + 1}], v[{Rr}:{Rr + 1}]")
                     E(f"v_pk_add_f32 v[{X + 2}:{X + 3}], v[{X + 2}:{X + 3}], v[{Rr + 2}:{Rr + 3}]")
                 E(f"v_cvt_pk_bf16_f32 v{Y}, v{X}, v{X + 1}")
                 E(f"v_cvt_pk_bf16_f32 v{Y + 1}, v{X + 2}, v{X + 3}")
-                E(f"v_cmp_gt_i32 vcc, {s('lim')}, {v('l15')}", "pixel n0 + 16 j + l15 inside the batch?") if i == 0 or True else None
-                E("s_nop 1", "hz: VALU-written VCC read by SALU")
-                E("s_mov_b64 exec, vcc")
+                E(f"s_mov_b64 exec, {s2('t64')}")
                 E(f"global_store_dwordx2 {v('oo', j)}, v[{Y}:{Y + 1}], {s2('out')} offset:{32 * i}")
                 E("s_mov_b64 exec, -1")
         if ACT:
@@ -688,6 +830,11 @@ def gen_kernel(name, RES, stamped=False):
     E(f"s_cbranch_scc1 .Lend_{name}")
     E(f"s_mov_b32 {s('tile')}, {s('next_tile')}")
     E(f"s_branch .Ltile_{name}")
+    for lx, what, ld in cold:
+        label(lx)
+        for line in ([f"s_waitcnt vmcnt({what})"] if isinstance(what, int) else what):
+            E(line)
+        E(f"s_branch {ld}")
     label(".Lend_" + name)
     E("s_waitcnt vmcnt(0)")
     if stamped:
@@ -715,21 +862,30 @@ def gen_kernel(name, RES, stamped=False):
     return list(out)
 
 
+def register_budget():
+    acc_off = (V.next + 3) // 4 * 4
+    total = (acc_off + n_acc() + 7) // 8 * 8
+    assert total <= 512 // OCC, f"NB = {NB}: {total} registers do not leave room for {OCC} wave(s) per SIMD"
+    assert OCC * LDS_BYTES <= 160 * 1024
+    return acc_off, total
+
+
 def descriptor(name):
+    acc_off, total = register_budget()
     return f"""
 	.rodata
 	.p2align 6
 	.amdhsa_kernel {name}
-		.amdhsa_group_segment_fixed_size 151552
+		.amdhsa_group_segment_fixed_size {LDS_BYTES}
 		.amdhsa_private_segment_fixed_size 0
 		.amdhsa_kernarg_size {ARG_BYTES}
 		.amdhsa_user_sgpr_count 2
 		.amdhsa_user_sgpr_kernarg_segment_ptr 1
 		.amdhsa_system_sgpr_workgroup_id_x 1
 		.amdhsa_system_vgpr_workitem_id 0
-		.amdhsa_next_free_vgpr 512
+		.amdhsa_next_free_vgpr {total}
 		.amdhsa_next_free_sgpr {S.next}
-		.amdhsa_accum_offset 256
+		.amdhsa_accum_offset {acc_off}
 		.amdhsa_reserve_vcc 1
 		.amdhsa_float_denorm_mode_32 3
 		.amdhsa_float_denorm_mode_16_64 3
@@ -740,27 +896,31 @@ def descriptor(name):
 """
 
 
-def metadata(names):
-    ks = "".join(f"""  - .agpr_count:     256
+def metadata_entry(name):
+    acc_off, total = register_budget()
+    return f"""  - .agpr_count:     {total - acc_off}
     .args:
       - .offset:         0
         .size:           {ARG_BYTES}
         .value_kind:     by_value
-    .group_segment_fixed_size: 151552
+    .group_segment_fixed_size: {LDS_BYTES}
     .kernarg_segment_align: 8
     .kernarg_segment_size: {ARG_BYTES}
     .max_flat_workgroup_size: 256
-    .name:           {n}
+    .name:           {name}
     .private_segment_fixed_size: 0
     .sgpr_count:     {S.next + 6}
-    .symbol:         {n}.kd
-    .vgpr_count:     512
+    .symbol:         {name}.kd
+    .vgpr_count:     {total}
     .wavefront_size: 64
-""" for n in names)
+"""
+
+
+def metadata(entries):
     return f"""	.amdgpu_metadata
 ---
 amdhsa.kernels:
-{ks}amdhsa.target:   amdgcn-amd-amdhsa--gfx950
+{"".join(entries)}amdhsa.target:   amdgcn-amd-amdhsa--gfx950
 amdhsa.version:
   - 1
   - 2
@@ -769,20 +929,29 @@ amdhsa.version:
 """
 
 
+DIAG = True      # also emit the timing-only ablations of the stamped build (tools/time_conv3x3.py --stamp --abl)
+
+
 def main():
     path = sys.argv[1] if len(sys.argv) > 1 else "conv3x3_pl_asm.s"
     text = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.text"]
-    names = []
-    for RES, stamped in ((False, False), (True, False), (True, True)):
-        name = f"conv3x3_pl_asm_nb{NB}_res{int(RES)}" + ("_stamped" if stamped else "")
-        names.append(name)
-        text += [f"\t.globl\t{name}", "\t.p2align\t8", f"\t.type\t{name},@function"]
-        text += gen_kernel(name, RES, stamped)
-        text += [f".Lfend_{name}:", f"\t.size\t{name}, .Lfend_{name}-{name}", descriptor(name)]
-    text.append(metadata(names))
+    entries = []
+    for nb in sorted(CONFIGS):
+        configure(nb)
+        variants = [(False, False, 0), (True, False, 0), (True, True, 0)]
+        if DIAG and nb in (7, 13):
+            variants += [(True, True, a) for a in (1, 2, 3, 4, 7, 8)]
+        for RES, stamped, abl in variants:
+            name = f"conv3x3_pl_asm_nb{NB}_res{int(RES)}" + ("_stamped" if stamped else "") + (f"_abl{abl}" if abl else "")
+            entries.append(metadata_entry(name))
+            text += [f"\t.globl\t{name}", "\t.p2align\t8", f"\t.type\t{name},@function"]
+            text += gen_kernel(name, RES, stamped, abl)
+            text += [f".Lfend_{name}:", f"\t.size\t{name}, .Lfend_{name}-{name}", descriptor(name)]
+        print(f"NB = {NB}: {V.next} VGPRs + {n_acc()} AGPRs, {S.next} SGPRs, {LDS_BYTES} B LDS, {OCC} workgroup(s) per CU")
+    text.append(metadata(entries))
     with open(path, "w") as f:
         f.write("\n".join(text) + "\n")
-    print(f"wrote {path}: {sum(1 for l in text if 'v_mfma' in l)} MFMAs, VGPRs used {V.next}, SGPRs used {S.next}")
+    print(f"wrote {path}: {sum(1 for l in text if 'v_mfma' in l)} MFMAs")
 
 
 if __name__ == "__main__":

@@ -69,7 +69,7 @@ def main():
 
         for nb in [int(v) for v in a.nbs.split(',') if v]:
             os.environ["AQ_PL_NB"] = str(nb)
-            for asm in ((1, 0) if nb == 13 else (0,)):
+            for asm in {13: (1, 0), 7: (1, 0), 8: (1,)}.get(nb, (0,)):
                 os.environ["AQ_PL_ASM"] = str(asm)
                 try:
                     us = timeit(run_pl)
@@ -78,11 +78,15 @@ def main():
                     print(f"{c}ch planar NB={nb}: {err}")
         os.environ.pop("AQ_PL_NB", None)
         os.environ.pop("AQ_PL_ASM", None)
-        for sab in (["asm", 16] + [16 + int(v) for v in a.abl.split(",") if v] if a.stamp else []):
+        asm_abl = [f"asm{nb}:{v}" for nb in (7, 13) for v in a.abl.split(",") if v]
+        for sab in (["asm13", "asm7", "asm8"] + asm_abl + [16] + [16 + int(v) for v in a.abl.split(",") if v and int(v) < 8] if a.stamp else []):
             buf = torch.zeros(1 << 16, dtype=torch.int64, device=dev)
             E._check(lib.aq_debug_conv_stamp(buf.data_ptr(), buf.numel() * 8))
-            if sab == "asm":
-                os.environ["AQ_PL_ASM"], os.environ["AQ_PL_NB"], sab = "2", "13", 16
+            if isinstance(sab, str):
+                nb_, _, abl_ = sab[3:].partition(":")
+                os.environ["AQ_PL_ASM"], os.environ["AQ_PL_NB"], sab = "2", nb_, 16 + int(abl_ or 0)
+                if abl_:
+                    os.environ["AQ_PL_ASM_ABL"] = abl_
             else:
                 os.environ["AQ_PL_ABL"] = str(sab)
             for i in range(3):
@@ -93,13 +97,14 @@ def main():
             torch.cuda.synchronize()
             lib.aq_debug_conv_stamp(None, 0)
             asm = os.environ.pop("AQ_PL_ASM", None)
-            os.environ.pop("AQ_PL_NB", None)
+            nbs = os.environ.pop("AQ_PL_NB", "")
+            os.environ.pop("AQ_PL_ASM_ABL", None)
             os.environ.pop("AQ_PL_ABL", None)
             t = buf.cpu().view(-1, 8).double()
             t = t[t[:, 6] > 0]
             names = ["prologue", "chunk-barrier", "stream", "tile-setup", "epilogue", "chunk-top"]
             life, ticks = t[:, 6], t[:, 7]
-            print(f"{c}ch stamped {'asm' if asm else 'hip'} ABL={sab - 16}: waves {t.shape[0]}  lifetime {life.mean():.0f} cycles (min {life.min():.0f} max {life.max():.0f}) = {ticks.mean() * 10:.0f} ns "
+            print(f"{c}ch stamped {'asm NB=' + nbs if asm else 'hip'} ABL={sab - 16}: waves {t.shape[0]}  lifetime {life.mean():.0f} cycles (min {life.min():.0f} max {life.max():.0f}) = {ticks.mean() * 10:.0f} ns "
                   f"-> clock {(life / ticks).median() * 100:.0f} MHz | " + " ".join(f"{n}={t[:, k].mean():.0f}" for k, n in enumerate(names)), flush=True)
         us = timeit(run_pl)
         print(f"{c}ch {H}x{W} B{B}  planar auto : {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
