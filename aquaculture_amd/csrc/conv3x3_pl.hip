@@ -23,7 +23,9 @@
 //     with hand-counted s_waitcnt vmcnt(N): the compiler never sees them, so it never drains them (round 1's vmcnt(0)
 //     findings); fragment reads and MFMAs are ordinary code that it schedules and pads for hazards.
 #include "conv_device.h"
+#include <cmath>
 #include <type_traits>
+#include <vector>
 
 using namespace aqdev;
 
@@ -398,7 +400,7 @@ struct PlAsmFamily { int nb, rows, occ; };
 const PlAsmFamily kPlAsm[] = {{13, 384, 1}, {7, 256, 2}, {8, 256, 2}};
 constexpr int kNumPlAsm = sizeof(kPlAsm) / sizeof(kPlAsm[0]);
 hipModule_t g_pl_asm_mod[64];
-hipFunction_t g_pl_asm_fn[64][kNumPlAsm][3];
+hipFunction_t g_pl_asm_fn[64][kNumPlAsm][5];     // res0, res1, res1 stamped, and (NB = 13 only) the fp8-weight res0, res1
 
 struct PlKernel { int nb; void (*plain)(const PlParams); void (*res)(const PlParams); };
 struct PlAblation { int abl; void (*fn)(const PlParams); };
@@ -478,9 +480,9 @@ static int pl_pick(int B, int H, int W, int n_mt, int cus, int* rows_out) {
 
 // in: bf16 pixels, `cin` channels; element (pixel P, channel group g) at in + P * in_sp + g * in_ss bytes (NHWC: in_sp = row bytes,
 // in_ss = 16).  out / res: NHWC bf16 with row lengths out_ld / res_ld (elements), channel slices at *_choff.
-extern "C" int aq_conv3x3_pl(const void* in_dev, long long in_sp, long long in_ss, int cin, void* out_dev, int out_ld, int out_choff,
-                             int cout, const void* res_dev, int res_ld, int res_choff, const void* packed_w_dev, const float* bias_dev,
-                             int B, int H, int W, int act, void* stream) {
+static int pl_conv(const void* in_dev, long long in_sp, long long in_ss, int cin, void* out_dev, int out_ld, int out_choff,
+                   int cout, const void* res_dev, int res_ld, int res_choff, const void* packed_w_dev, const float* bias_dev,
+                   int B, int H, int W, int act, void* stream, bool w8) {
     AQ_REQUIRE(in_dev && out_dev && packed_w_dev && bias_dev, "conv3x3_pl: null pointer");
     AQ_REQUIRE(aq_conv3x3_pl_supported(cin, cout), "conv3x3_pl: unsupported %d -> %d", cin, cout);
     AQ_REQUIRE(B > 0 && H > 0 && W > 0 && (long long)B * (H + 1) * (W + 1) + W + 2 < (1LL << 23), "conv3x3_pl: shape outside the fast-index range");
@@ -522,9 +524,11 @@ extern "C" int aq_conv3x3_pl(const void* in_dev, long long in_sp, long long in_s
             if (kPl[i].nb == nb && pl_region_rows(B, H, W, nb * 16) <= PL_ROWS) k = i;
     }
     int fam = -1;
-    if (!(use_asm && *use_asm == '0') && !(abl && *abl) && (p.n_mt & (p.n_mt - 1)) == 0 && in_sp < (1LL << 32) && in_ss < (1LL << 31))
+    if (w8) nb = 13;                                        // the fp8-weight stream exists in the NB = 13 assembly family only
+    if ((w8 || (!(use_asm && *use_asm == '0') && !(abl && *abl))) && (p.n_mt & (p.n_mt - 1)) == 0 && in_sp < (1LL << 32) && in_ss < (1LL << 31))
         for (int i = 0; i < kNumPlAsm; ++i)
             if (kPlAsm[i].nb == nb && pl_region_rows(B, H, W, nb * 16) <= kPlAsm[i].rows) fam = i;
+    AQ_REQUIRE(!w8 || fam >= 0, "conv3x3_pl_w8: shape outside the fp8-weight kernel (aq_conv3x3_pl_w8_supported)");
     AQ_REQUIRE(k >= 0 || fam >= 0, "conv3x3_pl: no tile of this kernel fits a %d-wide image in its region rows", W);
     const int bn = nb * 16;
     const long long ntiles = ((long long)p.npix + bn - 1) / bn * p.n_mt;
@@ -534,9 +538,10 @@ extern "C" int aq_conv3x3_pl(const void* in_dev, long long in_sp, long long in_s
         if (!g_pl_asm_mod[dev]) {
             AQ_CHECK_HIP(hipModuleLoadData(&g_pl_asm_mod[dev], kPlAsmCode));
             for (int i = 0; i < kNumPlAsm; ++i)
-                for (int v = 0; v < 3; ++v) {
+                for (int v = 0; v < (kPlAsm[i].nb == 13 ? 5 : 3); ++v) {
                     char name[64];
-                    snprintf(name, sizeof name, "conv3x3_pl_asm_nb%d_res%d%s", kPlAsm[i].nb, v ? 1 : 0, v == 2 ? "_stamped" : "");
+                    snprintf(name, sizeof name, "conv3x3_pl_asm_nb%d_res%d%s", kPlAsm[i].nb, v == 0 || v == 3 ? 0 : 1,
+                             v == 2 ? "_stamped" : v >= 3 ? "_w8" : "");
                     AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_asm_fn[dev][i][v], g_pl_asm_mod[dev], name));
                 }
         }
@@ -549,8 +554,8 @@ extern "C" int aq_conv3x3_pl(const void* in_dev, long long in_sp, long long in_s
         a.mt_log2 = 0;
         while ((1 << a.mt_log2) < p.n_mt) ++a.mt_log2;
         a.inv_hw = p.inv_hw; a.inv_w = p.inv_w; a.inv_hpwp = p.inv_hpwp; a.inv_wp = p.inv_wp; a.debug = nullptr;
-        int which = res_dev ? 1 : 0;
-        if (use_asm && *use_asm == '2' && res_dev) {        // stamped diagnostic build (tools/time_conv3x3.py --stamp): per-wave phase cycle sums
+        int which = (res_dev ? 1 : 0) + (w8 ? 3 : 0);
+        if (!w8 && use_asm && *use_asm == '2' && res_dev) {        // stamped diagnostic build (tools/time_conv3x3.py --stamp): per-wave phase cycle sums
             size_t sbytes = 0;
             unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
             if (sbuf && sbytes >= (size_t)grid * 4 * 64) { a.debug = sbuf; which = 2; }
@@ -589,4 +594,99 @@ extern "C" int aq_conv3x3_pl(const void* in_dev, long long in_sp, long long in_s
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;
+}
+
+extern "C" int aq_conv3x3_pl(const void* in_dev, long long in_sp, long long in_ss, int cin, void* out_dev, int out_ld, int out_choff,
+                             int cout, const void* res_dev, int res_ld, int res_choff, const void* packed_w_dev, const float* bias_dev,
+                             int B, int H, int W, int act, void* stream) {
+    return pl_conv(in_dev, in_sp, in_ss, cin, out_dev, out_ld, out_choff, cout, res_dev, res_ld, res_choff, packed_w_dev, bias_dev, B, H, W, act,
+                   stream, false);
+}
+
+// ---- fp8-weight stream (precision AQ_BF16_W8): the same kernel loading OCP e4m3fn codes -- half the L2 -> register weight traffic, the
+// bottleneck of the bf16 stream -- and converting them to bf16 fragments in the shadow of the MFMAs; the per-output-channel scale 2^e is
+// applied to the accumulators in the epilogue (and its inverse to the bias they start from), which is exact, so the outputs are bit for
+// bit those of the bf16 stream on the dequantised weights.
+extern "C" int aq_conv3x3_pl_w8_supported(int cin, int cout, int B, int H, int W) {
+    if (!aq_conv3x3_pl_supported(cin, cout) || B <= 0 || H <= 0 || W <= 0) return 0;
+    const int n_mt = cout / PL_BM;
+    return (n_mt & (n_mt - 1)) == 0 && pl_region_rows(B, H, W, 13 * 16) <= PL_ROWS;
+}
+
+// e4m3fn code of v if v is exactly representable (|v| <= 448, 3 mantissa bits, subnormal step 2^-9), else -1
+static int pl_e4m3_code(double v) {
+    const int sign = std::signbit(v) ? 0x80 : 0;
+    const double a = std::fabs(v);
+    if (a == 0.0) return sign;
+    if (a > 448.0) return -1;
+    if (a < 0.015625) {                                     // subnormals: multiples of 2^-9 below 2^-6
+        const double m = a * 512.0;
+        return (m == std::floor(m) && m >= 1.0 && m <= 7.0) ? sign | (int)m : -1;
+    }
+    int ex = 0;
+    std::frexp(a, &ex);                                     // a = f * 2^ex, f in [0.5, 1)
+    ex -= 1;
+    const double m = std::ldexp(a, 3 - ex);                 // in [8, 16)
+    if (m != std::floor(m) || ex < -6 || ex > 8) return -1;
+    return sign | ((ex + 7) << 3) | ((int)m - 8);
+}
+
+// Weights must already lie on a per-output-channel grid code x 2^e (aquaculture_amd/quant.py quantize_rows; AQ_ERR_INVALID otherwise).
+// Image: [M tile][wave][chunk][tap][fragment pair][lane] x 16 codes (fragment 2 p then 2 p + 1, aq_pack_conv3x3_pl's fragments);
+// scale_bias_dev: float[2048] = bias x 2^-e (1024, zero padded), then 2^e (1024).
+extern "C" int aq_pack_conv3x3_pl_w8(const float* w_host, const float* bias_host, int cin, int cout, void* packed_dev, size_t* bytes,
+                                     float* scale_bias_dev, void* stream) {
+    AQ_REQUIRE(w_host && bytes && aq_conv3x3_pl_supported(cin, cout) && cout <= 1024, "pack_conv3x3_pl_w8: unsupported %d -> %d", cin, cout);
+    const int CC = cin / 64, n_mt = cout / PL_BM;
+    *bytes = (size_t)n_mt * 4 * CC * 9 * (PL_STEP_B / 2);
+    if (!packed_dev) return AQ_OK;
+    AQ_REQUIRE(bias_host && scale_bias_dev, "pack_conv3x3_pl_w8: null pointer");
+    std::vector<int> ex(cout, 0);
+    std::vector<float> sb(2048, 0.0f);
+    const size_t kk = (size_t)9 * cin;
+    for (int co = 0; co < cout; ++co) {
+        const float* row = w_host + (size_t)co * kk;
+        double amax = 0.0;
+        for (size_t i = 0; i < kk; ++i) amax = std::fmax(amax, std::fabs((double)row[i]));
+        int e = amax > 0.0 ? (int)std::ceil(std::log2(amax / 448.0)) : 0;
+        bool ok = false;
+        for (int attempt = 0; attempt < 3 && !ok; ++attempt, ++e) {      // a dequantised maximum of 224 x 2^e reads as one binade lower
+            ok = true;
+            for (size_t i = 0; i < kk && ok; ++i) ok = pl_e4m3_code(std::ldexp((double)row[i], -e)) >= 0;
+            if (ok) break;
+        }
+        AQ_REQUIRE(ok, "pack_conv3x3_pl_w8: output channel %d is not on an e4m3 x 2^e grid", co);
+        ex[co] = e;
+        sb[co] = std::ldexp(bias_host[co], -e);
+        sb[1024 + co] = std::ldexp(1.0f, e);
+    }
+    unsigned char* host = (unsigned char*)malloc(*bytes);
+    AQ_REQUIRE(host, "pack_conv3x3_pl_w8: host allocation failed");
+    unsigned char* dst = host;
+    for (int mt = 0; mt < n_mt; ++mt)
+        for (int wv = 0; wv < 4; ++wv)
+            for (int c = 0; c < CC; ++c)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int pr = 0; pr < 3; ++pr)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int h = 0; h < 2; ++h) {
+                                const int k = 2 * pr + h, ks = k / 3, i = k % 3;
+                                const int co = mt * PL_BM + wv * 48 + i * 16 + (lane & 15);
+                                const int ci = 64 * c + 32 * ks + 8 * (lane >> 4);
+                                const float* src = w_host + ((size_t)co * 9 + tap) * cin + ci;
+                                for (int e = 0; e < 8; ++e) *dst++ = (unsigned char)pl_e4m3_code(std::ldexp((double)src[e], -ex[co]));
+                            }
+    hipError_t err = hipMemcpyAsync(packed_dev, host, *bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(scale_bias_dev, sb.data(), sb.size() * 4, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (err == hipSuccess) err = hipStreamSynchronize((hipStream_t)stream);
+    free(host);
+    AQ_CHECK_HIP(err);
+    return AQ_OK;
+}
+
+extern "C" int aq_conv3x3_pl_w8(const void* in_dev, long long in_sp, long long in_ss, int cin, void* out_dev, int out_ld, int out_choff,
+                                int cout, const void* res_dev, int res_ld, int res_choff, const void* packed_w8_dev,
+                                const float* scale_bias_dev, int B, int H, int W, int act, void* stream) {
+    return pl_conv(in_dev, in_sp, in_ss, cin, out_dev, out_ld, out_choff, cout, res_dev, res_ld, res_choff, packed_w8_dev, scale_bias_dev, B, H, W,
+                   act, stream, true);
 }

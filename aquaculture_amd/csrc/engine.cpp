@@ -22,7 +22,7 @@ void aq_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* aq_last_error(void) { return g_err; }
-extern "C" int aq_version(void) { return 4; }   // 2: fused stem / Bottleneck / down-block ops, direct 1x1 and 3x3/s2 candidates; 3: one-tile-per-workgroup grids
+extern "C" int aq_version(void) { return 5; }   // 5: AQ_BF16_W8, aq_conv3x3_pl_w8; 2: fused stem / Bottleneck / down-block ops, direct 1x1 and 3x3/s2 candidates; 3: one-tile-per-workgroup grids
 
 namespace {
 
@@ -36,6 +36,8 @@ struct PackedW {
     int kgroups = 0, kgroups_pad = 0, G = 0, cout_rows = 0;
     void* w_direct = nullptr;   // layers a direct kernel supports: its A-fragment image (csrc/conv1x1_direct.hip, csrc/downblock.hip)
     int direct_cfg = -1;        // AQ_CONV_CFG_DIRECT1X1 / AQ_CONV_CFG_DIRECT3X3S2 / AQ_CONV_CFG_PL3X3
+    void* w_pl8 = nullptr;      // AQ_BF16_W8 engines, planar 3x3 layers: the e4m3 code stream and its float[2048] bias x 2^-e | 2^e
+    float* sb_pl8 = nullptr;
 };
 
 // Host-side packing: KRSC fp32 -> [cout_rows][kgroups_pad*16 B] of bf16 / fp32, zero padded.
@@ -167,6 +169,12 @@ int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStr
     if (cfg == AQ_CONV_CFG_PL3X3) {
         if (pw.direct_cfg != cfg) { aq_set_error("conv op %d has no planar 3x3 form", oi); return AQ_ERR_INVALID; }
         const int ld = e->tensors[op.src.tensor].channels;
+        if (pw.w_pl8 && aq_conv3x3_pl_w8_supported(op.src.channels, op.dst.channels, B, ps.h, ps.w))
+            return aq_conv3x3_pl_w8(tptr(e, ws, tiles, op.src.tensor) + (size_t)op.src.ch_off * 2, (long long)ld * 2, 16, op.src.channels,
+                                    tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off, op.dst.channels,
+                                    op.res.tensor >= 0 ? tptr(e, ws, tiles, op.res.tensor) : nullptr,
+                                    op.res.tensor >= 0 ? e->tensors[op.res.tensor].channels : 0, op.res.ch_off,
+                                    pw.w_pl8, pw.sb_pl8, B, ps.h, ps.w, op.act, stream);
         return aq_conv3x3_pl(tptr(e, ws, tiles, op.src.tensor) + (size_t)op.src.ch_off * 2, (long long)ld * 2, 16, op.src.channels,
                              tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off, op.dst.channels,
                              op.res.tensor >= 0 ? tptr(e, ws, tiles, op.res.tensor) : nullptr,
@@ -327,10 +335,14 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
     AQ_REQUIRE(d && out, "engine_create: null pointer");
     AQ_REQUIRE(d->n_ops > 0 && d->n_tensors > 0 && d->ops && d->tensors, "engine_create: empty plan");
     AQ_REQUIRE(d->nl == 3 && d->na >= 1 && d->na <= 8 && d->nc >= 1, "engine_create: unsupported head nl=%d na=%d nc=%d", d->nl, d->na, d->nc);
-    AQ_REQUIRE(d->precision == AQ_BF16 || d->precision == AQ_FP32, "engine_create: bad precision %d", d->precision);
+    AQ_REQUIRE(d->precision == AQ_BF16 || d->precision == AQ_FP32 || d->precision == AQ_BF16_W8, "engine_create: bad precision %d", d->precision);
     AQ_CHECK_HIP(hipSetDevice(device));
     aq_engine* e = new aq_engine();
     e->device = device;
+    aq_model_desc compute_desc = *d;                   // AQ_BF16_W8 computes exactly as AQ_BF16; only the planar 3x3 weight stream differs
+    const bool w8 = d->precision == AQ_BF16_W8;
+    if (w8) compute_desc.precision = AQ_BF16;
+    d = &compute_desc;
     e->desc = *d;
     e->tensors.assign(d->tensors, d->tensors + d->n_tensors);
     e->ops.assign(d->ops, d->ops + d->n_ops);
@@ -471,6 +483,21 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
                 return fail(AQ_ERR_HIP);
             }
             pw.direct_cfg = AQ_CONV_CFG_PL3X3;
+            // AQ_BF16_W8 engines: the e4m3 code stream is built on request only (AQ_PL_W8=1).  Measured (tools/time_conv3x3.py, batch 64):
+            // 85.0 vs 82.2 us at 192 ch / 40^2 and 76.6 vs 68.3 us at 384 ch / 20^2 -- the stream is bound by what one wave per SIMD can
+            // ISSUE between MFMAs, not by L2 -> register bytes, so halving the bytes at the price of 48 conversion instructions per tap
+            // loses.  It is bit-identical to the bf16 stream and halves the planar layers' weight footprint.
+            const char* use_w8 = getenv("AQ_PL_W8");
+            if (w8 && use_w8 && *use_w8 == '1') {
+                // a layer whose weights are not on an fp8 grid (the caller did not quantise it) keeps the bf16 stream
+                if (aq_pack_conv3x3_pl_w8(op.weight, op.bias, op.src.channels, op.dst.channels, nullptr, &nb, nullptr, nullptr) == AQ_OK &&
+                    hipMalloc(&pw.w_pl8, nb) == hipSuccess && hipMalloc((void**)&pw.sb_pl8, 2048 * sizeof(float)) == hipSuccess) {
+                    if (aq_pack_conv3x3_pl_w8(op.weight, op.bias, op.src.channels, op.dst.channels, pw.w_pl8, &nb, pw.sb_pl8, nullptr) != AQ_OK) {
+                        (void)hipFree(pw.w_pl8); (void)hipFree(pw.sb_pl8);
+                        pw.w_pl8 = nullptr; pw.sb_pl8 = nullptr;
+                    }
+                }
+            }
         }
         op.weight = nullptr; op.bias = nullptr;   // host pointers are not kept
     }
@@ -483,6 +510,8 @@ extern "C" void aq_engine_destroy(aq_engine* e) {
     for (PackedW& pw : e->packed) {
         if (pw.w) (void)hipFree(pw.w);
         if (pw.w_direct) (void)hipFree(pw.w_direct);
+        if (pw.w_pl8) (void)hipFree(pw.w_pl8);
+        if (pw.sb_pl8) (void)hipFree(pw.sb_pl8);
         if (pw.bias) (void)hipFree(pw.bias);
     }
     if (e->zero_page) (void)hipFree(e->zero_page);

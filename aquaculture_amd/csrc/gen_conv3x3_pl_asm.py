@@ -38,7 +38,8 @@ CONFIGS = {
     7: dict(NB=7, PD=8, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False),
     8: dict(NB=8, PD=7, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False),
 }
-STEP_B = 6 * 1024
+STEP_B = 6 * 1024          # weight bytes per (wave, tap-step): six 1 KB bf16 fragments ...
+W8 = False                 # ... or, in the fp8-weight kernels (set per kernel by gen_kernel), three 1 KB pairs of e4m3 fragments
 
 
 def configure(nb):
@@ -165,6 +166,32 @@ def areg(set_idx, k):
         b = 12 * NB + 24 * set_idx + 4 * k
         return f"a[{b}:{b + 3}]"
     return vr("A", 24 * set_idx + 4 * k, 4)
+
+
+# fp8-weight kernels: the 72 weight registers hold three RAW sets of 12 (e4m3 codes as loaded), two converted bf16 half-sets of 12
+# (k-step 0 and k-step 1 of the tap being multiplied) and the 12 per-channel scales of the epilogue
+def rawreg(set_idx, pair):
+    assert W8 and not A_IN_ACC and 0 <= set_idx < 3 and 0 <= pair < 3
+    return vr("A", 12 * set_idx + 4 * pair, 4)
+
+
+def bfreg(half, i):
+    assert W8 and half in (0, 1) and 0 <= i < 3
+    return vr("A", 36 + 12 * half + 4 * i, 4)
+
+
+def emit_convert(tap, ks, i, step):
+    """Quarter `step` (two VALU instructions) of converting fragment i of (tap, k-step ks) from raw e4m3 codes to bf16."""
+    k = 3 * ks + i
+    raw = V.names["A"][0] + 12 * (tap % 3) + 4 * (k // 2) + 2 * (k % 2) + step // 2
+    dst = V.names["A"][0] + 36 + 12 * ks + 4 * i + 2 * (step // 2)
+    t0 = V.names["t"][0] + 12
+    if step % 2 == 0:
+        E(f"v_cvt_pk_f32_fp8_e32 v[{t0}:{t0 + 1}], v{raw}")
+        E(f"v_cvt_pk_f32_fp8_sdwa v[{t0 + 2}:{t0 + 3}], v{raw} src0_sel:WORD_1")
+    else:
+        E(f"v_cvt_pk_bf16_f32 v{dst}, v{t0}, v{t0 + 1}")
+        E(f"v_cvt_pk_bf16_f32 v{dst + 1}, v{t0 + 2}, v{t0 + 3}")
 
 
 def n_acc():
@@ -327,10 +354,11 @@ def emit_dma(k, s2i, cd_s, bd_s):
 
 
 def emit_load_a(set_idx, k, base_s2, extra_off):
-    """fragment k (0..5) of a tap-step into A set set_idx: 1 KB at base + extra_off + 1024 k (base is the tap-step's stream + 3072)."""
+    """fragment k (0..5) of a tap-step into A set set_idx: 1 KB at base + extra_off + 1024 k (base is the tap-step's stream + 3072);
+    fp8 weights: fragment PAIR k (0..2), lane = 8 codes of fragment 2 k then 8 of fragment 2 k + 1, into raw set set_idx."""
     off = 1024 * k - 3072 + extra_off
     assert -4096 <= off <= 4095
-    E(f"global_load_dwordx4 {areg(set_idx, k)}, {v('aoff')}, {base_s2} offset:{off}")
+    E(f"global_load_dwordx4 {rawreg(set_idx, k) if W8 else areg(set_idx, k)}, {v('aoff')}, {base_s2} offset:{off}")
 
 
 def emit_set_a_base(dst, tap):
@@ -354,7 +382,7 @@ def emit_a_stream_base(dst, tile_s, c_s):
     E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {c_s}")
     E(f"s_mul_i32 {s('tmp1')}, {s('tmp0')}, {9 * STEP_B}")
     E(f"s_mul_hi_u32 {s('tmp2')}, {s('tmp0')}, {9 * STEP_B}")
-    E(f"s_add_u32 {s('tmp1')}, {s('tmp1')}, 3072")
+    E(f"s_add_u32 {s('tmp1')}, {s('tmp1')}, 3072", "keeps every fragment offset inside the 13-bit immediate")
     E(f"s_addc_u32 {s('tmp2')}, {s('tmp2')}, 0")
     E(f"s_add_u32 {s(dst)}, {s('w')}, {s('tmp1')}")
     E(f"s_addc_u32 {s(dst, 1)}, {s('w', 1)}, {s('tmp2')}")
@@ -382,12 +410,14 @@ def stamp(k):
     E(f"s_mov_b64 {s2('st_last')}, {s2('t64')}")
 
 
-def gen_kernel(name, RES, stamped=False, abl=0):
+def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     """abl: timing-only ablations of the stamped build (wrong results): 1 = no weight loads in the stream, 2 = no LDS-DMA in the stream,
     4 = no B fragment reads, 8 = no MFMAs."""
-    global out
+    global out, W8, STEP_B
     out = []
     STAMPED[0] = stamped
+    W8, STEP_B = w8, (3 if w8 else 6) * 1024
+    assert not w8 or (RES_EARLY and LOOK == 2 and not A_IN_ACC and NB >= 12)
     _uid[0], _uid[1] = 0, name.split("asm_", 1)[1].replace("_", "")
     E(f"; conv3x3_pl assembly, NB = {NB}, {OCC} workgroup(s) per CU, RES = {int(RES)}: generated by gen_conv3x3_pl_asm.py -- do not edit")
     label(name)
@@ -453,7 +483,7 @@ def gen_kernel(name, RES, stamped=False, abl=0):
     emit_a_stream_base("a_cur", s("tile"), s("c"))
     for tap in range(LOOK):                        # offsets beyond a tap-step exceed the immediate range, so move the base
         emit_set_a_base("a_ld", tap)
-        for k in range(6):
+        for k in range(3 if w8 else 6):
             emit_load_a(tap, k, s2("a_ld"), 0)
     emit_region_rows(s("tile"))
     E(f"s_mov_b32 {s('cd')}, 0")
@@ -479,6 +509,17 @@ def gen_kernel(name, RES, stamped=False, abl=0):
     E(f"s_mov_b32 m0, {s('tmp0')}")
     E("s_nop 0", "hz: s_mov m0 -> LDS-DMA")
     E(f"global_load_lds_dwordx4 v[{V.names['t'][0] + 4}:{V.names['t'][0] + 5}], off")
+    if w8:
+        # fp8 weights: `bias` holds bias x 2^-e (1024 floats) and then the per-channel scales 2^e (1024 floats)
+        E(f"v_add_co_u32 {T[4]}, vcc, 4096, {T[4]}")
+        E(f"v_addc_co_u32 {T[5]}, vcc, 0, {T[5]}, vcc")
+        E(f"v_cmp_lt_u32 vcc, {s('cout')}, {T[3]}")
+        E(f"v_cndmask_b32 {T[4]}, {T[4]}, {v('zero_lo')}, vcc")
+        E(f"v_cndmask_b32 {T[5]}, {T[5]}, {v('zero_hi')}, vcc")
+        E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, 4096")
+        E(f"s_mov_b32 m0, {s('tmp0')}")
+        E("s_nop 0", "hz: s_mov m0 -> LDS-DMA")
+        E(f"global_load_lds_dwordx4 v[{V.names['t'][0] + 4}:{V.names['t'][0] + 5}], off")
     if RING == 3:
         E(f"s_mov_b32 {s('cd')}, 1")
         E(f"s_mov_b32 {s('bd')}, 1")
@@ -489,6 +530,10 @@ def gen_kernel(name, RES, stamped=False, abl=0):
     else:
         E("s_waitcnt vmcnt(0)", "weights of taps 0 and 1, chunk 0, the bias")
     emit_barrier()
+    if w8:
+        for i in range(3):                         # k-step 0 of the very first tap; every later half-tap is converted under MFMAs
+            for step in range(4):
+                emit_convert(0, 0, i, step)
     stamp(PH_PROLOGUE)
     E(f"s_mov_b32 {s('buf')}, 0")
     E(f"s_mov_b32 {s('first')}, 1")
@@ -653,7 +698,7 @@ def gen_kernel(name, RES, stamped=False, abl=0):
         assert nxt == NB and kD1 + 2 < 2 * NB
 
     def tap_ops(t, last=True):
-        ops = [(2 * k + 1, "A", (t + LOOK) % 9, k) for k in range(6) if not abl & 1]
+        ops = [(2 * k + 1, "A", (t + LOOK) % 9, k) for k in range(3 if w8 else 6) if not abl & 1]
         if t < NG and not abl & 2:
             ops += [(kD0, "D", t, 0), (kD1, "D", t, 1)]
         if in_stream_res and last:
@@ -661,26 +706,26 @@ def gen_kernel(name, RES, stamped=False, abl=0):
                 ops += [((kD0, kD1)[g] + 2, "R", j, i) for i in range(3)]
         return sorted(ops, key=lambda o: o[0])
 
-    def younger_than(t, k_last, e_wait, last):
-        """Vector-memory operations issued after weight load k_last of tap t's set and before element e_wait of tap t, in a tile's
+    def younger_than(tap, k_last, t_wait, e_wait, last):
+        """Vector-memory operations issued after weight load k_last of tap `tap` and before element e_wait of tap t_wait, in a tile's
         last chunk (with the residual loads) or another one; the chunk before is never a last chunk that matters: its residual loads
         are older than the weights of taps 0 and 1."""
-        seq = [o for tt in range(9) for o in tap_ops(tt, False)] + [o for tt in range(t) for o in tap_ops(tt, last)]
-        seq += [o for o in tap_ops(t, last) if o[0] < e_wait]
-        idx = max(i for i, o in enumerate(seq) if o[1] == "A" and o[2] == t and o[3] == k_last)
+        seq = [o for tt in range(9) for o in tap_ops(tt, False)] + [o for tt in range(t_wait) for o in tap_ops(tt, last)]
+        seq += [o for o in tap_ops(t_wait, last) if o[0] < e_wait]
+        idx = max(i for i, o in enumerate(seq) if o[1] == "A" and o[2] == tap and o[3] == k_last)
         return len(seq) - 1 - idx
 
-    def wait_weights(t, half):
-        """First (k-step 0) or second (k-step 1) three fragments of tap t's weights."""
+    def wait_weights(tap, k_last, t_wait, e_wait):
+        """Weight loads 0 .. k_last of tap `tap` have landed, at element e_wait of tap t_wait."""
         if abl & 1:
             return
-        kN = younger_than(t, 2 + 3 * half, half * NB, False)
-        kL = younger_than(t, 2 + 3 * half, half * NB, True)
+        kN = younger_than(tap, k_last, t_wait, e_wait, False)
+        kL = younger_than(tap, k_last, t_wait, e_wait, True)
         assert kN <= kL <= 63
         cases = []                                        # (flag register, immediate)
         if kL != kN:
             cases.append((s("lastc"), kL))
-        if t < LOOK:
+        if tap < LOOK and t_wait < LOOK:                  # loaded before the previous tile's epilogue
             cases.append((s("extra"), min(63, kN + n_extra)))
         # the common case falls through (a taken branch costs the wave its instruction buffer); the others wait out of line
         ld = uid("wd")
@@ -689,7 +734,7 @@ def gen_kernel(name, RES, stamped=False, abl=0):
             E(f"s_cmp_eq_u32 {flag}, 1")
             E(f"s_cbranch_scc1 {lx}")
             cold.append((lx, imm, ld))
-        E(f"s_waitcnt vmcnt({kN})", f"weights of tap {t}, k-step {half}")
+        E(f"s_waitcnt vmcnt({kN})", f"weights of tap {tap}, loads 0 .. {k_last}")
         label(ld)
 
     for n in range(NE):
@@ -698,8 +743,12 @@ def gen_kernel(name, RES, stamped=False, abl=0):
         e = ks * NB + j
         if n + PD < NE:
             b_read(n + PD)
-        if j == 0:
-            wait_weights(t, ks)
+        if j == 0 and not w8:
+            wait_weights(t, 2 + 3 * ks, t, e)             # bf16 fragments: three per k-step
+        elif j == 0 and ks == 0:
+            wait_weights(t, 2, t, e)                      # raw pair 2 of this tap: converted (k-step 1) under this k-step's MFMAs
+        elif j == 0:
+            wait_weights((t + 1) % 9, 1, t, e)            # raw pairs 0, 1 of the next tap: its k-step 0 is converted under this one
         for op in tap_ops(t):
             if op[0] != e:
                 continue
@@ -725,7 +774,14 @@ def gen_kernel(name, RES, stamped=False, abl=0):
         allowed = min(PD, NE - 1 - n)
         E(f"s_waitcnt lgkmcnt({allowed})")
         for i in range(3 if not abl & 8 else 0):
-            E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {areg(t % (LOOK + 1), 3 * ks + i)}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
+            srca = bfreg(ks, i) if w8 else areg(t % (LOOK + 1), 3 * ks + i)
+            E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {srca}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
+        if w8 and j < 12:
+            # one quarter of a fragment of the NEXT half-tap per element: two VALU instructions in the shadow of three MFMAs
+            if ks == 0:
+                emit_convert(t, 1, j // 4, j % 4)
+            else:
+                emit_convert((t + 1) % 9, 0, j // 4, j % 4)
     # ---- chunk end ----
     stamp(PH_STREAM)
     # next chunk: delta0 = (next buffer - this buffer) * CHUNK - (2 Wp + 2) * 16
@@ -767,6 +823,14 @@ def gen_kernel(name, RES, stamped=False, abl=0):
         tail = [o for tt in range(9) for o in tap_ops(tt, True)]
         k_res = len(tail) - 1 - max(i for i, o in enumerate(tail) if o[1] == "R")
         E(f"s_waitcnt vmcnt({k_res})", "the residual (only weight loads of the next tile's first taps are younger)")
+    SC = V.names["A"][0] + 60    # fp8 weights: per-channel scales 2^e of this lane's 3 x 4 output channels
+    if w8:
+        for i in range(3):
+            E(f"v_lshl_add_u32 {T[6]}, {v('q')}, 2, {s('cbase')}")
+            E(f"v_lshlrev_b32 {T[6]}, 2, {T[6]}")
+            E(f"v_add_u32 {T[6]}, {BIAS_OFF + 4096}, {T[6]}")
+            E(f"ds_read_b128 v[{SC + 4 * i}:{SC + 4 * i + 3}], {T[6]} offset:{64 * i}")
+        E("s_waitcnt lgkmcnt(0)")
     lact, lepd = uid("noact"), uid("epd")
     X = V.names["t"][0] + 0      # x[0:3]
     Y = V.names["t"][0] + 4      # work
@@ -788,6 +852,9 @@ def gen_kernel(name, RES, stamped=False, abl=0):
                     E(f"v_accvgpr_read_b32 v{X + e}, a{a0 + e}")
                 if RES and not RES_EARLY:
                     E(f"s_waitcnt vmcnt({3 * NB - 1})", "this block's residual: the younger loads and the stores issued so far stay in flight")
+                if w8:                                   # exact: the scales are powers of two
+                    E(f"v_pk_mul_f32 v[{X}:{X + 1}], v[{X}:{X + 1}], v[{SC + 4 * i}:{SC + 4 * i + 1}]")
+                    E(f"v_pk_mul_f32 v[{X + 2}:{X + 3}], v[{X + 2}:{X + 3}], v[{SC + 4 * i + 2}:{SC + 4 * i + 3}]")
 
                 def unpack_residual():
                     E(f"v_lshlrev_b32 v{Rr}, 16, v{r0}")
@@ -862,11 +929,15 @@ def gen_kernel(name, RES, stamped=False, abl=0):
     return list(out)
 
 
+def lds_bytes():
+    return LDS_BYTES + (4096 if W8 else 0)
+
+
 def register_budget():
     acc_off = (V.next + 3) // 4 * 4
     total = (acc_off + n_acc() + 7) // 8 * 8
     assert total <= 512 // OCC, f"NB = {NB}: {total} registers do not leave room for {OCC} wave(s) per SIMD"
-    assert OCC * LDS_BYTES <= 160 * 1024
+    assert OCC * lds_bytes() <= 160 * 1024
     return acc_off, total
 
 
@@ -876,7 +947,7 @@ def descriptor(name):
 	.rodata
 	.p2align 6
 	.amdhsa_kernel {name}
-		.amdhsa_group_segment_fixed_size {LDS_BYTES}
+		.amdhsa_group_segment_fixed_size {lds_bytes()}
 		.amdhsa_private_segment_fixed_size 0
 		.amdhsa_kernarg_size {ARG_BYTES}
 		.amdhsa_user_sgpr_count 2
@@ -903,7 +974,7 @@ def metadata_entry(name):
       - .offset:         0
         .size:           {ARG_BYTES}
         .value_kind:     by_value
-    .group_segment_fixed_size: {LDS_BYTES}
+    .group_segment_fixed_size: {lds_bytes()}
     .kernarg_segment_align: 8
     .kernarg_segment_size: {ARG_BYTES}
     .max_flat_workgroup_size: 256
@@ -938,14 +1009,16 @@ def main():
     entries = []
     for nb in sorted(CONFIGS):
         configure(nb)
-        variants = [(False, False, 0), (True, False, 0), (True, True, 0)]
+        variants = [(False, False, 0, False), (True, False, 0, False), (True, True, 0, False)]
+        if nb == 13:
+            variants += [(False, False, 0, True), (True, False, 0, True), (True, True, 0, True)]     # fp8-weight stream
         if DIAG and nb in (7, 13):
-            variants += [(True, True, a) for a in (1, 2, 3, 4, 7, 8)]
-        for RES, stamped, abl in variants:
-            name = f"conv3x3_pl_asm_nb{NB}_res{int(RES)}" + ("_stamped" if stamped else "") + (f"_abl{abl}" if abl else "")
-            entries.append(metadata_entry(name))
+            variants += [(True, True, a, False) for a in (1, 2, 3, 4, 7, 8)]
+        for RES, stamped, abl, w8 in variants:
+            name = f"conv3x3_pl_asm_nb{NB}_res{int(RES)}" + ("_w8" if w8 else "") + ("_stamped" if stamped else "") + (f"_abl{abl}" if abl else "")
             text += [f"\t.globl\t{name}", "\t.p2align\t8", f"\t.type\t{name},@function"]
-            text += gen_kernel(name, RES, stamped, abl)
+            text += gen_kernel(name, RES, stamped, abl, w8)
+            entries.append(metadata_entry(name))
             text += [f".Lfend_{name}:", f"\t.size\t{name}, .Lfend_{name}-{name}", descriptor(name)]
         print(f"NB = {NB}: {V.next} VGPRs + {n_acc()} AGPRs, {S.next} SGPRs, {LDS_BYTES} B LDS, {OCC} workgroup(s) per CU")
     text.append(metadata(entries))

@@ -22,10 +22,12 @@ import torch
 from . import spec as _spec
 from .checkpoint import Checkpoint, pack_plan_weights
 
-AQ_BF16, AQ_FP32 = 0, 1
+AQ_BF16, AQ_FP32, AQ_BF16_W8 = 0, 1, 2
 PRECISIONS = {"bf16": AQ_BF16, "fp32": AQ_FP32, "fp8w": AQ_BF16}
-"""fp8w = fp8 (OCP e4m3fn) weights with per-output-channel power-of-two scales, bf16 activations (quant.py): values bf16 holds
-exactly, so the C engine runs it in its bf16 mode."""
+"""Compute precision of the single-op helpers.  fp8w = fp8 (OCP e4m3fn) weights with per-output-channel power-of-two scales, bf16
+activations (quant.py): values bf16 holds exactly, so every bf16 kernel runs them as they are."""
+ENGINE_PRECISIONS = {"bf16": AQ_BF16, "fp32": AQ_FP32, "fp8w": AQ_BF16_W8}
+"""aq_model_desc.precision.  AQ_BF16_W8 computes as AQ_BF16; kernels with an fp8-weight stream (the planar 3x3) load the e4m3 codes."""
 _DTYPE_CODE = {"act": 0, "f32": 1, "u8": 2}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaqengine.so")
@@ -67,7 +69,7 @@ EXPORTS = (
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
     "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
     "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct",
-    "aq_conv3x3_pl_supported", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_preprocess_s2d", "aq_sppf_pool",
+    "aq_conv3x3_pl_supported", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_letterbox_tiles_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
 
@@ -120,6 +122,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_conv3x3_pl_supported.argtypes = [i32, i32]
     lib.aq_pack_conv3x3_pl.argtypes = [C.POINTER(f32), i32, i32, vp, C.POINTER(sz), vp]
     lib.aq_conv3x3_pl.argtypes = [vp, C.c_longlong, C.c_longlong, i32, vp, i32, i32, i32, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp]
+    lib.aq_conv3x3_pl_w8.argtypes = lib.aq_conv3x3_pl.argtypes
+    lib.aq_pack_conv3x3_pl_w8.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), i32, i32, vp, C.POINTER(C.c_size_t), vp, vp]
+    lib.aq_conv3x3_pl_w8_supported.argtypes = [i32] * 5
     lib.aq_preprocess_s2d.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.aq_sppf_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.aq_upsample2x.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -163,7 +168,7 @@ class Engine:
         _require_gpu()
         self.lib = load_library()
         self.ck = ck
-        self.precision = PRECISIONS[precision]
+        self.precision = ENGINE_PRECISIONS[precision]
         self.precision_name = precision
         self.device = torch.device("cuda", device)
         if fused_bottleneck is None:
@@ -570,9 +575,10 @@ CONV_CFG_ONE_TILE_PER_WG = 4096  # AQ_CONV_CFG_ONE_TILE_PER_WG (OR-ed into a til
 
 
 def conv3x3_pl_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, act: bool = True,
-                    residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, w8: bool = False) -> torch.Tensor:
     """bf16 NHWC [B,H,W,cin] (may be a channel slice) -> (residual +) SiLU(conv3x3/s1/p1(x) + b) through aq_conv3x3_pl (tests).
-    ``out`` and ``residual`` may be channel slices of wider tensors; ``residual`` may be ``out`` itself (in-place shortcut)."""
+    ``out`` and ``residual`` may be channel slices of wider tensors; ``residual`` may be ``out`` itself (in-place shortcut).
+    ``w8``: through aq_conv3x3_pl_w8 (e4m3 weight stream; ``w_oihw`` must lie on an fp8 grid, quant.quantize_rows)."""
     _require_gpu()
     lib = load_library()
     assert x.dtype == torch.bfloat16 and x.stride(3) == 1
@@ -583,14 +589,24 @@ def conv3x3_pl_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, a
     w = np.ascontiguousarray(w_oihw.permute(0, 2, 3, 1).float().cpu().numpy())
     n = C.c_size_t()
     wp = w.ctypes.data_as(C.POINTER(C.c_float))
-    _check(lib.aq_pack_conv3x3_pl(wp, cin, cout, None, C.byref(n), None))
-    wbuf = torch.empty(n.value, dtype=torch.uint8, device=x.device)
-    _check(lib.aq_pack_conv3x3_pl(wp, cin, cout, wbuf.data_ptr(), C.byref(n), _stream_ptr()))
-    bbuf = bias.float().to(x.device).contiguous()
+    if w8:
+        if not lib.aq_conv3x3_pl_w8_supported(cin, cout, B, H, W):
+            raise RuntimeError("aq_conv3x3_pl_w8 does not support this shape")
+        bh = np.ascontiguousarray(bias.float().cpu().numpy())
+        bp = bh.ctypes.data_as(C.POINTER(C.c_float))
+        _check(lib.aq_pack_conv3x3_pl_w8(wp, bp, cin, cout, None, C.byref(n), None, None))
+        wbuf = torch.empty(n.value, dtype=torch.uint8, device=x.device)
+        bbuf = torch.empty(2048, dtype=torch.float32, device=x.device)
+        _check(lib.aq_pack_conv3x3_pl_w8(wp, bp, cin, cout, wbuf.data_ptr(), C.byref(n), bbuf.data_ptr(), _stream_ptr()))
+    else:
+        _check(lib.aq_pack_conv3x3_pl(wp, cin, cout, None, C.byref(n), None))
+        wbuf = torch.empty(n.value, dtype=torch.uint8, device=x.device)
+        _check(lib.aq_pack_conv3x3_pl(wp, cin, cout, wbuf.data_ptr(), C.byref(n), _stream_ptr()))
+        bbuf = bias.float().to(x.device).contiguous()
     if out is None:
         out = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=x.device)
     assert out.stride(3) == 1 and (residual is None or residual.stride(3) == 1)
-    _check(lib.aq_conv3x3_pl(x.data_ptr(), ld * 2, 16, cin, out.data_ptr(), out.stride(2), 0, cout,
+    _check((lib.aq_conv3x3_pl_w8 if w8 else lib.aq_conv3x3_pl)(x.data_ptr(), ld * 2, 16, cin, out.data_ptr(), out.stride(2), 0, cout,
                              residual.data_ptr() if residual is not None else None, residual.stride(2) if residual is not None else 0, 0,
                              wbuf.data_ptr(), bbuf.data_ptr(), B, H, W, int(act), _stream_ptr()))
     torch.cuda.current_stream().synchronize()

@@ -41,7 +41,9 @@ typedef enum aq_status {
 
 typedef enum aq_precision {
     AQ_BF16 = 0,   /* bf16 weights + activations, fp32 accumulate/epilogue/head (throughput mode) */
-    AQ_FP32 = 1    /* fp32 everywhere on f32-input MFMA (parity mode: detect.py without --half) */
+    AQ_FP32 = 1,   /* fp32 everywhere on f32-input MFMA (parity mode: detect.py without --half) */
+    AQ_BF16_W8 = 2 /* AQ_BF16 whose conv weights lie on an OCP e4m3fn x 2^e[cout] grid (BASELINE.json configs[3], "fp8 weights"):
+                    * kernels that have an fp8-weight stream (the planar 3x3) load the 1-byte codes, the others the same values as bf16 */
 } aq_precision;
 
 typedef enum aq_op_kind {
@@ -208,6 +210,15 @@ int aq_pack_conv3x3_pl(const float* w_krsc_host, int cin, int cout, void* packed
 int aq_conv3x3_pl(const void* in_dev, long long in_pixel_stride_b, long long in_group_stride_b, int cin,
                   void* out_dev, int out_ld, int out_choff, int cout, const void* res_dev, int res_ld, int res_choff,
                   const void* packed_w_dev, const float* bias_dev, int B, int H, int W, int act, void* stream);
+/* The same kernel streaming e4m3fn weight codes (AQ_BF16_W8): bit-identical outputs to aq_conv3x3_pl on the dequantised weights.
+ * `w` must lie on a per-output-channel grid code x 2^e (AQ_ERR_INVALID otherwise); scale_bias_dev: float[2048] written by the packer
+ * (bias x 2^-e, then 2^e).  _supported: NB = 13 tiles fit the image and cout / 192 is a power of two. */
+int aq_conv3x3_pl_w8_supported(int cin, int cout, int B, int H, int W);
+int aq_pack_conv3x3_pl_w8(const float* w_krsc_host, const float* bias_host, int cin, int cout, void* packed_dev, size_t* bytes,
+                          float* scale_bias_dev, void* stream);
+int aq_conv3x3_pl_w8(const void* in_dev, long long in_sp, long long in_ss, int cin, void* out_dev, int out_ld, int out_choff,
+                     int cout, const void* res_dev, int res_ld, int res_choff, const void* packed_w8_dev,
+                     const float* scale_bias_dev, int B, int H, int W, int act, void* stream);
 /* uint8 RGB NHWC -> 2x2 space-to-depth, 16 channels, value/255 ([UPSTREAM detect.py: im.float()/255]). */
 int aq_preprocess_s2d(const uint8_t* tiles_dev, void* out_dev, int B, int H, int W, int precision, void* stream);
 /* Letterbox on device (the real 1024x1024 tiles of reference src/load_data/tile_tifs.py:13 -> 640x640):

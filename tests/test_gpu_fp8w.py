@@ -36,6 +36,85 @@ def test_conv_on_fp8_valued_weights(lib, case):
     torch.testing.assert_close(out, ref.bfloat16().float(), rtol=2 ** -7, atol=2e-3)
 
 
+W8_CASES = [
+    # B, H, W, Cin, Cout, residual mode, act -- shapes of tests/test_gpu_conv.py PL_CASES that the fp8-weight kernel supports
+    (3, 40, 40, 192, 192, "inplace", True),
+    (2, 20, 20, 384, 384, "sep", True),
+    (1, 9, 7, 192, 192, "sep", True),
+    (2, 13, 24, 128, 192, None, True),
+    (5, 20, 20, 192, 192, None, False),
+    (40, 40, 40, 192, 192, "inplace", True),     # persistent workgroups walk several tiles: conversions across the tile seam
+    (3, 10, 10, 768, 768, "sep", True),
+]
+
+
+@pytest.mark.parametrize("case", W8_CASES)
+def test_fp8_weight_stream_is_bit_identical_to_the_bf16_stream(lib, case, monkeypatch):
+    """aq_conv3x3_pl_w8 (e4m3 codes loaded, converted to bf16 fragments under the MFMAs, power-of-two scale in the epilogue) against
+    aq_conv3x3_pl on the dequantised weights, same tile shape: the scale commutes with every fp32 rounding, so EVERY output bit must
+    agree -- this also pins the hardware conversion (v_cvt_pk_f32_fp8 = OCP e4m3fn on gfx950) for all codes the weights use."""
+    from aquaculture_amd import engine, quant
+    B, H, W, cin, c, resmode, act = case
+    monkeypatch.setenv("AQ_PL_NB", "13")
+    monkeypatch.setenv("AQ_PL_ASM", "1")
+    g = torch.Generator().manual_seed(c * 5 + H)
+    x = (torch.randn(B, H, W, cin, generator=g) * 0.8).bfloat16().cuda()
+    w = torch.randn(c, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    w[1] *= 1e-3                                   # a channel whose scale differs by ten binades, with subnormal codes
+    w[2, : cin // 2] = 0.0
+    deq, codes, _ = quant.quantize_rows(w.numpy())
+    assert len(np.unique(codes)) > 200             # nearly every e4m3 code, subnormals and both signs included
+    wq = torch.from_numpy(deq)
+    b = torch.randn(c, generator=g) * 0.2
+    outs = []
+    for w8 in (False, True):
+        out = (torch.randn(B, H, W, c + 8, generator=torch.Generator().manual_seed(7))).bfloat16().cuda()
+        o = out[..., 8:]
+        res = None
+        if resmode == "sep":
+            res = (torch.randn(B, H, W, c, generator=torch.Generator().manual_seed(9))).bfloat16().cuda()
+        elif resmode == "inplace":
+            res = o
+        engine.conv3x3_pl_nhwc(x, wq, b, act, residual=res, out=o, w8=w8)
+        outs.append(out.cpu())
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wq, b, padding=1)
+    ref = (F.silu(ref) if act else ref).permute(0, 2, 3, 1)
+    if resmode == "sep":
+        ref = ref + torch.randn(B, H, W, c, generator=torch.Generator().manual_seed(9)).bfloat16().float()
+    if resmode != "inplace":
+        torch.testing.assert_close(outs[1][..., 8:].float(), ref.bfloat16().float(), rtol=2 ** -7, atol=4e-3)
+
+
+def test_fp8_weight_stream_refuses_weights_off_the_grid(lib):
+    from aquaculture_amd import engine
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 8, 8, 128, generator=g).bfloat16().cuda()
+    w = torch.randn(192, 128, 3, 3, generator=g) * 0.05
+    with pytest.raises(RuntimeError, match="e4m3"):
+        engine.conv3x3_pl_nhwc(x, w, torch.zeros(192), True, w8=True)
+
+
+def test_fp8w_engine_with_and_without_the_fp8_stream(lib, synth_ck, monkeypatch):
+    """AQ_BF16_W8 engines: the planar layers on the e4m3 stream (AQ_PL_W8=1) and on the bf16 stream (default) give the same bits."""
+    from aquaculture_amd import engine, tiles
+    x = torch.from_numpy(tiles.synthetic_batch([3, 11], 128)).cuda()
+    monkeypatch.setenv("AQ_PL_NB", "13")
+    raws = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("AQ_PL_W8", on)
+        eng = engine.Engine(synth_ck, "fp8w")
+        forced = 0
+        for i, o in enumerate(eng.plan.ops):
+            if o.kind == 1 and o.k == 3 and o.stride == 1 and eng.lib.aq_conv3x3_pl_supported(o.src.channels, o.dst.channels):
+                eng.set_conv_config(i, engine.CONV_CFG_PL3X3)
+                forced += 1
+        assert forced >= 14
+        raws.append(eng.forward_raw(x).float().cpu().clone())
+        del eng
+    assert torch.equal(raws[0], raws[1])
+
+
 def _stats(x, ref):
     d = (x - ref).abs()
     rms = float(ref.pow(2).mean().sqrt())

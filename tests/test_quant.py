@@ -55,3 +55,17 @@ def test_engine_packing_and_oracle_quantise_the_checkpoint_alike(synth_ck):
             assert np.array_equal(pk.weight, w_or.permute(0, 2, 3, 1).numpy()), op.name
             seen += 1
     assert seen >= 30
+
+
+def test_fp8_weight_stream_image_is_half_the_bf16_one():
+    """aq_pack_conv3x3_pl_w8 size query (no GPU): one byte per weight, against two in aq_pack_conv3x3_pl's fragment stream."""
+    import ctypes as C
+    from aquaculture_amd import engine
+    lib = engine.load_library()
+    n8, n16 = C.c_size_t(), C.c_size_t()
+    w = np.zeros((192, 3, 3, 128), np.float32)
+    wp = w.ctypes.data_as(C.POINTER(C.c_float))
+    assert lib.aq_pack_conv3x3_pl_w8(wp, None, 128, 192, None, C.byref(n8), None, None) == 0
+    assert lib.aq_pack_conv3x3_pl(wp, 128, 192, None, C.byref(n16), None) == 0
+    assert n8.value * 2 == n16.value == 192 * 9 * 128 * 2
+    assert lib.aq_conv3x3_pl_w8_supported(192, 192, 64, 40, 40) == 1 and lib.aq_conv3x3_pl_w8_supported(192, 576, 64, 40, 40) == 0

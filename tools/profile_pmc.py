@@ -34,7 +34,7 @@ def run_pass(name, counters, out, batch, steps):
     env = dict(os.environ, TMPDIR="/tmp", AQ_TUNE_CACHE=os.path.join(out, "tune_cache.json"))
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters.split(), "--output-format", "csv", "-d", d, "-o", "pmc", "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "1", "--batch", str(batch),
-           "--no-cpu-baseline", "--no-profile"]
+           "--no-cpu-baseline", "--no-profile", "--parity-steps", "0"]
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     with open(os.path.join(d, "log.txt"), "w") as f:
         f.write(r.stdout[-4000:] + "\n---\n" + r.stderr[-4000:])
@@ -51,7 +51,7 @@ def run_stats(out, batch):
     os.makedirs(d, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp", AQ_TUNE_CACHE=os.path.join(out, "tune_cache.json"))
     cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "bench", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--batch", str(batch), "--no-cpu-baseline"]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--batch", str(batch), "--no-cpu-baseline", "--parity-steps", "0"]
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     with open(os.path.join(d, "bench_stdout.json"), "w") as f:
         f.write(r.stdout)

@@ -50,6 +50,20 @@ def main():
             E._check(lib.aq_conv3x3_pl(xs[i % nbuf].data_ptr(), c * 2, 16, c, o.data_ptr(), 2 * c, 0, c, o.data_ptr(), 2 * c, 0,
                                        wpl.data_ptr(), bb.data_ptr(), B, H, W, 1, st))
 
+        from aquaculture_amd import quant
+        wq = np.ascontiguousarray(quant.quantize_rows(wk.reshape(c, -1))[0].reshape(wk.shape))
+        wqp = wq.ctypes.data_as(C.POINTER(C.c_float))
+        bh = np.ascontiguousarray(b.numpy())
+        E._check(lib.aq_pack_conv3x3_pl_w8(wqp, bh.ctypes.data_as(C.POINTER(C.c_float)), c, c, None, C.byref(n), None, None))
+        w8 = torch.empty(n.value, dtype=torch.uint8, device=dev)
+        sb8 = torch.empty(2048, dtype=torch.float32, device=dev)
+        E._check(lib.aq_pack_conv3x3_pl_w8(wqp, bh.ctypes.data_as(C.POINTER(C.c_float)), c, c, w8.data_ptr(), C.byref(n), sb8.data_ptr(), st))
+
+        def run_w8(i):
+            o = outs[i % nbuf]
+            E._check(lib.aq_conv3x3_pl_w8(xs[i % nbuf].data_ptr(), c * 2, 16, c, o.data_ptr(), 2 * c, 0, c, o.data_ptr(), 2 * c, 0,
+                                          w8.data_ptr(), sb8.data_ptr(), B, H, W, 1, st))
+
         def run_old(i):
             o = outs[i % nbuf]
             E._check(lib.aq_conv2d(xs[i % nbuf].data_ptr(), c, 0, c, o.data_ptr(), 2 * c, 0, c, o.data_ptr(), 2 * c, 0,
@@ -106,6 +120,8 @@ def main():
             life, ticks = t[:, 6], t[:, 7]
             print(f"{c}ch stamped {'asm NB=' + nbs if asm else 'hip'} ABL={sab - 16}: waves {t.shape[0]}  lifetime {life.mean():.0f} cycles (min {life.min():.0f} max {life.max():.0f}) = {ticks.mean() * 10:.0f} ns "
                   f"-> clock {(life / ticks).median() * 100:.0f} MHz | " + " ".join(f"{n}={t[:, k].mean():.0f}" for k, n in enumerate(names)), flush=True)
+        us = timeit(run_w8)
+        print(f"{c}ch {H}x{W} B{B}  planar NB=13 asm, e4m3 weight stream: {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
         us = timeit(run_pl)
         print(f"{c}ch {H}x{W} B{B}  planar auto : {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
         for cfg in [int(v) for v in a.old.split(",") if v]:
