@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <vector>
 
 namespace {
@@ -336,6 +337,14 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
     AQ_REQUIRE(d->n_ops > 0 && d->n_tensors > 0 && d->ops && d->tensors, "engine_create: empty plan");
     AQ_REQUIRE(d->nl == 3 && d->na >= 1 && d->na <= 8 && d->nc >= 1, "engine_create: unsupported head nl=%d na=%d nc=%d", d->nl, d->na, d->nc);
     AQ_REQUIRE(d->precision == AQ_BF16 || d->precision == AQ_FP32 || d->precision == AQ_BF16_W8, "engine_create: bad precision %d", d->precision);
+    {   // One device per process (one process per GPU is how every entry point of this package runs): the kernels' launch-attribute,
+        // CU-count and occupancy caches in conv_igemm / conv_halo / downblock / conv1x1_direct / detect_nms are process-global, and
+        // hipFuncSetAttribute is per device -- a second device would skip it and fail to launch anything above 64 KiB of LDS.
+        static std::atomic<int> first_device{-1};
+        int expected = -1;
+        if (!first_device.compare_exchange_strong(expected, device))
+            AQ_REQUIRE(expected == device, "engine_create: this process already runs engines on device %d; device %d needs its own process", expected, device);
+    }
     AQ_CHECK_HIP(hipSetDevice(device));
     aq_engine* e = new aq_engine();
     e->device = device;
