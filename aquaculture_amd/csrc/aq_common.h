@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include "../../include/aq_engine.h"
 
 typedef unsigned short bf16_t;  // raw bf16 bits
@@ -73,6 +74,14 @@ unsigned long long* aq_stamp_buffer(size_t* bytes);
 // 256 zero bytes on the CURRENT device (allocated on first use, one per device, never freed): the LDS-DMA source for pixels
 // outside the image in the standalone kernel entry points (the engine passes its own zero page to the conv kernels).
 const char* aq_zero_page();
+// Compute units the persistent grids are sized for: the device's count, or AQ_NUM_CUS when the caller runs this process's streams on a
+// subset of the CUs (hipExtStreamCreateWithCUMask: bench.py --cu-split gives each of the two batches in flight half of the chip).
+// Read once per kernel family (their grid caches are process-global), so set the variable before the first launch.
+inline hipError_t aq_query_cus(int* cus, int dev) {
+    const char* v = getenv("AQ_NUM_CUS");
+    if (v && atoi(v) > 0) { *cus = atoi(v); return hipSuccess; }
+    return hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev);
+}
 int aq_conv_halo_tiles(int hcfg, int* bm, int* bn);
 extern "C" int aq_conv_config_tiles(int cfg, int* bm, int* bn);
 extern "C" int aq_conv_num_configs(void);

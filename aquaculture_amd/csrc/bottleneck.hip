@@ -625,7 +625,7 @@ extern "C" int aq_bottleneck(const void* in_dev, int in_ld, int in_choff, void* 
     if (g_btl_cus == 0) {
         int dev = 0, cus = 256;
         AQ_CHECK_HIP(hipGetDevice(&dev));
-        AQ_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        AQ_CHECK_HIP(aq_query_cus(&cus, dev));
         g_btl_cus = cus;
     }
     const hipStream_t st = (hipStream_t)stream;

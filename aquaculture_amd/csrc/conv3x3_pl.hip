@@ -496,7 +496,7 @@ static int pl_conv(const void* in_dev, long long in_sp, long long in_ss, int cin
     AQ_REQUIRE(dev >= 0 && dev < 64, "conv3x3_pl: device ordinal %d", dev);
     if (g_pl_cus[dev] == 0) {
         int cus = 256;
-        AQ_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        AQ_CHECK_HIP(aq_query_cus(&cus, dev));
         g_pl_cus[dev] = cus;
     }
     PlParams p{};

@@ -362,7 +362,7 @@ int aq_launch_conv_halo(const ConvParams& p_in, int precision, int out_f32, int 
     if (g_halo_cus == 0) {
         int dev = 0, cus = 256;
         AQ_CHECK_HIP(hipGetDevice(&dev));
-        AQ_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        AQ_CHECK_HIP(aq_query_cus(&cus, dev));
         g_halo_cus = cus;
     }
     long long grid = g_halo_cus;          // > 80 KiB of LDS per workgroup: one resident workgroup per CU

@@ -606,7 +606,7 @@ int aq_launch_conv(const ConvParams& p_in, int precision, int out_f32, int cfg_i
     if (g_num_cus == 0) {
         int dev = 0, cus = 256;
         AQ_CHECK_HIP(hipGetDevice(&dev));
-        AQ_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        AQ_CHECK_HIP(aq_query_cus(&cus, dev));
         g_num_cus = cus;
     }
     int blocks = 0;

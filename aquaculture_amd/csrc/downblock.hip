@@ -306,7 +306,7 @@ int down_common(DownParams& p, const void* in_dev, int in_ld, int in_choff, int 
     if (g_down_cus == 0) {
         int dev = 0, cus = 256;
         AQ_CHECK_HIP(hipGetDevice(&dev));
-        AQ_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        AQ_CHECK_HIP(aq_query_cus(&cus, dev));
         g_down_cus = cus;
     }
     return AQ_OK;

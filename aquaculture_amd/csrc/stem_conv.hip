@@ -377,7 +377,7 @@ extern "C" int aq_stem_conv(const uint8_t* tiles_dev, void* out_dev, int out_ld,
     if (g_stem_cus == 0) {
         int dev = 0, cus = 256;
         AQ_CHECK_HIP(hipGetDevice(&dev));
-        AQ_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        AQ_CHECK_HIP(aq_query_cus(&cus, dev));
         g_stem_cus = cus;
     }
     const hipStream_t st = (hipStream_t)stream;

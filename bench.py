@@ -49,6 +49,9 @@ def parse():
     p.add_argument("--two-kernel-bottleneck", action="store_true", help="A/B: 1x1 + 3x3 launches instead of the fused Bottleneck kernel")
     p.add_argument("--two-kernel-stem", action="store_true", help="A/B: preprocess + space-to-depth conv instead of the fused stem kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cu-split", default="", help="experiment (measured: no gain -- 14.2 k tiles/s with `low`, 13.2-13.3 k with the others, against 14.5 k without): run the "
+                   "batches in flight on disjoint halves of the CUs (hipExtStreamCreateWithCUMask); value = layout of the even streams' "
+                   "mask: low | even | pairs | xcd (odd streams get the complement)")
     p.add_argument("--parity-steps", type=int, default=3, help="steps of the fp32 parity-mode engine timed beside the bf16 metric (0 = skip)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle sample budget")
     p.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristic instead of timing configs")
@@ -114,6 +117,9 @@ def main() -> int:
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if a.cu_split:
+        ncu = torch.cuda.get_device_properties(local).multi_processor_count
+        os.environ["AQ_NUM_CUS"] = str(ncu // 2)          # persistent grids sized for half the chip (read once, before the first launch)
     ck = checkpoint.synthetic_checkpoint(a.variant, 5)
     eng = Engine(ck, a.precision, local, fused_stem=not a.two_kernel_stem,
                  fused_bottleneck=(a.precision in ("bf16", "fp8w") and not a.two_kernel_bottleneck))
@@ -124,6 +130,24 @@ def main() -> int:
     counts = torch.zeros((K, B), dtype=torch.int32, device=dev)
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(a.streams)] if a.streams > 1 else [torch.cuda.current_stream()]
+    if a.cu_split:
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        words = (ncu + 31) // 32
+        bit = {"low": lambda i: i < ncu // 2, "even": lambda i: i % 2 == 0, "pairs": lambda i: (i // 2) % 2 == 0,
+               "xcd": lambda i: (i % 8) < 4}[a.cu_split]
+        streams = []
+        for si in range(max(2, a.streams)):
+            side = si % 2
+            m = (C.c_uint32 * words)()
+            for i in range(ncu):
+                if bit(i) == (side == 0):
+                    m[i // 32] |= 1 << (i % 32)
+            h = C.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), C.c_uint32(words), m)
+            if rc != 0:
+                raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
+            streams.append(torch.cuda.ExternalStream(h.value, device=dev))
 
     def step(k: int, slot: int):
         # independent batches alternate over the streams: batch k+1's high-resolution layers fill the CUs that
@@ -149,7 +173,9 @@ def main() -> int:
         t = torch.tensor([g.total if rank == 0 else int(counts.sum())], dtype=torch.int64)
         return t
 
-    cfgs = eng.autotune(tiles_dev[0], cache=os.environ.get("AQ_TUNE_CACHE")) if not a.no_autotune else None
+    with torch.cuda.stream(streams[0]):                   # (a CU-masked stream times the candidates on the CUs they will run on)
+        cfgs = eng.autotune(tiles_dev[0], cache=os.environ.get("AQ_TUNE_CACHE")) if not a.no_autotune else None
+    torch.cuda.synchronize()
     for k in range(max(W, a.streams)):
         step(k, 0)
     join()
@@ -269,7 +295,7 @@ def main() -> int:
         "config": {"workload": f"{a.variant} {a.precision}, 1xMI355X per rank, batch={B}, synthetic {a.size}x{a.size} ocean tiles "
                                f"resident in HBM ({a.pool} distinct batches cycled), seeded random-init weights nc=5 "
                                f"(BASELINE.json configs[{3 if a.precision == 'fp8w' else 1}])",
-                   "batch_per_gpu": B, "tile_px": a.size, "parallelism": f"tile-sharded dp{world}", "batches_in_flight": a.streams,
+                   "batch_per_gpu": B, "tile_px": a.size, "parallelism": f"tile-sharded dp{world}", "batches_in_flight": a.streams, **({"cu_split": a.cu_split} if a.cu_split else {}),
                    "detections_gathered": n_dets_total},
         "roofline": roof,
     }
