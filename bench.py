@@ -243,7 +243,7 @@ def main() -> int:
             one_per_wg = cbest >= aqengine.CONV_CFG_ONE_TILE_PER_WG          # flag OR-ed into a tile-shape id
             shape = cbest & (aqengine.CONV_CFG_ONE_TILE_PER_WG - 1)
             if not one_per_wg and cbest == aqengine.CONV_CFG_PL3X3:
-                kname = "conv3x3_pl_kernel (planar 3x3/s1: weights streamed to registers, slot-major region in LDS)"
+                kname = "conv3x3_pl_asm_nb13 / conv3x3_pl_kernel (planar 3x3/s1: weights streamed to registers, slot-major region in LDS; generated gfx950 assembly build, HIP-source fallback)"
             elif not one_per_wg and cbest >= 1000:
                 kname = "downblock_kernel<96, 192> (direct 3x3/s2)"
             else:
@@ -274,7 +274,7 @@ def main() -> int:
             pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": f"conv3x3_pl_kernel / conv3x3_halo_kernel / conv_igemm_kernel / downblock_kernel (3x3 convs, kernel and tile shape autotuned per layer) on the {len(idx3)} 3x3 "
+                "kernel": f"conv3x3_pl_asm_nb13 (planar 3x3/s1, assembly build) / conv3x3_halo_kernel / conv_igemm_kernel / downblock_kernel (3x3 convs, kernel and tile shape autotuned per layer) on the {len(idx3)} 3x3 "
                           f"layers launched as plain convs ({len(idxb)} Bottlenecks run in bottleneck_kernel, reported separately)",
                 "launches_per_step": len(idx3), "avg_launch_ms": round(1e3 * t3 / len(idx3), 4),
                 "flops_per_step": f3, "steps_timed": calls,

@@ -117,3 +117,33 @@ def test_planar_kernel_hand_counted_memory_operations(planar_asm):
                 if not line.strip() or "global_load_dwordx" in line:
                     continue
                 assert not (_regs(line) & dest), f"{name}: '{line.strip()}' touches a register that '{l.strip()}' is still loading"
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# The generated assembly build of the planar kernel (csrc/gen_conv3x3_pl_asm.py): it must assemble for gfx950 with the ROCm clang, and
+# every family must fit the occupancy it is built for (registers per wave, LDS per workgroup) -- the generator asserts the same, this
+# checks what the assembler was actually told.
+def test_generated_planar_assembly_fits_its_occupancy(tmp_path):
+    import sys
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("ROCm clang not available")
+    src = tmp_path / "pl.s"
+    gen = os.path.join(ROOT, "aquaculture_amd", "csrc", "gen_conv3x3_pl_asm.py")
+    subprocess.run([sys.executable, gen, str(src)], check=True, capture_output=True)
+    subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src), "-o", str(tmp_path / "pl.o")],
+                   check=True, capture_output=True)
+    text = src.read_text()
+    kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S)
+    names = [k for k, _ in kernels]
+    for want in ("conv3x3_pl_asm_nb13_res0", "conv3x3_pl_asm_nb13_res1", "conv3x3_pl_asm_nb7_res1", "conv3x3_pl_asm_nb8_res0", "conv3x3_pl_asm_nb13_res1_w8"):
+        assert want in names
+    for name, body in kernels:
+        regs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1))
+        sgpr = int(re.search(r"\.amdhsa_next_free_sgpr (\d+)", body).group(1))
+        occ = 1 if "_nb13_" in name else 2
+        assert regs <= 512 // occ and lds * occ <= 160 * 1024 and sgpr <= 102, (name, regs, lds, sgpr)
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) == 0      # no scratch: every memory operation is counted by hand
+    # every hand-counted wait fits the 6-bit vmcnt field, and no kernel relies on a compiler: there is none
+    assert all(int(n) <= 63 for n in re.findall(r"s_waitcnt vmcnt\((\d+)\)", text))
