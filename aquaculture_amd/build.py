@@ -28,6 +28,7 @@ SOURCES = [
     ("conv3x3_pl.hip", []),
     ("pointwise.hip", []),
     ("detect_nms.hip", ["-ffp-contract=off"]),   # bit-level parity with the oracle's fp32 op order
+    ("head_decode.hip", ["-ffp-contract=off"]),  # the same decode arithmetic, fused behind the Detect head convs
     ("engine.cpp", ["-x", "hip"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

@@ -31,12 +31,15 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr size_t kAlign = 256;
 constexpr int kCoutSlack = 256;   // packed weight rows beyond cout so any BM tile may over-read zeros
 
+constexpr int kCountStride = 1024;   // ints between the per-image candidate counters of the fused head kernels (4 KB)
+
 struct PackedW {
     void* w = nullptr;      // [cout_rows][kgroups_pad] x 16 B
     float* bias = nullptr;  // [cout_rows]
     int kgroups = 0, kgroups_pad = 0, G = 0, cout_rows = 0;
     void* w_direct = nullptr;   // layers a direct kernel supports: its A-fragment image (csrc/conv1x1_direct.hip, csrc/downblock.hip)
     int direct_cfg = -1;        // AQ_CONV_CFG_DIRECT1X1 / AQ_CONV_CFG_DIRECT3X3S2 / AQ_CONV_CFG_PL3X3
+    void* w_head = nullptr;     // bf16 engines, Detect head convs with a small head: aq_pack_head_weights image (csrc/head_decode.hip)
     void* w_pl8 = nullptr;      // AQ_BF16_W8 engines, planar 3x3 layers: the e4m3 code stream and its float[2048] bias x 2^-e | 2^e
     float* sb_pl8 = nullptr;
 };
@@ -81,7 +84,7 @@ struct aq_engine {
     // workspace layout of the last sizing / call
     int lay_B = 0, lay_H = 0, lay_W = 0;
     std::vector<TensorPlace> place;
-    size_t off_pred = 0, off_cand = 0, off_cand_rows = 0, off_cand_count = 0, off_nms = 0, total_bytes = 0;
+    size_t off_pred = 0, off_cand = 0, off_cand_rows = 0, off_cand_count = 0, off_cand_wide = 0, off_nms = 0, total_bytes = 0;
     int N = 0;
     void* last_ws = nullptr;
     const uint8_t* last_tiles = nullptr;
@@ -121,6 +124,7 @@ int layout(aq_engine* e, int B, int H, int W) {
     e->off_cand = off; off += align_up((size_t)B * N * sizeof(int32_t), kAlign);
     e->off_cand_rows = off; off += align_up((size_t)B * N * (e->desc.nc + 5) * sizeof(float), kAlign);
     e->off_cand_count = off; off += align_up((size_t)B * sizeof(int32_t), kAlign);
+    e->off_cand_wide = off; off += align_up((size_t)B * kCountStride * sizeof(int32_t), kAlign);   // fused heads: counters 4 KB apart
     e->off_nms = off; off += align_up(aq_nms_scratch_bytes(B, N), kAlign);
     e->total_bytes = off;
     e->lay_B = B; e->lay_H = H; e->lay_W = W;
@@ -210,6 +214,15 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
     int32_t* cand = (int32_t*)((char*)ws + e->off_cand);
     int32_t* cand_count = (int32_t*)((char*)ws + e->off_cand_count);
     float* cand_rows = (float*)((char*)ws + e->off_cand_rows);
+    // the NMS path of a bf16 engine whose three head convs all have a fused form skips the fp32 head maps
+    bool fuse_heads = dets != nullptr, heads_started = false;
+    int n_heads = 0, heads_done = 0;
+    for (int oi = 0; oi < n_ops; ++oi)
+        if (e->ops[oi].kind == AQ_OP_CONV && e->ops[oi].level >= 0) {
+            ++n_heads;
+            if (!e->packed[oi].w_head) fuse_heads = false;
+        }
+    if (n_heads != 3) fuse_heads = false;
     for (int oi = 0; oi < n_ops; ++oi) {
         const aq_op_desc& op = e->ops[oi];
         if (ev) AQ_CHECK_HIP(hipEventRecord(ev[oi], stream));
@@ -218,6 +231,27 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
             rc = aq_preprocess_s2d(tiles, tptr(e, ws, tiles, op.dst.tensor), B, H, W, prec, stream);
             break;
         case AQ_OP_CONV:
+            if (fuse_heads && op.level >= 0) {
+                // Detect level fused with its decode (csrc/head_decode.hip): candidates go straight to the compact list NMS reads
+                int32_t* wide = (int32_t*)((char*)ws + e->off_cand_wide);
+                if (!heads_started) {
+                    AQ_CHECK_HIP(hipMemsetAsync(wide, 0, sizeof(int32_t) * B * kCountStride, stream));
+                    heads_started = true;
+                }
+                const TensorPlace& pl = e->place[op.src.tensor];
+                int off = 0;
+                for (int l = 0; l < op.level; ++l) off += e->desc.na * (H / (int)e->desc.stride[l]) * (W / (int)e->desc.stride[l]);
+                float anchors[8 * 2];
+                for (int a = 0; a < e->desc.na; ++a) {
+                    anchors[2 * a] = e->desc.anchors_px[op.level][a][0];
+                    anchors[2 * a + 1] = e->desc.anchors_px[op.level][a][1];
+                }
+                rc = aq_head_decode(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off, op.src.channels,
+                                    e->packed[oi].w_head, B, pl.h, pl.w, off, e->desc.stride[op.level], anchors, e->desc.nc, e->desc.na, conf,
+                                    cand, cand_rows, wide, kCountStride, e->N, stream);
+                if (!rc && ++heads_done == 3) rc = aq_head_counts_gather(wide, kCountStride, cand_count, B, stream);
+                break;
+            }
             rc = run_conv(e, oi, ws, tiles, B, stream);
             break;
         case AQ_OP_STEM:
@@ -252,6 +286,7 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
             break;
         }
         case AQ_OP_DECODE: {
+            if (fuse_heads) break;                       // done level by level behind the head convs
             const float* heads[3];
             for (int l = 0; l < 3; ++l) heads[l] = (const float*)tptr(e, ws, tiles, e->desc.head_tensor[l]);
             float anchors[3 * 8 * 2];
@@ -508,6 +543,17 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
                 }
             }
         }
+        const char* no_hf = getenv("AQ_DISABLE_HEAD_FUSION");   // A/B switch: Detect heads as conv + aq_detect_decode even in `infer`
+        if (d->precision == AQ_BF16 && op.level >= 0 && op.k == 1 && op.stride == 1 && !op.act && op.res.tensor < 0 &&
+            op.dst.channels >= d->na * (d->nc + 5) && op.dst.channels <= 32 && aq_head_decode_supported(op.src.channels, d->na, d->nc) && !(no_hf && *no_hf == '1')) {
+            size_t nb = 0;
+            if (aq_pack_head_weights(op.weight, op.bias, op.src.channels, op.dst.channels, nullptr, &nb, nullptr) != AQ_OK ||
+                hipMalloc(&pw.w_head, nb) != hipSuccess ||
+                aq_pack_head_weights(op.weight, op.bias, op.src.channels, op.dst.channels, pw.w_head, &nb, nullptr) != AQ_OK) {
+                aq_set_error("engine_create: fused head weight upload failed (op %zu)", oi);
+                return fail(AQ_ERR_HIP);
+            }
+        }
         op.weight = nullptr; op.bias = nullptr;   // host pointers are not kept
     }
     *out = e;
@@ -519,6 +565,7 @@ extern "C" void aq_engine_destroy(aq_engine* e) {
     for (PackedW& pw : e->packed) {
         if (pw.w) (void)hipFree(pw.w);
         if (pw.w_direct) (void)hipFree(pw.w_direct);
+        if (pw.w_head) (void)hipFree(pw.w_head);
         if (pw.w_pl8) (void)hipFree(pw.w_pl8);
         if (pw.sb_pl8) (void)hipFree(pw.sb_pl8);
         if (pw.bias) (void)hipFree(pw.bias);

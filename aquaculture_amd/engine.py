@@ -69,7 +69,7 @@ EXPORTS = (
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
     "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
     "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct",
-    "aq_conv3x3_pl_supported", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_preprocess_s2d", "aq_sppf_pool",
+    "aq_conv3x3_pl_supported", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_letterbox_tiles_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
 
@@ -658,3 +658,33 @@ def conv3x3s2_direct_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Ten
                                    _stream_ptr()))
     torch.cuda.current_stream().synchronize()
     return out
+
+
+def head_decode_level(x: torch.Tensor, w_oi: torch.Tensor, bias: torch.Tensor, cand_off: int, stride: float, anchors_px, nc: int,
+                      conf_thres: float, cap: int):
+    """One Detect level through aq_head_decode (tests): x bf16 NHWC [B, ny, nx, cin] (may be a channel slice), w [na * (nc + 5), cin].
+    Returns (counts [B] int32, cand [B, cap] int32, rows [B, cap, nc + 5] float32); the order within an image is unspecified."""
+    _require_gpu()
+    lib = load_library()
+    assert x.dtype == torch.bfloat16 and x.stride(3) == 1
+    B, ny, nx, cin = x.shape
+    ld = x.stride(2)
+    assert x.stride(1) == nx * ld and x.stride(0) == ny * nx * ld
+    na = len(anchors_px)
+    cout = na * (nc + 5)
+    w = np.ascontiguousarray(w_oi.float().cpu().numpy().reshape(cout, cin))
+    bh = np.ascontiguousarray(bias.float().cpu().numpy())
+    n = C.c_size_t()
+    fp = C.POINTER(C.c_float)
+    _check(lib.aq_pack_head_weights(w.ctypes.data_as(fp), bh.ctypes.data_as(fp), cin, cout, None, C.byref(n), None))
+    wbuf = torch.empty(n.value, dtype=torch.uint8, device=x.device)
+    _check(lib.aq_pack_head_weights(w.ctypes.data_as(fp), bh.ctypes.data_as(fp), cin, cout, C.c_void_p(wbuf.data_ptr()), C.byref(n), C.c_void_p(_stream_ptr())))
+    counts = torch.zeros(B, dtype=torch.int32, device=x.device)
+    cand = torch.full((B, cap), -1, dtype=torch.int32, device=x.device)
+    rows = torch.zeros((B, cap, nc + 5), dtype=torch.float32, device=x.device)
+    anch = np.ascontiguousarray(np.asarray(anchors_px, np.float32).reshape(-1))
+    _check(lib.aq_head_decode(C.c_void_p(x.data_ptr()), ld, 0, cin, C.c_void_p(wbuf.data_ptr()), B, ny, nx, cand_off, C.c_float(stride),
+                              anch.ctypes.data_as(fp), nc, na, C.c_float(conf_thres), C.c_void_p(cand.data_ptr()), C.c_void_p(rows.data_ptr()),
+                              C.c_void_p(counts.data_ptr()), 1, cap, C.c_void_p(_stream_ptr())))
+    torch.cuda.current_stream().synchronize()
+    return counts, cand, rows

@@ -239,6 +239,19 @@ int aq_sppf_pool(void* buf_dev, int ld, int ch_off, int c, int B, int H, int W, 
 /* nearest 2x upsample of a channel slice into a channel slice. */
 int aq_upsample2x(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff,
                   int c, int B, int H, int W, int precision, void* stream);
+/* One Detect level fused with its decode (bf16, small heads: na * (nc + 5) <= 32, cin a multiple of 32 up to 1024): the 1x1 head conv,
+ * sigmoid(objectness) > conf_thres, box decode and the append to the image's compact candidate list, with the arithmetic of
+ * aq_detect_decode; the fp32 head maps are never written.  The caller zeroes the counters before the first level.
+ * [UPSTREAM models/yolo.py Detect.forward + utils/general.py non_max_suppression's candidate filter] */
+int aq_head_decode_supported(int cin, int na, int nc);
+int aq_pack_head_weights(const float* w_host, const float* bias_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream);
+int aq_head_decode(const void* in_dev, int in_ld, int in_choff, int cin, const void* packed_dev, int B, int ny, int nx,
+                   int cand_off, float stride, const float* anchors_px, int nc, int na, float conf_thres,
+                   int32_t* cand_dev, float* cand_rows_dev, int32_t* cand_count_dev, int count_stride, int cand_cap, void* stream);
+/* image b's candidate counter lives at cand_count_dev[b * count_stride] (the engine spaces them 4 KB apart: adjacent counters share an L2
+ * channel and its atomic unit); this copies them into the compact [B] array aq_nms reads. */
+int aq_head_counts_gather(const int32_t* wide_dev, int count_stride, int32_t* compact_dev, int B, void* stream);
+
 /* Detect.forward inference branch on raw fp32 head maps [B][ny][nx][head_ld] (channel = a*no + o):
  * writes pred [B][N][no] when pred_dev != NULL; when cand_dev != NULL also compacts the candidates with
  * obj > conf_thres: their candidate indices into cand_dev[B][cand_cap], their decoded rows into

@@ -106,9 +106,12 @@ def test_max_nms_cap_30000(lib):
     assert r.shape[0] == 30000
 
 
-def test_engine_decode_plus_nms_equals_nms_on_raw_pred(lib, synth_ck):
-    """The fused path (compact candidate rows) and S1 -> S2 through the full pred tensor agree bit for bit."""
+def test_engine_decode_plus_nms_equals_nms_on_raw_pred(lib, synth_ck, monkeypatch):
+    """The compact-candidate path (decode writes only rows with obj > conf_thres) and S1 -> S2 through the full pred tensor agree bit for
+    bit.  (With the Detect heads fused with their decode -- csrc/head_decode.hip, the default of `infer` -- the head convs sum K in a
+    different order, so that comparison is one of tolerances: tests/test_gpu_head_decode.py.)"""
     from aquaculture_amd import engine, tiles
+    monkeypatch.setenv("AQ_DISABLE_HEAD_FUSION", "1")
     eng = engine.Engine(synth_ck, "bf16")
     t = torch.from_numpy(tiles.synthetic_batch([3, 4], 640)).cuda()
     d0, c0 = eng.infer(t)
