@@ -35,6 +35,11 @@ struct DownParams {
     int B, H, W, Ho, Wo;     // input / output spatial size (Ho = H / 2)
     int tiles_x, tiles_y, n_tiles;
     int act;                 // plain 3x3/s2 form only (the fused form always applies SiLU twice)
+    // stem-fused form (STEM): the input patch is COMPUTED from the uint8 tile instead of loaded
+    const uint8_t* tiles;    // [B][Hi][Wi][3]
+    const char* stem_w;      // aq_pack_stem_weights image (bf16): A fragments [k-step 0..4][M block 0..2][lane]
+    const float* stem_b;     // [64]: stem bias, zero padded
+    int Hi, Wi;              // tile size in pixels (H = Hi / 2, W = Wi / 2 are the stem's output size)
 };
 
 constexpr int kNW = 12;                                  // waves per workgroup (3 per SIMD)
@@ -43,7 +48,9 @@ constexpr int kTW = 16;                                  // output tile width; e
 // CIN -> CMID by the 3x3/s2; FUSE: followed by a 1x1 CMID -> CMID; KT: last k-steps of the 3x3 weights kept in LDS.
 //   <48, 96, true, 0>:   yolov5m model.1 + model.2.cv1|cv2   (6 M blocks x 2 pixel groups, 8 x 16 tile)
 //   <96, 192, false, 3>: yolov5m model.3                     (12 M blocks x 1 pixel group, 4 x 16 tile)
-template <int CIN, int CMID, bool FUSE, int KT> struct DownGeom {
+// STEM (with <48, 96, true, 0> only): model.0 in front -- uint8 tile -> / 255 -> Conv(3, 48, 6, 2, 2) + SiLU is evaluated for every pixel of the
+// 17 x 33 patch (the halo is recomputed, 561 / 512 = 1.10 x), so the 629 MB stem output of a 64-tile batch is never written or read.
+template <int CIN, int CMID, bool FUSE, int KT, bool STEM = false> struct DownGeom {
     static constexpr int MB = CMID / 16;                     // M blocks = wave groups along M
     static constexpr int PG = kNW / MB;                      // pixel groups
     static constexpr int TH = 4 * PG;
@@ -64,11 +71,24 @@ template <int CIN, int CMID, bool FUSE, int KT> struct DownGeom {
     static constexpr int SPPT = CMID / 8 + 2, TPXB = SPPT * 16;   // t tile (FUSE): channel slots + 2 pad (conflict-free stride-1 reads)
     static constexpr int TPB = FUSE ? TH * kTW * TPXB : 0;
     static constexpr int NBIAS = FUSE ? 2 * CMID : CMID;
-    static constexpr int LDS = 2 * XPB + TPB + WTB + NBIAS * 4;
+    // STEM: raw patch = image rows 2 iy0 - 2 .. + 2 PH + 1 (6 x 6 / stride 2 / pad 2 window of PH stem rows), bytes 6 ix0 - 6 .. of each
+    // (RGB interleaved; a pixel's 18 values of one ky are consecutive, the K padding to 24 reads on into its neighbour against zero weights)
+    static constexpr int RAWROWS = 2 * PH + 4;
+    static constexpr int RAWDW = (6 * (PW - 1) + 24) / 4;    // dwords (= 4 bytes = 4 patch elements) per raw row
+    static constexpr int RAWPROWB = RAWDW * 8 + 16;          // bf16 patch row stride
+    static constexpr int RAWB = STEM ? RAWROWS * RAWPROWB : 0;
+    static constexpr int NRAW = RAWROWS * RAWDW;
+    static constexpr int NITR = (NRAW + kNW * 64 - 1) / (kNW * 64);
+    static constexpr int STAGEB = STEM ? NITR * kNW * 64 * 4 : 0;
+    static constexpr int WSTEMB = STEM ? 5 * 3 * 1024 : 0;
+    static constexpr int NBIAS_ALL = NBIAS + (STEM ? 64 : 0);
+    static constexpr int LDS = (STEM ? 1 : 2) * XPB + RAWB + STAGEB + TPB + WTB + WSTEMB + NBIAS_ALL * 4;
+    static_assert(!STEM || (CIN == 48 && FUSE && RAWB % 16 == 0), "the stem-fused form is yolov5m's first block");
     static constexpr int WFRAGS = KSA + KSB;                 // A fragments per M block
     static_assert(kNW % MB == 0 && LDS <= 160 * 1024, "shape");
     static_assert(KT == 0 || UNIFORM_K, "the LDS tail is only wired into the uniform-K loop");
 };
+
 
 __device__ __forceinline__ f32x4 down_silu4(f32x4 v) {   // same sequence as the shared conv epilogue (bf16 mode)
     const f32x4 t = v * -1.44269504f;
@@ -87,14 +107,17 @@ __device__ __forceinline__ void down_lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int CIN, int CMID, bool FUSE, int KT>
+template <int CIN, int CMID, bool FUSE, int KT, bool STEM = false>
 __global__ __launch_bounds__(kNW * 64) void downblock_kernel(const DownParams p) {
-    using G = DownGeom<CIN, CMID, FUSE, KT>;
+    using G = DownGeom<CIN, CMID, FUSE, KT, STEM>;
     constexpr int PW = G::PW, PXB = G::PXB, KSA = G::KSA, KSB = G::KSB, KREG = G::KREG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_t = smem + 2 * G::XPB;
+    char* s_raw = smem + (STEM ? 1 : 2) * G::XPB;            // STEM: the x patch has ONE buffer (it is computed, not loaded ahead)
+    char* s_stage = s_raw + G::RAWB;
+    char* s_t = s_stage + G::STAGEB;
     char* s_wt = s_t + G::TPB;
-    float* s_b = (float*)(s_wt + G::WTB);
+    char* s_ws = s_wt + G::WTB;
+    float* s_b = (float*)(s_ws + G::WSTEMB);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,6 +140,10 @@ __global__ __launch_bounds__(kNW * 64) void downblock_kernel(const DownParams p)
         for (int s = 0; s < KSB; ++s) wb[s] = wsrc[(KSA + s) * 64];
     }
     for (int i = tid; i < G::NBIAS; i += kNW * 64) s_b[i] = p.bias[i];
+    if constexpr (STEM) {
+        for (int i = tid; i < 64; i += kNW * 64) s_b[G::NBIAS + i] = p.stem_b[i];
+        for (int i = tid; i < G::WSTEMB / 16; i += kNW * 64) ((bf16x8*)s_ws)[i] = ((const bf16x8*)p.stem_w)[i];
+    }
     // per-lane byte offset of this lane's K block relative to the tap-(0,0) pixel of an output pixel's 3x3 window
     int koffa[G::UNIFORM_K ? 1 : KSA];
     if constexpr (G::UNIFORM_K) koffa[0] = g * 16;
@@ -150,13 +177,52 @@ __global__ __launch_bounds__(kNW * 64) void downblock_kernel(const DownParams p)
         const char* src = o.org + (pr * W + pc) * p.in_ld_b + part * 16;
         glds16(valid ? src : p.zero, xb + q * 1024);
     };
+    // STEM: the raw uint8 dwords of a tile's patch travel by LDS-DMA into a lane-linear staging area (slot i = tid + 768 it), are
+    // converted to bf16 activations (v * (1 / 255), RNE: the stem kernel's arithmetic) by the lanes that loaded them, and stage 0 below
+    // turns them into the x patch.
+    auto dma_raw = [&](int tile) {
+        const int b = tile / tiles_per_img, tr = tile - b * tiles_per_img;
+        const int ty0 = tr / p.tiles_x, tx0 = tr - ty0 * p.tiles_x;
+        const int iy0 = 2 * ty0 * G::TH - 1, ix0 = 2 * tx0 * kTW - 1;
+        const uint8_t* img = p.tiles + (size_t)b * p.Hi * p.Wi * 3;
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));                      // opaque: no per-slot row / column decode hoisted out of the tile loop
+#pragma unroll
+        for (int it = 0; it < G::NITR; ++it) {
+            const int i = tid_o + it * (kNW * 64);
+            const int r = i / G::RAWDW, d = i - r * G::RAWDW;
+            const int iy = 2 * iy0 - 2 + r, byte0 = 6 * ix0 - 6 + 4 * d;
+            const bool ok = tile < p.n_tiles && i < G::NRAW && (unsigned)iy < (unsigned)p.Hi && byte0 >= 0 && byte0 < p.Wi * 3;
+            const char* src = ok ? (const char*)img + (size_t)iy * p.Wi * 3 + byte0 : p.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(s_stage + (it * (kNW * 64) + wave * 64) * 4), 4, 0, 0);
+        }
+    };
+    auto convert_stage = [&]() {
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));                      // opaque: no per-slot row / column decode hoisted out of the tile loop
+#pragma unroll
+        for (int it = 0; it < G::NITR; ++it) {
+            const int i = tid_o + it * (kNW * 64);
+            const int r = i / G::RAWDW, d = i - r * G::RAWDW;
+            if (i < G::NRAW) {
+                const uint32_t v = *(const uint32_t*)(s_stage + i * 4);
+                constexpr float k = 1.0f / 255.0f;
+                const float f0 = (float)(v & 255u) * k, f1 = (float)((v >> 8) & 255u) * k, f2 = (float)((v >> 16) & 255u) * k,
+                            f3 = (float)(v >> 24) * k;
+                down_lds_write_b64(s_raw + r * G::RAWPROWB + d * 8, make_uint2(pack_bf16x2(f0, f1), pack_bf16x2(f2, f3)));
+            }
+        }
+    };
     constexpr int NQW = (G::NQ + kNW - 1) / kNW;             // DMA instructions per wave and tile
     constexpr int NSTEP = G::UNIFORM_K ? 3 * G::CQ * 9 : KSA;    // MFMA-loop steps that can carry one each
     constexpr int SP = NSTEP / NQW;
     static_assert(SP >= 1 && NQW * SP <= NSTEP, "not enough MFMA-loop steps to carry the DMA issue");
 
     int tile = first_tile(gridDim.x, blockIdx.x);
-    if (tile < p.n_tiles) {
+    if constexpr (STEM) {
+        dma_raw(tile);
+    } else if (tile < p.n_tiles) {
         const PatchOrg o = patch_org(tile);
 #pragma unroll 1
         for (int q = wave; q < G::NQ; q += kNW) dma_one(o, q, smem);
@@ -167,10 +233,59 @@ __global__ __launch_bounds__(kNW * 64) void downblock_kernel(const DownParams p)
         const int b = tile / tiles_per_img, tr = tile - b * tiles_per_img;
         const int ty0 = tr / p.tiles_x, tx0 = tr - ty0 * p.tiles_x;
         const int y0 = ty0 * G::TH, x0 = tx0 * kTW;
-        const char* s_x = smem + cur * G::XPB;
+        const char* s_x = smem + (STEM ? 0 : cur) * G::XPB;
         // this tile's patch has landed (own DMA: vmcnt; the other waves': barrier).  vmcnt is in-order: after a full tile the
         // youngest DMA instruction is older than that tile's 4 output stores, which may stay in flight.
         if (prev_full) wait_vmcnt<4>(); else wait_vmcnt<0>();
+        if constexpr (STEM) {
+            // ---- 0. the x patch = SiLU(stem(raw patch)), zero outside the stem's output image (the 3x3 pads x, not the tile) ----
+            convert_stage();                                 // own slots only: no barrier between the DMA and here
+            down_lds_barrier();                              // raw patch complete; everyone is done with the previous tile's x and t
+            dma_raw(tile + (int)gridDim.x);                  // the staging area is free again (zeros past the last tile)
+            const int iy0 = 2 * y0 - 1, ix0 = 2 * x0 - 1;
+            int g_o = g;
+            asm volatile("" : "+v"(g_o));                    // opaque: the K offsets are rebuilt per tile instead of living in 5 registers
+            int koffs[5];                                    // per-lane byte offset of K block 4 s + g inside the raw patch
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const int blk = 4 * s + g_o;
+                const int ky = blk / 3 < 6 ? blk / 3 : 5;    // K blocks 18, 19 carry zero weights: read any valid row (csrc/stem_conv.hip)
+                koffs[s] = ky * G::RAWPROWB + (blk - 3 * (blk / 3)) * 16;
+            }
+            // a wave takes every 12th block of 16 patch pixels and ALL three M blocks of it: the B fragment (twenty 4-byte LDS reads --
+            // a pixel's values start on a 12-byte grid) is read once, not once per M block; the stem's A fragments stay in LDS
+            const char* wsl = s_ws + lane * 16;
+#pragma unroll 1
+            for (int blk = wave; blk < (G::PP + 15) / 16; blk += kNW) {
+                const int L = blk * 16 + l15;
+                const int Lc = L < G::PP ? L : G::PP - 1;
+                const int pr = Lc / PW, pc = Lc - pr * PW;
+                const char* base = s_raw + (2 * pr) * G::RAWPROWB + (6 * pc) * 2;
+                bf16x8 bf[5];
+#pragma unroll
+                for (int s = 0; s < 5; ++s) {
+                    const uint32_t* src = (const uint32_t*)(base + koffs[s]);        // 4-byte aligned
+                    const uint4 u = make_uint4(src[0], src[1], src[2], src[3]);
+                    __builtin_memcpy(&bf[s], &u, 16);
+                }
+                f32x4 a0[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) a0[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 5; ++s)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+                        a0[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(wsl + (s * 3 + m) * 1024), bf[s], a0[m], 0, 0, 0);
+                const bool inside = (unsigned)(iy0 + pr) < (unsigned)H && (unsigned)(ix0 + pc) < (unsigned)W;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {                // lane = (patch pixel L, stem channels 12 g + 4 m .. + 3)
+                    f32x4 v = down_silu4(a0[m] + *(const f32x4*)(s_b + G::NBIAS + 12 * g + 4 * m));
+                    if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (L < G::PP)
+                        down_lds_write_b64((char*)s_x + Lc * PXB + (12 * g + 4 * m) * 2, make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])));
+                }
+            }
+        }
         down_lds_barrier();
         const bool has_next = tile + (int)gridDim.x < p.n_tiles;
         prev_full = y0 + G::TH <= Ho && x0 + kTW <= Wo;
@@ -210,7 +325,7 @@ __global__ __launch_bounds__(kNW * 64) void downblock_kernel(const DownParams p)
                         if (r2 >= 9) { r2 -= 9; if (++cq2 == CQ) { cq2 = 0; ++dx2; } }
                         bf16x8 f2 = f0;
                         if (dx2 < 3) f2 = frag(dx2, cq2, r2);
-                        if (step % SP == 0 && step / SP < NQW) {
+                        if (!STEM && step % SP == 0 && step / SP < NQW) {
                             const int q = wave + kNW * (step / SP);
                             if (has_next && q < G::NQ) dma_one(on, q, xbn);
                         }
@@ -238,7 +353,7 @@ __global__ __launch_bounds__(kNW * 64) void downblock_kernel(const DownParams p)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fn[j] = *(const bf16x8*)(base + (2 * j * PW) * PXB + koffa[s + 1 < KSA ? s + 1 : 0]);
                 }
-                if (s % SP == 0 && s / SP < NQW) {           // one DMA instruction of the next tile's patch
+                if (!STEM && s % SP == 0 && s / SP < NQW) {  // one DMA instruction of the next tile's patch
                     const int q = wave + kNW * (s / SP);
                     if (has_next && q < G::NQ) dma_one(on, q, xbn);
                 }
@@ -312,11 +427,11 @@ int down_common(DownParams& p, const void* in_dev, int in_ld, int in_choff, int 
     return AQ_OK;
 }
 
-template <int CIN, int CMID, bool FUSE, int KT>
+template <int CIN, int CMID, bool FUSE, int KT, bool STEM = false>
 int launch_down(const DownParams& p, hipStream_t stream) {
-    using G = DownGeom<CIN, CMID, FUSE, KT>;
+    using G = DownGeom<CIN, CMID, FUSE, KT, STEM>;
     static bool attr = false;
-    auto fn = downblock_kernel<CIN, CMID, FUSE, KT>;
+    auto fn = downblock_kernel<CIN, CMID, FUSE, KT, STEM>;
     if (!attr) {
         AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         attr = true;
@@ -376,6 +491,24 @@ extern "C" int aq_downblock(const void* in_dev, int in_ld, int in_choff, void* o
     const int rc = down_common(p, in_dev, in_ld, in_choff, 48, out_dev, out_ld, out_choff, 96, packed_w_dev, bias_dev, B, H, W, DownGeom<48, 96, true, 0>::TH);
     if (rc) return rc;
     return launch_down<48, 96, true, 0>(p, (hipStream_t)stream);
+}
+
+// model.0 + model.1 + model.2.cv1|cv2 in one launch (yolov5m, bf16): tiles uint8 [B][Hi][Wi][3] -> [B][Hi/4][Wi/4][out_ld] with the 96
+// channels at out_choff.  stem_w / stem_bias: aq_pack_stem_weights' bf16 image of Conv(3, 48, 6, 2, 2) and its bias padded to 64 floats
+// (exactly what aq_stem_conv takes); packed_w / bias: aq_downblock's.  Bit-identical to aq_stem_conv followed by aq_downblock.
+extern "C" int aq_stemdown_supported(int Hi, int Wi) { return Hi > 0 && Wi > 0 && Hi % 4 == 0 && Wi % 4 == 0; }
+
+extern "C" int aq_stemdown(const uint8_t* tiles_dev, void* out_dev, int out_ld, int out_choff, const void* stem_w_dev, const float* stem_bias_dev,
+                           const void* packed_w_dev, const float* bias_dev, int B, int Hi, int Wi, void* stream) {
+    AQ_REQUIRE(tiles_dev && stem_w_dev && stem_bias_dev, "stemdown: null pointer");
+    AQ_REQUIRE(aq_stemdown_supported(Hi, Wi) && ((uintptr_t)tiles_dev & 3) == 0, "stemdown: tile size %dx%d must be a multiple of 4, tiles 4-byte aligned", Hi, Wi);
+    AQ_REQUIRE((long long)B * Hi * Wi * 3 < (1LL << 40), "stemdown: batch too large");
+    DownParams p{};
+    // `in` is unused by the stem-fused form; down_common only offsets it
+    const int rc = down_common(p, tiles_dev, 48, 0, 48, out_dev, out_ld, out_choff, 96, packed_w_dev, bias_dev, B, Hi / 2, Wi / 2, DownGeom<48, 96, true, 0, true>::TH);
+    if (rc) return rc;
+    p.tiles = tiles_dev; p.stem_w = (const char*)stem_w_dev; p.stem_b = stem_bias_dev; p.Hi = Hi; p.Wi = Wi;
+    return launch_down<48, 96, true, 0, true>(p, (hipStream_t)stream);
 }
 
 // Plain 3x3 / stride 2 / pad 1 convolution + bias (+ SiLU), 96 -> 192 channels (the autotuner's AQ_CONV_CFG_DIRECT3X3S2 candidate).

@@ -214,6 +214,15 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
     int32_t* cand = (int32_t*)((char*)ws + e->off_cand);
     int32_t* cand_count = (int32_t*)((char*)ws + e->off_cand_count);
     float* cand_rows = (float*)((char*)ws + e->off_cand_rows);
+    // model.0 + model.1 + model.2.cv1|cv2 as ONE launch (csrc/downblock.hip, STEM form; AQ_STEMDOWN=1).  Opt-in: it removes the stem
+    // output's 629 MB write and 613 MB read per 64-tile batch (10 % of the step's HBM traffic) and is bit-identical, but the stem's MFMAs,
+    // SiLU and LDS traffic then sit between the same barriers as the down-block's instead of overlapping another kernel's memory time:
+    // 480 us against 211 + 253, and 14.88 k vs 14.83 k tiles/s in bench.py (three runs each) -- a wash.  The stem's output tensor is not
+    // written in this mode (tensor taps read it).
+    const char* use_sd = getenv("AQ_STEMDOWN");
+    const bool stemdown = use_sd && *use_sd == '1' && prec == AQ_BF16 && n_ops > 2 && e->ops[0].kind == AQ_OP_STEM && e->ops[1].kind == AQ_OP_DOWNBLOCK &&
+                          e->ops[0].dst.channels == 48 && e->ops[1].src.tensor == e->ops[0].dst.tensor && e->ops[1].src.ch_off == e->ops[0].dst.ch_off &&
+                          aq_stemdown_supported(H, W) && ((uintptr_t)tiles & 3) == 0;
     // the NMS path of a bf16 engine whose three head convs all have a fused form skips the fp32 head maps
     bool fuse_heads = dets != nullptr, heads_started = false;
     int n_heads = 0, heads_done = 0;
@@ -255,6 +264,7 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
             rc = run_conv(e, oi, ws, tiles, B, stream);
             break;
         case AQ_OP_STEM:
+            if (stemdown) break;                         // computed inside the down-block launch below
             rc = aq_stem_conv(tiles, tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
                               op.dst.channels, e->packed[oi].w, e->packed[oi].bias, B, H, W, op.act, prec, stream);
             break;
@@ -267,6 +277,11 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
         }
         case AQ_OP_DOWNBLOCK: {
             const TensorPlace& pl = e->place[op.src.tensor];
+            if (stemdown && oi == 1) {
+                rc = aq_stemdown(tiles, tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
+                                 e->packed[0].w, e->packed[0].bias, e->packed[oi].w, e->packed[oi].bias, B, H, W, stream);
+                break;
+            }
             rc = aq_downblock(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
                               tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
                               e->packed[oi].w, e->packed[oi].bias, B, pl.h, pl.w, stream);

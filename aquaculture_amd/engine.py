@@ -67,7 +67,7 @@ EXPORTS = (
     "aq_engine_infer", "aq_engine_forward_raw", "aq_engine_tensor_ptr", "aq_engine_profile",
     "aq_engine_op_times", "aq_engine_num_ops", "aq_engine_set_conv_config", "aq_engine_autotune", "aq_engine_set_tuned_table",
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
-    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
+    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_stemdown_supported", "aq_stemdown", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
     "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct",
     "aq_conv3x3_pl_supported", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_letterbox_tiles_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
@@ -688,3 +688,34 @@ def head_decode_level(x: torch.Tensor, w_oi: torch.Tensor, bias: torch.Tensor, c
                               C.c_void_p(counts.data_ptr()), 1, cap, C.c_void_p(_stream_ptr())))
     torch.cuda.current_stream().synchronize()
     return counts, cand, rows
+
+
+def stemdown_nhwc(tiles_u8: torch.Tensor, ws_oihw: torch.Tensor, bs: torch.Tensor, wa_oihw: torch.Tensor, ba: torch.Tensor,
+                  wb_oihw: torch.Tensor, bb: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uint8 [B,Hi,Wi,3] -> stem (6x6/s2, 3 -> 48) -> 3x3/s2 (48 -> 96) -> 1x1 (96 -> 96), SiLU after each, as bf16 NHWC
+    [B,Hi/4,Wi/4,96] through aq_stemdown (tests): one launch, the stem's output never leaves the CU."""
+    _require_gpu()
+    lib = load_library()
+    B, Hi, Wi, _ = tiles_u8.shape
+    assert tiles_u8.dtype == torch.uint8 and tiles_u8.is_contiguous() and ws_oihw.shape[0] == 48
+    dev = tiles_u8.device
+    fp = C.POINTER(C.c_float)
+    ws = np.ascontiguousarray(ws_oihw.permute(0, 2, 3, 1).float().cpu().numpy())
+    n = C.c_size_t()
+    _check(lib.aq_pack_stem_weights(ws.ctypes.data_as(fp), 48, AQ_BF16, None, C.byref(n), None))
+    wsbuf = torch.empty(n.value, dtype=torch.uint8, device=dev)
+    _check(lib.aq_pack_stem_weights(ws.ctypes.data_as(fp), 48, AQ_BF16, wsbuf.data_ptr(), C.byref(n), _stream_ptr()))
+    bsbuf = torch.zeros(64, dtype=torch.float32, device=dev)
+    bsbuf[:48] = bs.float().to(dev)
+    wa = np.ascontiguousarray(wa_oihw.permute(0, 2, 3, 1).float().cpu().numpy())
+    wb = np.ascontiguousarray(wb_oihw.permute(0, 2, 3, 1).float().cpu().numpy())
+    _check(lib.aq_pack_downblock_weights(wa.ctypes.data_as(fp), wb.ctypes.data_as(fp), None, C.byref(n), None))
+    wbuf = torch.empty(n.value, dtype=torch.uint8, device=dev)
+    _check(lib.aq_pack_downblock_weights(wa.ctypes.data_as(fp), wb.ctypes.data_as(fp), wbuf.data_ptr(), C.byref(n), _stream_ptr()))
+    bbuf = torch.cat([ba.float(), bb.float()]).to(dev).contiguous()
+    if out is None:
+        out = torch.empty((B, Hi // 4, Wi // 4, 96), dtype=torch.bfloat16, device=dev)
+    _check(lib.aq_stemdown(C.c_void_p(tiles_u8.data_ptr()), C.c_void_p(out.data_ptr()), out.stride(2), 0, C.c_void_p(wsbuf.data_ptr()),
+                           C.c_void_p(bsbuf.data_ptr()), C.c_void_p(wbuf.data_ptr()), C.c_void_p(bbuf.data_ptr()), B, Hi, Wi, C.c_void_p(_stream_ptr())))
+    torch.cuda.current_stream().synchronize()
+    return out

@@ -175,6 +175,13 @@ int aq_bottleneck(const void* in_dev, int in_ld, int in_choff, void* out_dev, in
 int aq_pack_downblock_weights(const float* wa_host, const float* wb_host, void* packed_dev, size_t* bytes, void* stream);
 int aq_downblock(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff,
                  const void* packed_w_dev, const float* bias_dev, int B, int H, int W, void* stream);
+/* The fused stem in front of it as well (yolov5m model.0 + model.1 + model.2.cv1|cv2 in ONE launch, bf16): the 17 x 33-pixel patch of
+ * stem outputs a down-block tile needs is computed from the uint8 tile inside the kernel, so the stem's output tensor (629 MB per
+ * 64-tile batch) is never written or read.  Takes exactly aq_stem_conv's and aq_downblock's weight images; bit-identical to the two
+ * launches.  Hi, Wi: tile size (multiples of 4). */
+int aq_stemdown_supported(int Hi, int Wi);
+int aq_stemdown(const uint8_t* tiles_dev, void* out_dev, int out_ld, int out_choff, const void* stem_w_dev, const float* stem_bias_dev,
+                const void* packed_w_dev, const float* bias_dev, int B, int Hi, int Wi, void* stream);
 
 /* Direct 1x1 convolution (bf16; Cin -> Cout in {96->96, 192->192, 384->192, 384->384}): no K pipeline, whole-K pixel tiles by LDS-DMA, weights
  * in registers.  Same operation as aq_conv2d with k = 1; the engine's autotuner times it per layer against the implicit-GEMM tile
