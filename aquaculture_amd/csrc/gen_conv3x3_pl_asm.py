@@ -29,14 +29,24 @@ import sys
 # registers fetched under the last chunk.  "nb7" / "nb8": TWO workgroups per CU (<= 256 registers per wave, <= 80 KB LDS), so that one
 # workgroup's chunk tops, epilogue and prologue run under the other's MFMAs; two ring buffers of 256 region rows, and the residual is
 # fetched at the start of the epilogue into registers the stream has finished with (weight set 2 and the B ring).
+# SPLIT = s > 0: a tile's LAST chunk has its own code: all 18 half-taps for pixel blocks 0 .. s - 1 first, then again for blocks s .. NB - 1
+# with the epilogue of the first group (accumulators final) issued between those MFMAs -- the epilogue is VALU-bound (v_exp + v_rcp at
+# quarter rate, 10 k cycles per tile) and one wave per SIMD has nothing else to overlap it with; this way it also pays for workgroups
+# that own a single tile, which a second accumulator set (epilogue under the NEXT tile) would not.  Costs: the last chunk's weights are
+# streamed twice, and its own copy of the stream code.
+# MEASURED (SPLIT = 7, parity-green on all ten geometries; stamped build, cycles per wave): 192 ch @ 40x40: epilogue 19.5 k -> 9.9 k but
+# stream 99.2 k -> 113.1 k, lifetime 140.1 k -> 143.9 k; 384 ch @ 20x20: epilogue 10.4 k -> 5.1 k, stream 93.0 k -> 99.2 k, lifetime
+# 117.2 k -> 118.0 k.  The instructions put between the MFMAs are not free: with one wave per SIMD the stream is bound by what the wave
+# can issue and by in-order waits, so every filler lengthens it by about its own issue time (the same reason the fp8 weight stream's
+# conversions lose).  Off; kept as a generator option because it is the measurement behind "the epilogue cannot be hidden here".
 # LOOK = how many taps ahead the weights are loaded (LOOK + 1 fragment sets of 24 registers).  Loads return in order, so every LDS-DMA or
 # residual load (HBM / MALL latency) holds back the weight loads issued behind it: with LOOK = 2 such a load has two taps (2.5 k cycles)
 # before it stalls the stream, and the stamped builds showed exactly that stall; the one-workgroup family keeps its FOUR sets in the
 # accumulator half of the register file (100 AGPRs are free there), which also frees 72 VGPRs for a deeper B ring.
 CONFIGS = {
-    13: dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False),
-    7: dict(NB=7, PD=8, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False),
-    8: dict(NB=8, PD=7, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False),
+    13: dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0),     # SPLIT=7: measured slower, below
+    7: dict(NB=7, PD=8, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False, SPLIT=0),
+    8: dict(NB=8, PD=7, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False, SPLIT=0),
 }
 STEP_B = 6 * 1024          # weight bytes per (wave, tap-step): six 1 KB bf16 fragments ...
 W8 = False                 # ... or, in the fp8-weight kernels (set per kernel by gen_kernel), three 1 KB pairs of e4m3 fragments
@@ -104,6 +114,7 @@ def allocate_registers():
     S.alloc("a_ld", 2, 2)         # base of the weight loads being issued
     S.alloc("dbase", 2, 2)        # LDS-DMA: input base of (chunk, plane)
     S.alloc("t64", 2, 2)
+    S.alloc("actm", 2, 2)         # all ones when the layer has an activation (in-stream epilogue blocks select instead of branching)
     S.alloc("st_acc", 12, 2)      # stamped build only: cycle sums of six phases
     S.alloc("st_last", 2, 2)
     S.alloc("st_rt0", 2, 2)
@@ -456,6 +467,8 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_mov_b32 {s('klog2e2', 1)}, 0xbfb8aa3b")
     E(f"s_mov_b32 {s('kone2')}, 1.0")
     E(f"s_mov_b32 {s('kone2', 1)}, 1.0")
+    E(f"s_cmp_lg_u32 {s('act')}, 0")
+    E(f"s_cselect_b64 {s2('actm')}, -1, 0")
     if stamped:
         for k in range(12):
             E(f"s_mov_b32 {s('st_acc', k)}, 0")
@@ -665,123 +678,354 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         label(l_pd)
     stamp(PH_TOP)
 
-    # first B fragments
-    def b_read(n):
-        h, j = divmod(n, NB)
-        t, ks = divmod(h, 2)
-        if ks == 0:
-            # advance this pixel block's address to tap t
-            if t == 0:
-                E(f"v_add_u32 {v('addr', j)}, {s('delta0')}, {v('addr', j)}")
-            elif t % 3 == 0:
-                E(f"v_add_u32 {v('addr', j)}, {s('dRow')}, {v('addr', j)}")
+    SPLIT_ON = bool(SPLIT) and not w8 and not abl
+    cold = []                             # out-of-line code: (label, immediate or instruction list, label to return to)
+    T7RES = RES and RES_EARLY
+
+    def epilogue_block(i, j, mode, lines):
+        """Appends the instructions of one 16 x 16 output block (M block i, pixel block j): accumulators -> (x scale) -> SiLU -> + residual ->
+        bf16 -> store.  mode: "act" / "noact" (the two copies behind a branch after the stream) or "select" (branch-free, for the copy
+        issued between MFMAs).  The store's EXEC mask is in t64 (per pixel block, set by the caller)."""
+        X = V.names["t"][0] + 0
+        Y = V.names["t"][0] + 4
+        Rr = V.names["t"][0] + 8
+        a0 = 4 * (3 * j + i)
+        r0 = rreg(3 * j + i) if RES else 0
+        L = lines.append
+        for e in range(4):
+            L(f"v_accvgpr_read_b32 v{X + e}, a{a0 + e}")
+
+        def unpack():
+            L(f"v_lshlrev_b32 v{Rr}, 16, v{r0}")
+            L(f"v_and_b32 v{Rr + 1}, 0xffff0000, v{r0}")
+            L(f"v_lshlrev_b32 v{Rr + 2}, 16, v{r0 + 1}")
+            L(f"v_and_b32 v{Rr + 3}, 0xffff0000, v{r0 + 1}")
+
+        if mode in ("act", "select"):
+            L(f"v_pk_mul_f32 v[{Y}:{Y + 1}], v[{X}:{X + 1}], {s2('klog2e2')}")
+            L(f"v_pk_mul_f32 v[{Y + 2}:{Y + 3}], v[{X + 2}:{X + 3}], {s2('klog2e2')}")
+            for e in range(4):
+                L(f"v_exp_f32 v{Y + e}, v{Y + e}")
+            L(f"v_pk_add_f32 v[{Y}:{Y + 1}], v[{Y}:{Y + 1}], {s2('kone2')}")
+            L(f"v_pk_add_f32 v[{Y + 2}:{Y + 3}], v[{Y + 2}:{Y + 3}], {s2('kone2')}")
+            for e in range(4):
+                L(f"v_rcp_f32 v{Y + e}, v{Y + e}")
+            if RES:                                       # independent work between the rcp and its consumer (hz: transcendental -> consumer)
+                unpack()
             else:
-                E(f"v_add_u32 {v('addr', j)}, 16, {v('addr', j)}")
-        if not abl & 4:
-            E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)}" + (f" offset:{4 * PS}" if ks else ""))
+                L("s_nop 0")
+            if mode == "select":                          # no activation: multiply by 1 (a lane's exp may have overflowed; the select drops it)
+                for e in range(4):
+                    L(f"v_cndmask_b32 v{Y + e}, 1.0, v{Y + e}, {s2('actm')}")
+            L(f"v_pk_mul_f32 v[{X}:{X + 1}], v[{X}:{X + 1}], v[{Y}:{Y + 1}]")
+            L(f"v_pk_mul_f32 v[{X + 2}:{X + 3}], v[{X + 2}:{X + 3}], v[{Y + 2}:{Y + 3}]")
+        elif RES:
+            unpack()
+        if RES:
+            L(f"v_pk_add_f32 v[{X}:{X + 1}], v[{X}:{X + 1}], v[{Rr}:{Rr + 1}]")
+            L(f"v_pk_add_f32 v[{X + 2}:{X + 3}], v[{X + 2}:{X + 3}], v[{Rr + 2}:{Rr + 3}]")
+        L(f"v_cvt_pk_bf16_f32 v{Y}, v{X}, v{X + 1}")
+        L(f"v_cvt_pk_bf16_f32 v{Y + 1}, v{X + 2}, v{X + 3}")
+        # one unit: nothing (no MFMA, no other block's instruction) may sit between the EXEC switch and the store
+        L("\n\t".join([f"s_mov_b64 exec, {s2('t64')}", f"global_store_dwordx2 {v('oo', j)}, v[{Y}:{Y + 1}], {s2('out')} offset:{32 * i}",
+                         "s_mov_b64 exec, -1"]))
 
-    for n in range(PD):
-        b_read(n)
-    cold = []                             # out-of-line waits: (label, immediate, label to return to)
-    # ---- the element stream ----
-    # Vector-memory operations of one tap, in issue order: (element, kind, ...).  Weights of tap t + 2 at the odd elements 1 .. 11,
-    # two LDS-DMA instructions in the first NG taps, residual loads (one or two pixel blocks of three) in taps 0 .. 6.
-    kD0, kD1 = 12, 12 + (2 * NB - 12) // 2
-    in_stream_res = RES and RES_EARLY
-    res_groups = []                       # res_groups[t] = pixel blocks whose residual is loaded in tap t
-    if in_stream_res:
-        nxt = 0
-        for t in range(9):
-            cnt = min(NB - nxt, -(-(NB - nxt) // (7 - t))) if t < 7 else 0
-            res_groups.append(list(range(nxt, nxt + cnt)))
-            nxt += cnt
-        assert nxt == NB and kD1 + 2 < 2 * NB
+    def block_mask_lines(j, lines):
+        lines.append(f"s_sub_i32 {s('lim')}, {s('npix')}, {s('n0')}")
+        lines.append(f"s_sub_i32 {s('lim')}, {s('lim')}, {16 * j}")
+        lines.append(f"v_cmp_gt_i32 {s2('t64')}, {s('lim')}, {v('l15')}")
 
-    def tap_ops(t, last=True):
-        ops = [(2 * k + 1, "A", (t + LOOK) % 9, k) for k in range(3 if w8 else 6) if not abl & 1]
-        if t < NG and not abl & 2:
-            ops += [(kD0, "D", t, 0), (kD1, "D", t, 1)]
-        if in_stream_res and last:
-            for g, j in enumerate(res_groups[t]):
-                ops += [((kD0, kD1)[g] + 2, "R", j, i) for i in range(3)]
-        return sorted(ops, key=lambda o: o[0])
+    if SPLIT_ON:
+        NBA = SPLIT
 
-    def younger_than(tap, k_last, t_wait, e_wait, last):
-        """Vector-memory operations issued after weight load k_last of tap `tap` and before element e_wait of tap t_wait, in a tile's
-        last chunk (with the residual loads) or another one; the chunk before is never a last chunk that matters: its residual loads
-        are older than the weights of taps 0 and 1."""
-        seq = [o for tt in range(9) for o in tap_ops(tt, False)] + [o for tt in range(t_wait) for o in tap_ops(tt, last)]
-        seq += [o for o in tap_ops(t_wait, last) if o[0] < e_wait]
-        idx = max(i for i, o in enumerate(seq) if o[1] == "A" and o[2] == tap and o[3] == k_last)
-        return len(seq) - 1 - idx
+        def make_body(last):
+            """Tap sequence and element list of a chunk body.  taps[p] = (tap 0..8, pixel blocks); elems[n] = (p, e, t, ks, j)."""
+            passes = [list(range(NBA)), list(range(NBA, NB))] if last else [list(range(NB))]
+            taps, elems = [], []
+            for js in passes:
+                for t in range(9):
+                    p = len(taps)
+                    taps.append((t, js))
+                    e = 0
+                    for ks in (0, 1):
+                        for j in js:
+                            elems.append((p, e, t, ks, j))
+                            e += 1
+            return taps, elems
 
-    def wait_weights(tap, k_last, t_wait, e_wait):
-        """Weight loads 0 .. k_last of tap `tap` have landed, at element e_wait of tap t_wait."""
-        if abl & 1:
-            return
-        kN = younger_than(tap, k_last, t_wait, e_wait, False)
-        kL = younger_than(tap, k_last, t_wait, e_wait, True)
-        assert kN <= kL <= 63
-        cases = []                                        # (flag register, immediate)
-        if kL != kN:
-            cases.append((s("lastc"), kL))
-        if tap < LOOK and t_wait < LOOK:                  # loaded before the previous tile's epilogue
-            cases.append((s("extra"), min(63, kN + n_extra)))
-        # the common case falls through (a taken branch costs the wave its instruction buffer); the others wait out of line
-        ld = uid("wd")
-        for flag, imm in cases:
-            lx = uid("wx")
-            E(f"s_cmp_eq_u32 {flag}, 1")
-            E(f"s_cbranch_scc1 {lx}")
-            cold.append((lx, imm, ld))
-        E(f"s_waitcnt vmcnt({kN})", f"weights of tap {tap}, loads 0 .. {k_last}")
-        label(ld)
+        def body_ops(last):
+            """Vector-memory operations of a body in issue order: (p, e, kind, x, y).  A: weight load y (0..5) of tap sequence number x
+            (x >= len(taps): tap x - len(taps) of the NEXT chunk); D: LDS-DMA (group x, half y); R: residual load (pixel block x, M block y);
+            S: store of the epilogue block issued between the MFMAs (filled in by the emitter)."""
+            taps, _ = make_body(last)
+            ops = []
+            for p, (t, js) in enumerate(taps):
+                ne = 2 * len(js)
+                assert ne >= 12
+                ops += [(p, 2 * k + 1, "A", p + LOOK, k) for k in range(6)]
+                if p < NG:
+                    ops += [(p, 12, "D", p, 0), (p, 12 + (ne - 12) // 2 if ne > 13 else 13, "D", p, 1)]
+                if last and RES and p < 7:
+                    groups = [2 * p, 2 * p + 1] if p < 6 else [12]
+                    for gi, jr in enumerate(g for g in groups if g < NB):
+                        ops += [(p, (6, 10)[gi], "R", jr, i) for i in range(3)]
+            return ops
 
-    for n in range(NE):
-        h, j = divmod(n, NB)
-        t, ks = divmod(h, 2)
-        e = ks * NB + j
-        if n + PD < NE:
-            b_read(n + PD)
-        if j == 0 and not w8:
-            wait_weights(t, 2 + 3 * ks, t, e)             # bf16 fragments: three per k-step
-        elif j == 0 and ks == 0:
-            wait_weights(t, 2, t, e)                      # raw pair 2 of this tap: converted (k-step 1) under this k-step's MFMAs
-        elif j == 0:
-            wait_weights((t + 1) % 9, 1, t, e)            # raw pairs 0, 1 of the next tap: its k-step 0 is converted under this one
-        for op in tap_ops(t):
-            if op[0] != e:
-                continue
-            if op[1] == "A":
-                if op[3] == 0:
-                    emit_set_a_base("a_ld", t + LOOK)
-                emit_load_a((t + LOOK) % (LOOK + 1), op[3], s2("a_ld"), 0)
-            elif op[1] == "D":
-                emit_dma(t, op[3], s("cd"), s("bd"))
-            elif op[1] == "R" and op[3] == 0:
-                # out of line as well: only a tile's last chunk takes the branch
-                jr = op[2]
-                lx, ld = uid("res"), uid("resd")
-                E(f"s_cmp_eq_u32 {s('lastc')}, 1")
-                E(f"s_cbranch_scc1 {lx}")
-                label(ld)
-                body = [f"v_add_u32 {T[4]}, {s('n0')}, {v('l15')}"]
-                if jr:
-                    body.append(f"v_add_u32 {T[4]}, {16 * jr}, {T[4]}")
-                body += [f"v_min_i32 {T[4]}, {s('rlim')}, {T[4]}", f"v_mul_lo_u32 {T[4]}, {T[4]}, {s('res_ld')}", f"v_add_u32 {T[4]}, {T[4]}, {T[7]}"]
-                body += [f"global_load_dwordx2 v[{rreg(3 * jr + i)}:{rreg(3 * jr + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}" for i in range(3)]
-                cold.append((lx, body, ld))
-        allowed = min(PD, NE - 1 - n)
-        E(f"s_waitcnt lgkmcnt({allowed})")
-        for i in range(3 if not abl & 8 else 0):
-            srca = bfreg(ks, i) if w8 else areg(t % (LOOK + 1), 3 * ks + i)
-            E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {srca}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
-        if w8 and j < 12:
-            # one quarter of a fragment of the NEXT half-tap per element: two VALU instructions in the shadow of three MFMAs
+        def emit_body(last, label_name):
+            taps, elems = make_body(last)
+            m = len(taps)
+            ops = body_ops(last)
+            # epilogue slices (last body): the blocks of the first group, issued from the second element of the second pass on
+            slices = {}
+            if last:
+                lines = []
+                for j in range(NBA):
+                    block_mask_lines(j, lines)
+                    for i in range(3):
+                        epilogue_block(i, j, "select", lines)
+                first = next(n for n, el in enumerate(elems) if el[0] == 9) + 1
+                slots = [n for n in range(first, len(elems) - 2 * len(taps[-1][1]) * 2)]       # done before the last two taps: their
+                per = -(-len(lines) // len(slots))                                             # tails then look like a plain body's
+                for k, n in enumerate(slots):
+                    slices[n] = lines[k * per:(k + 1) * per]
+                assert sum(len(v_) for v_ in slices.values()) == len(lines) and per <= 9
+                for n, ls in slices.items():
+                    for l in ls:
+                        if "global_store" in l:
+                            ops.append((elems[n][0], elems[n][1] + 0.5, "S", 0, 0))
+            ops.sort(key=lambda o: (o[0], o[1]))
+            flat = [(o, (o[0], o[1])) for o in ops]
+
+            def seq_until(p_w, e_w):
+                return [o for o in ops if (o[0], o[1]) < (p_w, e_w)]
+
+            return taps, elems, ops, slices, m, seq_until
+
+        bodies = {False: emit_body(False, "plain"), True: emit_body(True, "last")}
+        rem_stores = 3 * (NB - NBA)
+
+        def prev_tail(kind):
+            """Operations that precede a body: a plain chunk, or a last chunk followed by the rest of the epilogue (its stores)."""
+            if kind == "plain":
+                return list(bodies[False][2])
+            return list(bodies[True][2]) + [(99, k, "S", 0, 0) for k in range(rem_stores)]
+
+        def younger(prev_kind, last, tapseq, k_last, p_w, e_w):
+            taps, elems, ops, slices, m, seq_until = bodies[last]
+            prev = prev_tail(prev_kind)
+            m_prev = 9 if prev_kind == "plain" else 18
+            seq = []
+            for o in prev:                                   # weight loads of the previous body for "tap m_prev + k" are this body's tap k
+                if o[2] == "A":
+                    seq.append(("A", o[3] - m_prev, o[4]))
+                else:
+                    seq.append((o[2], -1, -1))
+            for o in seq_until(p_w, e_w):
+                seq.append(("A", o[3], o[4]) if o[2] == "A" else (o[2], -1, -1))
+            idx = max(i for i, o in enumerate(seq) if o == ("A", tapseq, k_last))
+            return len(seq) - 1 - idx
+
+        def emit_stream(last):
+            taps, elems, ops, slices, m, seq_until = bodies[last]
+            ne_all = len(elems)
+
+            def b_read(n):
+                p, e, t, ks, j = elems[n]
+                if ks == 0:
+                    if t == 0:
+                        E(f"v_add_u32 {v('addr', j)}, {s('delta0')}, {v('addr', j)}")
+                    elif t % 3 == 0:
+                        E(f"v_add_u32 {v('addr', j)}, {s('dRow')}, {v('addr', j)}")
+                    else:
+                        E(f"v_add_u32 {v('addr', j)}, 16, {v('addr', j)}")
+                E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)}" + (f" offset:{4 * PS}" if ks else ""))
+
+            for n in range(PD):
+                b_read(n)
+            res_waited = False
+            for n in range(ne_all):
+                p, e, t, ks, j = elems[n]
+                js = taps[p][1]
+                if n + PD < ne_all:
+                    b_read(n + PD)
+                if j == js[0]:                               # first element of a half-tap: its three weight fragments
+                    k_last = 2 + 3 * ks
+                    if last:
+                        kN = younger("plain", True, p, k_last, p, e)
+                        assert kN <= 63
+                        E(f"s_waitcnt vmcnt({kN})", f"weights of tap {p}, k-step {ks}")
+                    else:
+                        kN = younger("plain", False, p, k_last, p, e)
+                        assert kN <= 63
+                        ld = uid("wd")
+                        if p < LOOK:                         # loaded before the previous tile's epilogue finished: more is in flight
+                            kX = min(63, younger("last", False, p, k_last, p, e))
+                            lx = uid("wx")
+                            E(f"s_cmp_eq_u32 {s('extra')}, 1")
+                            E(f"s_cbranch_scc1 {lx}")
+                            cold.append((lx, kX, ld))
+                        E(f"s_waitcnt vmcnt({kN})", f"weights of tap {p}, k-step {ks}")
+                        label(ld)
+                for o in ops:
+                    if (o[0], o[1]) != (p, e):
+                        continue
+                    if o[2] == "A":
+                        tp = o[3]
+                        if o[4] == 0:
+                            if tp < m:
+                                emit_set_a_base("a_ld", taps[tp][0])
+                            else:
+                                emit_set_a_base("a_ld", 9 + tp - m)
+                        emit_load_a(tp % (LOOK + 1), o[4], s2("a_ld"), 0)
+                    elif o[2] == "D":
+                        emit_dma(o[3], o[4], s("cd"), s("bd"))
+                    elif o[2] == "R":
+                        jr, i = o[3], o[4]
+                        if i == 0:
+                            E(f"v_add_u32 {T[4]}, {s('n0')}, {v('l15')}")
+                            if jr:
+                                E(f"v_add_u32 {T[4]}, {16 * jr}, {T[4]}")
+                            E(f"v_min_i32 {T[4]}, {s('rlim')}, {T[4]}")
+                            E(f"v_mul_lo_u32 {T[4]}, {T[4]}, {s('res_ld')}")
+                            E(f"v_add_u32 {T[4]}, {T[4]}, {T[7]}")
+                        E(f"global_load_dwordx2 v[{rreg(3 * jr + i)}:{rreg(3 * jr + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}")
+                E(f"s_waitcnt lgkmcnt({min(PD, ne_all - 1 - n)})")
+                for i in range(3):
+                    E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {areg(p % (LOOK + 1), 3 * ks + i)}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
+                if n in slices:
+                    if RES and not res_waited:               # the residual of the first group (loaded in the first pass) has landed
+                        seq = seq_until(p, e + 0.25)
+                        k_r = len(seq) - 1 - max(i for i, o in enumerate(seq) if o[2] == "R" and o[3] < NBA)
+                        E(f"s_waitcnt vmcnt({min(63, k_r)})", "residual of the pixel blocks whose epilogue starts here")
+                        res_waited = True
+                    for l in slices[n]:
+                        E(l)
+
+        l_last, l_cend = uid("lastbody"), uid("cend")
+        E(f"s_cmp_eq_u32 {s('lastc')}, 1")
+        E(f"s_cbranch_scc1 {l_last}")
+        emit_stream(False)
+        E(f"s_branch {l_cend}")
+        label(l_last)
+        emit_stream(True)
+        label(l_cend)
+    if not SPLIT_ON:
+        # first B fragments
+        def b_read(n):
+            h, j = divmod(n, NB)
+            t, ks = divmod(h, 2)
             if ks == 0:
-                emit_convert(t, 1, j // 4, j % 4)
-            else:
-                emit_convert((t + 1) % 9, 0, j // 4, j % 4)
+                # advance this pixel block's address to tap t
+                if t == 0:
+                    E(f"v_add_u32 {v('addr', j)}, {s('delta0')}, {v('addr', j)}")
+                elif t % 3 == 0:
+                    E(f"v_add_u32 {v('addr', j)}, {s('dRow')}, {v('addr', j)}")
+                else:
+                    E(f"v_add_u32 {v('addr', j)}, 16, {v('addr', j)}")
+            if not abl & 4:
+                E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)}" + (f" offset:{4 * PS}" if ks else ""))
+
+        for n in range(PD):
+            b_read(n)
+        # ---- the element stream ----
+        # Vector-memory operations of one tap, in issue order: (element, kind, ...).  Weights of tap t + 2 at the odd elements 1 .. 11,
+        # two LDS-DMA instructions in the first NG taps, residual loads (one or two pixel blocks of three) in taps 0 .. 6.
+        kD0, kD1 = 12, 12 + (2 * NB - 12) // 2
+        in_stream_res = RES and RES_EARLY
+        res_groups = []                       # res_groups[t] = pixel blocks whose residual is loaded in tap t
+        if in_stream_res:
+            nxt = 0
+            for t in range(9):
+                cnt = min(NB - nxt, -(-(NB - nxt) // (7 - t))) if t < 7 else 0
+                res_groups.append(list(range(nxt, nxt + cnt)))
+                nxt += cnt
+            assert nxt == NB and kD1 + 2 < 2 * NB
+
+        def tap_ops(t, last=True):
+            ops = [(2 * k + 1, "A", (t + LOOK) % 9, k) for k in range(3 if w8 else 6) if not abl & 1]
+            if t < NG and not abl & 2:
+                ops += [(kD0, "D", t, 0), (kD1, "D", t, 1)]
+            if in_stream_res and last:
+                for g, j in enumerate(res_groups[t]):
+                    ops += [((kD0, kD1)[g] + 2, "R", j, i) for i in range(3)]
+            return sorted(ops, key=lambda o: o[0])
+
+        def younger_than(tap, k_last, t_wait, e_wait, last):
+            """Vector-memory operations issued after weight load k_last of tap `tap` and before element e_wait of tap t_wait, in a tile's
+            last chunk (with the residual loads) or another one; the chunk before is never a last chunk that matters: its residual loads
+            are older than the weights of taps 0 and 1."""
+            seq = [o for tt in range(9) for o in tap_ops(tt, False)] + [o for tt in range(t_wait) for o in tap_ops(tt, last)]
+            seq += [o for o in tap_ops(t_wait, last) if o[0] < e_wait]
+            idx = max(i for i, o in enumerate(seq) if o[1] == "A" and o[2] == tap and o[3] == k_last)
+            return len(seq) - 1 - idx
+
+        def wait_weights(tap, k_last, t_wait, e_wait):
+            """Weight loads 0 .. k_last of tap `tap` have landed, at element e_wait of tap t_wait."""
+            if abl & 1:
+                return
+            kN = younger_than(tap, k_last, t_wait, e_wait, False)
+            kL = younger_than(tap, k_last, t_wait, e_wait, True)
+            assert kN <= kL <= 63
+            cases = []                                        # (flag register, immediate)
+            if kL != kN:
+                cases.append((s("lastc"), kL))
+            if tap < LOOK and t_wait < LOOK:                  # loaded before the previous tile's epilogue
+                cases.append((s("extra"), min(63, kN + n_extra)))
+            # the common case falls through (a taken branch costs the wave its instruction buffer); the others wait out of line
+            ld = uid("wd")
+            for flag, imm in cases:
+                lx = uid("wx")
+                E(f"s_cmp_eq_u32 {flag}, 1")
+                E(f"s_cbranch_scc1 {lx}")
+                cold.append((lx, imm, ld))
+            E(f"s_waitcnt vmcnt({kN})", f"weights of tap {tap}, loads 0 .. {k_last}")
+            label(ld)
+
+        for n in range(NE):
+            h, j = divmod(n, NB)
+            t, ks = divmod(h, 2)
+            e = ks * NB + j
+            if n + PD < NE:
+                b_read(n + PD)
+            if j == 0 and not w8:
+                wait_weights(t, 2 + 3 * ks, t, e)             # bf16 fragments: three per k-step
+            elif j == 0 and ks == 0:
+                wait_weights(t, 2, t, e)                      # raw pair 2 of this tap: converted (k-step 1) under this k-step's MFMAs
+            elif j == 0:
+                wait_weights((t + 1) % 9, 1, t, e)            # raw pairs 0, 1 of the next tap: its k-step 0 is converted under this one
+            for op in tap_ops(t):
+                if op[0] != e:
+                    continue
+                if op[1] == "A":
+                    if op[3] == 0:
+                        emit_set_a_base("a_ld", t + LOOK)
+                    emit_load_a((t + LOOK) % (LOOK + 1), op[3], s2("a_ld"), 0)
+                elif op[1] == "D":
+                    emit_dma(t, op[3], s("cd"), s("bd"))
+                elif op[1] == "R" and op[3] == 0:
+                    # out of line as well: only a tile's last chunk takes the branch
+                    jr = op[2]
+                    lx, ld = uid("res"), uid("resd")
+                    E(f"s_cmp_eq_u32 {s('lastc')}, 1")
+                    E(f"s_cbranch_scc1 {lx}")
+                    label(ld)
+                    body = [f"v_add_u32 {T[4]}, {s('n0')}, {v('l15')}"]
+                    if jr:
+                        body.append(f"v_add_u32 {T[4]}, {16 * jr}, {T[4]}")
+                    body += [f"v_min_i32 {T[4]}, {s('rlim')}, {T[4]}", f"v_mul_lo_u32 {T[4]}, {T[4]}, {s('res_ld')}", f"v_add_u32 {T[4]}, {T[4]}, {T[7]}"]
+                    body += [f"global_load_dwordx2 v[{rreg(3 * jr + i)}:{rreg(3 * jr + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}" for i in range(3)]
+                    cold.append((lx, body, ld))
+            allowed = min(PD, NE - 1 - n)
+            E(f"s_waitcnt lgkmcnt({allowed})")
+            for i in range(3 if not abl & 8 else 0):
+                srca = bfreg(ks, i) if w8 else areg(t % (LOOK + 1), 3 * ks + i)
+                E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {srca}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
+            if w8 and j < 12:
+                # one quarter of a fragment of the NEXT half-tap per element: two VALU instructions in the shadow of three MFMAs
+                if ks == 0:
+                    emit_convert(t, 1, j // 4, j % 4)
+                else:
+                    emit_convert((t + 1) % 9, 0, j // 4, j % 4)
     # ---- chunk end ----
     stamp(PH_STREAM)
     # next chunk: delta0 = (next buffer - this buffer) * CHUNK - (2 Wp + 2) * 16
@@ -819,7 +1063,11 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     else:
         E("s_nop 15", "hz: MFMA result -> VALU read")
         E("s_nop 15")
-    if RES and RES_EARLY:
+    if RES and RES_EARLY and SPLIT_ON:
+        tail = bodies[True][2]
+        k_res = len(tail) - 1 - max(i for i, o in enumerate(tail) if o[2] == "R")
+        E(f"s_waitcnt vmcnt({min(63, k_res)})", "the residual (loads return in order: at most 63 younger operations can be outstanding)")
+    elif RES and RES_EARLY:
         tail = [o for tt in range(9) for o in tap_ops(tt, True)]
         k_res = len(tail) - 1 - max(i for i, o in enumerate(tail) if o[1] == "R")
         E(f"s_waitcnt vmcnt({k_res})", "the residual (only weight loads of the next tile's first taps are younger)")
@@ -841,7 +1089,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             E(f"s_cbranch_scc1 {lact}")
         else:
             label(lact)
-        for j in range(NB):
+        for j in range(SPLIT if SPLIT_ON else 0, NB):        # (split last chunk: the first pixel blocks were done between its MFMAs)
             E(f"s_sub_i32 {s('lim')}, {s('npix')}, {s('n0')}")
             E(f"s_sub_i32 {s('lim')}, {s('lim')}, {16 * j}", "pixels of this block inside the batch")
             E(f"v_cmp_gt_i32 {s2('t64')}, {s('lim')}, {v('l15')}", "pixel n0 + 16 j + l15 inside the batch?")
