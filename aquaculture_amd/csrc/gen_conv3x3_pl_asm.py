@@ -337,30 +337,37 @@ def emit_no_rows():
         E(f"v_mov_b32 {v('prow', k)}, -1")
 
 
-def emit_dma(k, s2i, cd_s, bd_s):
-    """One LDS-DMA instruction: plane 2 wave + s2i of chunk cd, region rows 64 k .. 64 k + 63, into ring buffer bd."""
-    T = [v("t", i) for i in range(8, 12)]
-    # scalar: dbase = inp + (8 cd + 2 wave + s2i) * in_ss ; dlds = smem + bd * CHUNK + (2 wave + s2i) * PS + k * 1024
+def emit_dma_base(cd_s, bd_s):
+    """Per chunk: dbase = inp + (8 cd + 2 wave) * in_ss (plane 2 wave of chunk cd) and dlds = bd * CHUNK + 2 wave * PS, the operands every
+    LDS-DMA instruction of that chunk starts from.  (Computing them inside each of the 12 instructions' sequences cost 13 scalar
+    instructions apiece, in a stream that is bound by instruction issue.)"""
     E(f"s_lshl_b32 {s('tmp0')}, {cd_s}, 3")
     E(f"s_lshl_b32 {s('tmp1')}, {s('wave')}, 1")
-    E(f"s_add_u32 {s('tmp1')}, {s('tmp1')}, {s2i}")
-    E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {s('tmp1')}", "slot")
+    E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {s('tmp1')}", "slot of this wave's first plane")
     E(f"s_mul_i32 {s('tmp2')}, {s('tmp0')}, {s('in_ss')}")
     E(f"s_mul_hi_u32 {s('tmp3')}, {s('tmp0')}, {s('in_ss')}")
     E(f"s_add_u32 {s('dbase')}, {s('inp')}, {s('tmp2')}")
     E(f"s_addc_u32 {s('dbase', 1)}, {s('inp', 1)}, {s('tmp3')}")
     E(f"s_mul_i32 {s('tmp2')}, {bd_s}, {CHUNK}")
     E(f"s_mul_i32 {s('tmp1')}, {s('tmp1')}, {PS}")
-    E(f"s_mov_b32 {s('dlds')}, {s('tmp2')}", "the ring starts at LDS address 0")
-    E(f"s_add_u32 {s('dlds')}, {s('dlds')}, {s('tmp1')}")
-    E(f"s_add_u32 {s('dlds')}, {s('dlds')}, {k * 1024}")
+    E(f"s_add_u32 {s('dlds')}, {s('tmp2')}, {s('tmp1')}", "the ring starts at LDS address 0")
+
+
+def emit_dma(k, s2i, cd_s=None, bd_s=None):
+    """One LDS-DMA instruction: plane 2 wave + s2i of the chunk emit_dma_base was called for, region rows 64 k .. 64 k + 63."""
+    T = [v("t", i) for i in range(8, 12)]
+    base = s2("dbase")
+    if s2i:
+        E(f"s_add_u32 {s('t64')}, {s('dbase')}, {s('in_ss')}")
+        E(f"s_addc_u32 {s('t64', 1)}, {s('dbase', 1)}, 0")
+        base = s2("t64")
     E(f"v_max_i32 {T[2]}, 0, {v('prow', k)}")
-    E(f"v_mad_u64_u32 v[{V.names['t'][0] + 8}:{V.names['t'][0] + 9}], vcc, {T[2]}, {v('insp')}, {s2('dbase')}")
+    E(f"v_mad_u64_u32 v[{V.names['t'][0] + 8}:{V.names['t'][0] + 9}], vcc, {T[2]}, {v('insp')}, {base}")
     E(f"v_cmp_gt_i32 vcc, 0, {v('prow', k)}")
     E(f"v_cndmask_b32 {T[0]}, {T[0]}, {v('zero_lo')}, vcc")
     E(f"v_cndmask_b32 {T[1]}, {T[1]}, {v('zero_hi')}, vcc")
-    E(f"s_mov_b32 m0, {s('dlds')}")
-    E("s_nop 0", "hz: s_mov m0 -> LDS-DMA")
+    E(f"s_add_u32 m0, {s('dlds')}, {s2i * PS + k * 1024}")
+    E("s_nop 0", "hz: m0 write -> LDS-DMA")
     E(f"global_load_lds_dwordx4 v[{V.names['t'][0] + 8}:{V.names['t'][0] + 9}], off")
 
 
@@ -462,7 +469,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_add_u32 {s('lead')}, {s('W')}, 2")
     E(f"s_add_u32 {s('Hpad')}, {s('tmp0')}, {s('W')}", "H + W + 1")
     E(f"s_lshl_b32 {s('tmp0')}, {s('Wp')}, 4")
-    E(f"s_sub_u32 {s('dRow')}, {s('tmp0')}, 32", "tap (r, 2) -> (r + 1, 0): (Wp - 2) * 16 bytes")
+    E(f"s_mov_b32 {s('dRow')}, {s('tmp0')}", "kernel row r -> r + 1: Wp * 16 bytes")
     E(f"s_mov_b32 {s('klog2e2')}, 0xbfb8aa3b", "-log2(e)")
     E(f"s_mov_b32 {s('klog2e2', 1)}, 0xbfb8aa3b")
     E(f"s_mov_b32 {s('kone2')}, 1.0")
@@ -501,6 +508,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     emit_region_rows(s("tile"))
     E(f"s_mov_b32 {s('cd')}, 0")
     E(f"s_mov_b32 {s('bd')}, 0")
+    emit_dma_base(s("cd"), s("bd"))
     for k in range(NG):
         for s2i in range(2):
             emit_dma(k, s2i, s("cd"), s("bd"))
@@ -533,20 +541,21 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         E(f"s_mov_b32 m0, {s('tmp0')}")
         E("s_nop 0", "hz: s_mov m0 -> LDS-DMA")
         E(f"global_load_lds_dwordx4 v[{V.names['t'][0] + 4}:{V.names['t'][0] + 5}], off")
-    if RING == 3:
-        E(f"s_mov_b32 {s('cd')}, 1")
-        E(f"s_mov_b32 {s('bd')}, 1")
-        for k in range(NG):
-            for s2i in range(2):
-                emit_dma(k, s2i, s("cd"), s("bd"))
-        E(f"s_waitcnt vmcnt({2 * NG})", "all but chunk 1's LDS-DMA: weights of taps 0 and 1, chunk 0, the bias")
-    else:
-        E("s_waitcnt vmcnt(0)", "weights of taps 0 and 1, chunk 0, the bias")
+    E("s_waitcnt vmcnt(0)", "weights of the first taps, chunk 0, the bias")
     emit_barrier()
     if w8:
         for i in range(3):                         # k-step 0 of the very first tap; every later half-tap is converted under MFMAs
             for step in range(4):
                 emit_convert(0, 0, i, step)
+    if RING == 3:
+        # chunk 1's LDS-DMA only now: issued together with chunk 0's, every workgroup of the launch asked for twice the bytes at once and
+        # the first barrier came 2-3 k cycles later; it has the whole first chunk to land
+        E(f"s_mov_b32 {s('cd')}, 1")
+        E(f"s_mov_b32 {s('bd')}, 1")
+        emit_dma_base(s("cd"), s("bd"))
+        for k in range(NG):
+            for s2i in range(2):
+                emit_dma(k, s2i, s("cd"), s("bd"))
     stamp(PH_PROLOGUE)
     E(f"s_mov_b32 {s('buf')}, 0")
     E(f"s_mov_b32 {s('first')}, 1")
@@ -624,6 +633,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     emit_no_rows()
     label(ldone)
     label(lskip)
+    emit_dma_base(s("cd"), s("bd"))
     # weight stream of this chunk and of the next (chunk c + 1, or chunk 0 of the next tile; the own tile again when there is none)
     emit_a_stream_base("a_cur", s("tile"), s("c"))
     lnx, lnd = uid("anxt"), uid("anxtd")
@@ -831,14 +841,11 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
 
             def b_read(n):
                 p, e, t, ks, j = elems[n]
-                if ks == 0:
-                    if t == 0:
-                        E(f"v_add_u32 {v('addr', j)}, {s('delta0')}, {v('addr', j)}")
-                    elif t % 3 == 0:
-                        E(f"v_add_u32 {v('addr', j)}, {s('dRow')}, {v('addr', j)}")
-                    else:
-                        E(f"v_add_u32 {v('addr', j)}, 16, {v('addr', j)}")
-                E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)}" + (f" offset:{4 * PS}" if ks else ""))
+                if ks == 0 and t == 0:
+                    E(f"v_add_u32 {v('addr', j)}, {s('delta0')}, {v('addr', j)}")
+                elif ks == 0 and t % 3 == 0:
+                    E(f"v_add_u32 {v('addr', j)}, {s('dRow')}, {v('addr', j)}")
+                E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)} offset:{16 * (t % 3) + (4 * PS if ks else 0)}")
 
             for n in range(PD):
                 b_read(n)
@@ -889,7 +896,8 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
                             E(f"v_mul_lo_u32 {T[4]}, {T[4]}, {s('res_ld')}")
                             E(f"v_add_u32 {T[4]}, {T[4]}, {T[7]}")
                         E(f"global_load_dwordx2 v[{rreg(3 * jr + i)}:{rreg(3 * jr + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}")
-                E(f"s_waitcnt lgkmcnt({min(PD, ne_all - 1 - n)})")
+                if n % 2 == 0:
+                    E(f"s_waitcnt lgkmcnt({max(min(PD, ne_all - 1 - n) - 1, 0) if n + 1 < ne_all else 0})")
                 for i in range(3):
                     E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {areg(p % (LOOK + 1), 3 * ks + i)}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
                 if n in slices:
@@ -914,16 +922,13 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         def b_read(n):
             h, j = divmod(n, NB)
             t, ks = divmod(h, 2)
-            if ks == 0:
-                # advance this pixel block's address to tap t
-                if t == 0:
-                    E(f"v_add_u32 {v('addr', j)}, {s('delta0')}, {v('addr', j)}")
-                elif t % 3 == 0:
-                    E(f"v_add_u32 {v('addr', j)}, {s('dRow')}, {v('addr', j)}")
-                else:
-                    E(f"v_add_u32 {v('addr', j)}, 16, {v('addr', j)}")
+            # the pixel block's address moves once per kernel ROW (taps 0, 3, 6); the column and the k-step are immediate offsets
+            if ks == 0 and t == 0:
+                E(f"v_add_u32 {v('addr', j)}, {s('delta0')}, {v('addr', j)}")
+            elif ks == 0 and t % 3 == 0:
+                E(f"v_add_u32 {v('addr', j)}, {s('dRow')}, {v('addr', j)}")
             if not abl & 4:
-                E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)}" + (f" offset:{4 * PS}" if ks else ""))
+                E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)} offset:{16 * (t % 3) + (4 * PS if ks else 0)}")
 
         for n in range(PD):
             b_read(n)
@@ -1015,8 +1020,10 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
                     body += [f"v_min_i32 {T[4]}, {s('rlim')}, {T[4]}", f"v_mul_lo_u32 {T[4]}, {T[4]}, {s('res_ld')}", f"v_add_u32 {T[4]}, {T[4]}, {T[7]}"]
                     body += [f"global_load_dwordx2 v[{rreg(3 * jr + i)}:{rreg(3 * jr + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}" for i in range(3)]
                     cold.append((lx, body, ld))
+            # one wait per PAIR of elements (fragments n and n + 1 have landed): the stream is bound by instruction issue
             allowed = min(PD, NE - 1 - n)
-            E(f"s_waitcnt lgkmcnt({allowed})")
+            if n % 2 == 0:
+                E(f"s_waitcnt lgkmcnt({max(allowed - 1, 0) if n + 1 < NE else allowed})")
             for i in range(3 if not abl & 8 else 0):
                 srca = bfreg(ks, i) if w8 else areg(t % (LOOK + 1), 3 * ks + i)
                 E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {srca}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
@@ -1028,14 +1035,13 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
                     emit_convert((t + 1) % 9, 0, j // 4, j % 4)
     # ---- chunk end ----
     stamp(PH_STREAM)
-    # next chunk: delta0 = (next buffer - this buffer) * CHUNK - (2 Wp + 2) * 16
+    # next chunk: delta0 = (next buffer - this buffer) * CHUNK - 2 Wp * 16
     E(f"s_add_u32 {s('tmp0')}, {s('buf')}, 1")
     E(f"s_cmp_ge_u32 {s('tmp0')}, {RING}")
     E(f"s_cselect_b32 {s('tmp0')}, 0, {s('tmp0')}", "next buffer")
     E(f"s_sub_i32 {s('tmp1')}, {s('tmp0')}, {s('buf')}")
     E(f"s_mul_i32 {s('tmp1')}, {s('tmp1')}, {CHUNK}")
-    E(f"s_lshl_b32 {s('tmp2')}, {s('Wp')}, 5")
-    E(f"s_add_u32 {s('tmp2')}, {s('tmp2')}, 32", "(2 Wp + 2) * 16")
+    E(f"s_lshl_b32 {s('tmp2')}, {s('Wp')}, 5", "2 Wp * 16: back from kernel row 2 to row 0")
     E(f"s_sub_i32 {s('delta0')}, {s('tmp1')}, {s('tmp2')}")
     E(f"s_mov_b32 {s('buf')}, {s('tmp0')}")
     E(f"s_mov_b32 {s('first')}, 0")
