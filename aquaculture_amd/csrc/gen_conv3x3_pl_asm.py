@@ -361,8 +361,8 @@ def emit_dma(k, s2i, cd_s=None, bd_s=None):
         E(f"s_add_u32 {s('t64')}, {s('dbase')}, {s('in_ss')}")
         E(f"s_addc_u32 {s('t64', 1)}, {s('dbase', 1)}, 0")
         base = s2("t64")
-    E(f"v_max_i32 {T[2]}, 0, {v('prow', k)}")
-    E(f"v_mad_u64_u32 v[{V.names['t'][0] + 8}:{V.names['t'][0] + 9}], vcc, {T[2]}, {v('insp')}, {base}")
+    # (an invalid row, prow = -1, multiplies out to a wild address that the select below replaces: no clamp needed)
+    E(f"v_mad_u64_u32 v[{V.names['t'][0] + 8}:{V.names['t'][0] + 9}], vcc, {v('prow', k)}, {v('insp')}, {base}")
     E(f"v_cmp_gt_i32 vcc, 0, {v('prow', k)}")
     E(f"v_cndmask_b32 {T[0]}, {T[0]}, {v('zero_lo')}, vcc")
     E(f"v_cndmask_b32 {T[1]}, {T[1]}, {v('zero_hi')}, vcc")
@@ -692,13 +692,13 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     cold = []                             # out-of-line code: (label, immediate or instruction list, label to return to)
     T7RES = RES and RES_EARLY
 
-    def epilogue_block(i, j, mode, lines):
+    def epilogue_block(i, j, mode, lines, tb=0, own_exec=True):
         """Appends the instructions of one 16 x 16 output block (M block i, pixel block j): accumulators -> (x scale) -> SiLU -> + residual ->
         bf16 -> store.  mode: "act" / "noact" (the two copies behind a branch after the stream) or "select" (branch-free, for the copy
         issued between MFMAs).  The store's EXEC mask is in t64 (per pixel block, set by the caller)."""
-        X = V.names["t"][0] + 0
-        Y = V.names["t"][0] + 4
-        Rr = V.names["t"][0] + 8
+        X = V.names["t"][0] + tb + 0
+        Y = V.names["t"][0] + tb + 4
+        Rr = V.names["t"][0] + tb + 8
         a0 = 4 * (3 * j + i)
         r0 = rreg(3 * j + i) if RES else 0
         L = lines.append
@@ -736,9 +736,12 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             L(f"v_pk_add_f32 v[{X + 2}:{X + 3}], v[{X + 2}:{X + 3}], v[{Rr + 2}:{Rr + 3}]")
         L(f"v_cvt_pk_bf16_f32 v{Y}, v{X}, v{X + 1}")
         L(f"v_cvt_pk_bf16_f32 v{Y + 1}, v{X + 2}, v{X + 3}")
-        # one unit: nothing (no MFMA, no other block's instruction) may sit between the EXEC switch and the store
-        L("\n\t".join([f"s_mov_b64 exec, {s2('t64')}", f"global_store_dwordx2 {v('oo', j)}, v[{Y}:{Y + 1}], {s2('out')} offset:{32 * i}",
-                         "s_mov_b64 exec, -1"]))
+        if own_exec:
+            # one unit: nothing (no MFMA, no other block's instruction) may sit between the EXEC switch and the store
+            L("\n\t".join([f"s_mov_b64 exec, {s2('t64')}", f"global_store_dwordx2 {v('oo', j)}, v[{Y}:{Y + 1}], {s2('out')} offset:{32 * i}",
+                             "s_mov_b64 exec, -1"]))
+        else:
+            L(f"global_store_dwordx2 {v('oo', j)}, v[{Y}:{Y + 1}], {s2('out')} offset:{32 * i}")
 
     def block_mask_lines(j, lines):
         lines.append(f"s_sub_i32 {s('lim')}, {s('npix')}, {s('n0')}")
@@ -1089,7 +1092,39 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     X = V.names["t"][0] + 0      # x[0:3]
     Y = V.names["t"][0] + 4      # work
     Rr = V.names["t"][0] + 8     # residual as f32
-    for ACT in (True, False):
+    PAIRED = not w8 and (RES_EARLY or not RES)
+    for ACT in (True, False) if PAIRED else ():
+        # Two blocks of a pixel block at a time, their instructions interleaved (the v_exp -> add -> v_rcp -> mul chains are dependent, the
+        # VALU issues in order: a second independent chain fills the gaps), on two sets of temporaries; EXEC is switched once per pixel
+        # block -- the masked-off lanes' arithmetic is never stored.
+        if ACT:
+            E(f"s_cmp_eq_u32 {s('act')}, 0")
+            E(f"s_cbranch_scc1 {lact}")
+        else:
+            label(lact)
+        E(f"s_sub_i32 {s('lim')}, {s('npix')}, {s('n0')}")
+        j0 = SPLIT if SPLIT_ON else 0
+        if j0:
+            E(f"s_sub_i32 {s('lim')}, {s('lim')}, {16 * j0}")
+        for j in range(j0, NB):
+            E(f"v_cmp_gt_i32 {s2('t64')}, {s('lim')}, {v('l15')}", "pixel n0 + 16 j + l15 inside the batch?")
+            E(f"s_sub_i32 {s('lim')}, {s('lim')}, 16")
+            E(f"s_mov_b64 exec, {s2('t64')}")
+            la, lb, lc = [], [], []
+            epilogue_block(0, j, "act" if ACT else "noact", la, 0, False)
+            epilogue_block(1, j, "act" if ACT else "noact", lb, 12, False)
+            epilogue_block(2, j, "act" if ACT else "noact", lc, 0, False)
+            for k in range(max(len(la), len(lb))):
+                if k < len(la):
+                    E(la[k])
+                if k < len(lb):
+                    E(lb[k])
+            for l in lc:
+                E(l)
+            E("s_mov_b64 exec, -1")
+        if ACT:
+            E(f"s_branch {lepd}")
+    for ACT in () if PAIRED else (True, False):
         if ACT:
             E(f"s_cmp_eq_u32 {s('act')}, 0")
             E(f"s_cbranch_scc1 {lact}")
