@@ -112,7 +112,8 @@ def allocate_registers():
     S.alloc("a_cur", 2, 2)
     S.alloc("a_nxt", 2, 2)
     S.alloc("a_ld", 2, 2)         # base of the weight loads being issued
-    S.alloc("dbase", 2, 2)        # LDS-DMA: input base of (chunk, plane)
+    S.alloc("dbase", 2, 2)        # LDS-DMA: input base of (chunk, this wave's first plane) ...
+    S.alloc("dbase1", 2, 2)       # ... and of its second plane
     S.alloc("t64", 2, 2)
     S.alloc("actm", 2, 2)         # all ones when the layer has an activation (in-stream epilogue blocks select instead of branching)
     S.alloc("st_acc", 12, 2)      # stamped build only: cycle sums of six phases
@@ -351,23 +352,20 @@ def emit_dma_base(cd_s, bd_s):
     E(f"s_mul_i32 {s('tmp2')}, {bd_s}, {CHUNK}")
     E(f"s_mul_i32 {s('tmp1')}, {s('tmp1')}, {PS}")
     E(f"s_add_u32 {s('dlds')}, {s('tmp2')}, {s('tmp1')}", "the ring starts at LDS address 0")
+    E(f"s_add_u32 {s('dbase1')}, {s('dbase')}, {s('in_ss')}")
+    E(f"s_addc_u32 {s('dbase1', 1)}, {s('dbase', 1)}, 0")
 
 
 def emit_dma(k, s2i, cd_s=None, bd_s=None):
     """One LDS-DMA instruction: plane 2 wave + s2i of the chunk emit_dma_base was called for, region rows 64 k .. 64 k + 63."""
     T = [v("t", i) for i in range(8, 12)]
-    base = s2("dbase")
-    if s2i:
-        E(f"s_add_u32 {s('t64')}, {s('dbase')}, {s('in_ss')}")
-        E(f"s_addc_u32 {s('t64', 1)}, {s('dbase', 1)}, 0")
-        base = s2("t64")
+    base = s2("dbase1") if s2i else s2("dbase")
+    E(f"s_add_u32 m0, {s('dlds')}, {s2i * PS + k * 1024}", "hz: m0 write -> LDS-DMA: the address arithmetic below sits in between")
     # (an invalid row, prow = -1, multiplies out to a wild address that the select below replaces: no clamp needed)
     E(f"v_mad_u64_u32 v[{V.names['t'][0] + 8}:{V.names['t'][0] + 9}], vcc, {v('prow', k)}, {v('insp')}, {base}")
     E(f"v_cmp_gt_i32 vcc, 0, {v('prow', k)}")
     E(f"v_cndmask_b32 {T[0]}, {T[0]}, {v('zero_lo')}, vcc")
     E(f"v_cndmask_b32 {T[1]}, {T[1]}, {v('zero_hi')}, vcc")
-    E(f"s_add_u32 m0, {s('dlds')}, {s2i * PS + k * 1024}")
-    E("s_nop 0", "hz: m0 write -> LDS-DMA")
     E(f"global_load_lds_dwordx4 v[{V.names['t'][0] + 8}:{V.names['t'][0] + 9}], off")
 
 
