@@ -39,14 +39,19 @@ import sys
 # 117.2 k -> 118.0 k.  The instructions put between the MFMAs are not free: with one wave per SIMD the stream is bound by what the wave
 # can issue and by in-order waits, so every filler lengthens it by about its own issue time (the same reason the fp8 weight stream's
 # conversions lose).  Off; kept as a generator option because it is the measurement behind "the epilogue cannot be hidden here".
+# DMA_FRONT: all 2 NG LDS-DMA instructions of a chunk in its FIRST tap, behind that tap's weight loads (one per element), instead of two per
+# tap over the first NG taps.  Loads return in order: a weight load issued behind an LDS-DMA (HBM / MALL latency) cannot land before it,
+# so with the DMA spread out every tap's weights could be held back; in front, only the weights of one tap per chunk sit behind it.
+# MEASURED: stream 92.8 k vs 90.1 k cycles (192 ch), 83.1 k vs 80.7 k (384 ch) -- worse; twelve requests at once queue behind each other.
+# Also measured on the weight loads: cache policy nt 94.4 k (worse), sc1 90.2 k (same) against 90.1 k (AQ_GEN_A_POLICY at build time).
 # LOOK = how many taps ahead the weights are loaded (LOOK + 1 fragment sets of 24 registers).  Loads return in order, so every LDS-DMA or
 # residual load (HBM / MALL latency) holds back the weight loads issued behind it: with LOOK = 2 such a load has two taps (2.5 k cycles)
 # before it stalls the stream, and the stamped builds showed exactly that stall; the one-workgroup family keeps its FOUR sets in the
 # accumulator half of the register file (100 AGPRs are free there), which also frees 72 VGPRs for a deeper B ring.
 CONFIGS = {
-    13: dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0),     # SPLIT=7: measured slower, below
-    7: dict(NB=7, PD=8, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False, SPLIT=0),
-    8: dict(NB=8, PD=7, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False, SPLIT=0),
+    13: dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False),    # SPLIT=7, DMA_FRONT: measured slower, below
+    7: dict(NB=7, PD=8, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False),
+    8: dict(NB=8, PD=7, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False),
 }
 STEP_B = 6 * 1024          # weight bytes per (wave, tap-step): six 1 KB bf16 fragments ...
 W8 = False                 # ... or, in the fp8-weight kernels (set per kernel by gen_kernel), three 1 KB pairs of e4m3 fragments
@@ -374,7 +379,9 @@ def emit_load_a(set_idx, k, base_s2, extra_off):
     fp8 weights: fragment PAIR k (0..2), lane = 8 codes of fragment 2 k then 8 of fragment 2 k + 1, into raw set set_idx."""
     off = 1024 * k - 3072 + extra_off
     assert -4096 <= off <= 4095
-    E(f"global_load_dwordx4 {rawreg(set_idx, k) if W8 else areg(set_idx, k)}, {v('aoff')}, {base_s2} offset:{off}")
+    import os as _os
+    pol = _os.environ.get("AQ_GEN_A_POLICY", "")          # experiment: cache policy of the weight loads ("nt", "sc0", "sc1", ...)
+    E(f"global_load_dwordx4 {rawreg(set_idx, k) if W8 else areg(set_idx, k)}, {v('aoff')}, {base_s2} offset:{off}" + (f" {pol}" if pol else ""))
 
 
 def emit_set_a_base(dst, tap):
@@ -949,7 +956,10 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
 
         def tap_ops(t, last=True):
             ops = [(2 * k + 1, "A", (t + LOOK) % 9, k) for k in range(3 if w8 else 6) if not abl & 1]
-            if t < NG and not abl & 2:
+            if DMA_FRONT and t == 0 and not abl & 2:
+                assert 12 + 2 * NG <= 2 * NB
+                ops += [(12 + 2 * k + h, "D", k, h) for k in range(NG) for h in range(2)]
+            elif not DMA_FRONT and t < NG and not abl & 2:
                 ops += [(kD0, "D", t, 0), (kD1, "D", t, 1)]
             if in_stream_res and last:
                 for g, j in enumerate(res_groups[t]):
@@ -1007,7 +1017,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
                         emit_set_a_base("a_ld", t + LOOK)
                     emit_load_a((t + LOOK) % (LOOK + 1), op[3], s2("a_ld"), 0)
                 elif op[1] == "D":
-                    emit_dma(t, op[3], s("cd"), s("bd"))
+                    emit_dma(op[2], op[3], s("cd"), s("bd"))
                 elif op[1] == "R" and op[3] == 0:
                     # out of line as well: only a tile's last chunk takes the branch
                     jr = op[2]

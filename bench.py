@@ -263,11 +263,16 @@ def main() -> int:
                 tj = json.load(f)
             with open(os.path.join(ROOT, "aquaculture_amd", "csrc", "libaqengine.so.sha256")) as f:
                 digest = f.read().strip()
-            same_cfgs = cfgs is None or not tj.get("conv3x3_configs") or any([int(cfgs[i]) for i in idx3] == v for v in tj["conv3x3_configs"].values())
+            mine = [int(cfgs[i]) for i in idx3] if cfgs is not None else None
+            # the tuner's pick between two implicit-GEMM shapes of a stride-2 layer flips from run to run (a few us apart); the PMC figure
+            # is still this build's and this workload's when at most two of the 19 layers differ -- and the label says how many do
+            differ = 0 if mine is None or not tj.get("conv3x3_configs") else min(
+                (sum(x != y for x, y in zip(mine, v)) if len(v) == len(mine) else 99) for v in tj["conv3x3_configs"].values())
             if (a.variant == "yolov5m" and a.size == 640 and a.precision in ("bf16", "fp8w") and int(tj.get("batch", -1)) == B
-                    and tj.get("library_source_digest") == digest and same_cfgs):
+                    and tj.get("library_source_digest") == digest and differ <= 2):
                 traffic = tj.get("bytes_per_launch")
-                traffic_src = f"{os.path.relpath(a.traffic_json, ROOT)} (separate rocprofv3 --pmc pass of this library build {digest[:12]}, same tuned 3x3 kernels)"
+                traffic_src = (f"{os.path.relpath(a.traffic_json, ROOT)} (separate rocprofv3 --pmc pass of this library build {digest[:12]}; "
+                               + ("same tuned 3x3 kernels)" if differ == 0 else f"the tuner picked another tile shape on {differ} of the {len(mine)} layers in this run)"))
             else:
                 traffic_src = f"null: {os.path.relpath(a.traffic_json, ROOT)} was collected on another build / workload / tuned table"
         except (OSError, ValueError):

@@ -21,8 +21,9 @@ def main():
     ap.add_argument("--stamp", action="store_true", help="run the stamped build once and print per-phase cycle sums per wave")
     ap.add_argument("--abl", default="", help="timing-only ablation builds of the planar kernel to time (comma list of AQ_PL_ABL values)")
     ap.add_argument("--nbs", default="13,10,7", help="pixel-block counts of the planar kernel to time ('' = automatic choice only)")
+    ap.add_argument("--lib", default=None, help="another build of libaqengine.so to time (experiments)")
     a = ap.parse_args()
-    lib = E.load_library()
+    lib = E.load_library(a.lib) if a.lib else E.load_library()
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream
     for (H, W, c) in ((40, 40, 192), (20, 20, 384)):
@@ -116,6 +117,9 @@ def main():
             os.environ.pop("AQ_PL_ABL", None)
             t = buf.cpu().view(-1, 8).double()
             t = t[t[:, 6] > 0]
+            if t.shape[0] == 0:
+                print(f"{c}ch stamped run wrote no rows (variant not built / not selected): skipped", flush=True)
+                continue
             names = ["prologue", "chunk-barrier", "stream", "tile-setup", "epilogue", "chunk-top"]
             life, ticks = t[:, 6], t[:, 7]
             print(f"{c}ch stamped {'asm NB=' + nbs if asm else 'hip'} ABL={sab - 16}: waves {t.shape[0]}  lifetime {life.mean():.0f} cycles (min {life.min():.0f} max {life.max():.0f}) = {ticks.mean() * 10:.0f} ns "
