@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 #include <atomic>
+#include <dlfcn.h>
 #include <vector>
 
 namespace {
@@ -30,6 +31,29 @@ namespace {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr size_t kAlign = 256;
 constexpr int kCoutSlack = 256;   // packed weight rows beyond cout so any BM tile may over-read zeros
+
+// Optional roctx ranges around every plan op (AQ_ROCTX=1; `rocprofv3 --kernel-trace --marker-trace` then shows which kernels belong to
+// which op).  The library is looked up at run time so that libaqengine.so does not depend on the profiler SDK.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    bool tried = false;
+    bool on() {
+        if (!tried) {
+            tried = true;
+            const char* v = getenv("AQ_ROCTX");
+            if (v && *v == '1') {
+                void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+                if (h) {
+                    push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+                    pop = (int (*)())dlsym(h, "roctxRangePop");
+                }
+            }
+        }
+        return push && pop;
+    }
+} g_roctx;
 
 constexpr int kCountStride = 1024;   // ints between the per-image candidate counters of the fused head kernels (4 KB)
 
@@ -235,6 +259,13 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
     for (int oi = 0; oi < n_ops; ++oi) {
         const aq_op_desc& op = e->ops[oi];
         if (ev) AQ_CHECK_HIP(hipEventRecord(ev[oi], stream));
+        const bool mark = g_roctx.on();
+        if (mark) {
+            char name[96];
+            snprintf(name, sizeof name, "aq op %02d kind %d: %d -> %d ch, k%d s%d%s", oi, op.kind, op.src.channels, op.dst.channels, op.k, op.stride,
+                     op.level >= 0 ? " (detect head)" : "");
+            g_roctx.push(name);
+        }
         switch (op.kind) {
         case AQ_OP_PREPROCESS:
             rc = aq_preprocess_s2d(tiles, tptr(e, ws, tiles, op.dst.tensor), B, H, W, prec, stream);
@@ -325,6 +356,7 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
             aq_set_error("unknown op kind %d", op.kind);
             rc = AQ_ERR_INVALID;
         }
+        if (mark) g_roctx.pop();
         if (rc) return rc;
     }
     if (ev) {
