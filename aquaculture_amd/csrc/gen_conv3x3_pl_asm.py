@@ -596,16 +596,14 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         E(f"v_subrev_u32 {T[5]}, {s('tmp2')}, {T[5]}")
         E(f"v_lshl_add_u32 {v('addr', j)}, {T[5]}, 4, {v('qps')}")
         E(f"v_add_u32 {v('addr', j)}, {s('tmp3')}, {v('addr', j)}")
-    # accumulators start from the bias
-    for i in range(3):
-        E(f"v_lshl_add_u32 {T[6]}, {v('q')}, 2, {s('cbase')}")
-        E(f"v_lshlrev_b32 {T[6]}, 2, {T[6]}")
-        E(f"v_add_u32 {T[6]}, {BIAS_OFF}, {T[6]}", "the bias sits behind the ring (beyond the 16-bit DS offset)")
-        E(f"ds_read_b128 {vr('t', 0, 4)}, {T[6]} offset:{64 * i}")
-        E("s_waitcnt lgkmcnt(0)")
-        for j in range(NB):
-            for e in range(4):
-                E(f"v_accvgpr_write_b32 a{4 * (3 * j + i) + e}, {v('t', e)}")
+    # accumulators start from the bias: LDS reads straight into the accumulator registers (3 NB reads instead of 12 NB register moves)
+    E(f"v_lshl_add_u32 {T[6]}, {v('q')}, 2, {s('cbase')}")
+    E(f"v_lshlrev_b32 {T[6]}, 2, {T[6]}")
+    E(f"v_add_u32 {T[6]}, {BIAS_OFF}, {T[6]}", "the bias sits behind the ring (beyond the 16-bit DS offset)")
+    for j in range(NB):
+        for i in range(3):
+            E(f"ds_read_b128 {acc(i, j)}, {T[6]} offset:{64 * i}")
+    E("s_waitcnt lgkmcnt(0)")
     E(f"s_mov_b32 {s('c')}, 0")
     E(f"s_mov_b32 {s('delta0')}, 0", "the first chunk of a tile starts at tap 0 of its own buffer")
     stamp(PH_SETUP)
