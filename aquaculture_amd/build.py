@@ -49,13 +49,28 @@ def _digest() -> str:
             h.update(open(os.path.join(CSRC, name), "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "aq_engine.h"), "rb").read())
     h.update(repr((SOURCES, COMMON)).encode())
+    # the assembly generator reads experiment switches from the environment at build time: a different kernel is a different digest
+    h.update(repr(sorted((k, v) for k, v in os.environ.items() if k.startswith("AQ_GEN_"))).encode())
     return h.hexdigest()
 
 
-def _assemble_planar(verbose: bool) -> None:
+def llvm_bin(cc: str) -> str:
+    """Directory of the ROCm clang / ld.lld that belong to the hipcc in use (ROCM_PATH, or beside hipcc, or /opt/rocm)."""
+    cands = []
+    if os.environ.get("ROCM_PATH"):
+        cands.append(os.path.join(os.environ["ROCM_PATH"], "lib", "llvm", "bin"))
+    cands.append(os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(cc))), "lib", "llvm", "bin"))
+    cands.append("/opt/rocm/lib/llvm/bin")
+    for d in cands:
+        if os.path.exists(os.path.join(d, "clang")) and os.path.exists(os.path.join(d, "ld.lld")):
+            return d
+    raise RuntimeError(f"ROCm clang / ld.lld not found in any of {cands}")
+
+
+def _assemble_planar(verbose: bool, cc: str) -> None:
     """The hand-scheduled assembly build of the planar 3x3 kernel: generate the .s (gen_conv3x3_pl_asm.py), assemble and link it into a
     gfx950 code object with the ROCm clang / lld, and write it as a byte list that conv3x3_pl.hip embeds (hipModuleLoadData)."""
-    llvm = "/opt/rocm/lib/llvm/bin"
+    llvm = llvm_bin(cc)
     src, obj, co = (os.path.join(CSRC, n) for n in ("conv3x3_pl_asm.s", "conv3x3_pl_asm.o", "conv3x3_pl_asm.hsaco"))
     cmds = [[sys.executable, os.path.join(CSRC, "gen_conv3x3_pl_asm.py"), src],
             [os.path.join(llvm, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-c", src, "-o", obj],
@@ -67,9 +82,11 @@ def _assemble_planar(verbose: bool) -> None:
         if r.returncode != 0:
             raise RuntimeError(f"{cmd[0]} failed:\n{r.stdout}\n{r.stderr}")
     data = open(co, "rb").read()
-    with open(os.path.join(CSRC, "conv3x3_pl_asm_hsaco.inc"), "w") as f:
+    inc = os.path.join(CSRC, "conv3x3_pl_asm_hsaco.inc")
+    with open(inc + ".tmp", "w") as f:
         for i in range(0, len(data), 32):
             f.write(",".join(str(b) for b in data[i:i + 32]) + ",\n")
+    os.replace(inc + ".tmp", inc)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -77,9 +94,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return LIB
+    # ranks (or test workers) that find a stale library at the same time: one builds, the others wait for the lock and find it fresh
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+            return LIB
+        return _build_locked(dig, stamp, verbose)
+
+
+def _build_locked(dig: str, stamp: str, verbose: bool) -> str:
     cc = hipcc()
     objs = []
-    _assemble_planar(verbose)
+    _assemble_planar(verbose, cc)
 
     def compile_one(item):
         src, extra = item
@@ -96,12 +123,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB + ".tmp", *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    with open(stamp, "w") as f:
+    os.replace(LIB + ".tmp", LIB)              # a process that has the old library mapped keeps its inode
+    with open(stamp + ".tmp", "w") as f:
         f.write(dig)
+    os.replace(stamp + ".tmp", stamp)
     return LIB
 
 

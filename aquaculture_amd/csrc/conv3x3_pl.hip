@@ -24,6 +24,7 @@
 //     findings); fragment reads and MFMAs are ordinary code that it schedules and pads for hazards.
 #include "conv_device.h"
 #include <cmath>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -412,8 +413,24 @@ constexpr int kNumPl = sizeof(kPl) / sizeof(kPl[0]);
 bool g_pl_attr[64][kNumPl][2];
 int g_pl_cus[64];
 
-// widest run of padded coordinates any tile of bn pixels needs, halo included
+// widest run of padded coordinates any tile of bn pixels needs, halo included.  O(npix / bn) divisions: remembered per geometry, because
+// every launch asks several times (~1 ms of launch-thread time per step otherwise, invisible to the event-timed tuner)
+int pl_region_rows_uncached(int B, int H, int W, int bn);
 int pl_region_rows(int B, int H, int W, int bn) {
+    struct Entry { int B, H, W, bn, rows; };
+    static Entry cache[64];
+    static int used = 0, next = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < used; ++i)
+        if (cache[i].B == B && cache[i].H == H && cache[i].W == W && cache[i].bn == bn) return cache[i].rows;
+    const int rows = pl_region_rows_uncached(B, H, W, bn);
+    cache[next] = Entry{B, H, W, bn, rows};
+    next = (next + 1) % 64;
+    if (used < 64) ++used;
+    return rows;
+}
+int pl_region_rows_uncached(int B, int H, int W, int bn) {
     const long long npix = (long long)B * H * W;
     auto pp = [&](long long P) { const long long b = P / (H * W), y = (P % (H * W)) / W; return P + b * (H + W + 1) + y; };
     long long worst = 0;

@@ -160,7 +160,15 @@ inline char* tptr(aq_engine* e, void* ws, const uint8_t* tiles, int t) {
     return (char*)ws + e->place[t].offset;
 }
 
-int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStream_t stream, int force_cfg = -1) {
+int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStream_t stream, int force_cfg = -1, bool no_table = false) {
+    if (force_cfg < 0 && !no_table && e->conv_cfg[oi] < 0 && e->tuned_B > 0 && B != e->tuned_B && e->tuned_H == e->lay_H && e->tuned_W == e->lay_W &&
+        e->tuned_cfg[oi] >= 0) {
+        // A table entry was validated (and timed) at tuned_B only.  Should it reject another batch size -- the ragged last batch of a
+        // sweep, a rank with fewer tiles -- that batch runs on the heuristic shape instead of ending the sweep.
+        const int rc = run_conv(e, oi, ws, tiles, B, stream, e->tuned_cfg[oi]);
+        if (rc != AQ_ERR_INVALID) return rc;
+        return run_conv(e, oi, ws, tiles, B, stream, -1, true);
+    }
     const aq_op_desc& op = e->ops[oi];
     const PackedW& pw = e->packed[oi];
     const int prec = e->desc.precision;
@@ -188,7 +196,7 @@ int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStr
     // The tuned table serves EVERY batch size of its tile geometry (a sweep's ragged last batch, a rank with fewer tiles): a kernel's
     // accumulation order per output element does not depend on the batch, so a tile's result no longer depends on which batch it
     // landed in (before, batches of another size fell back to the heuristic kernels and could round differently in bf16).
-    if (cfg < 0 && e->tuned_B > 0 && e->tuned_H == e->lay_H && e->tuned_W == e->lay_W) cfg = e->tuned_cfg[oi];
+    if (cfg < 0 && !no_table && e->tuned_B > 0 && e->tuned_H == e->lay_H && e->tuned_W == e->lay_W) cfg = e->tuned_cfg[oi];
     if (cfg == AQ_CONV_CFG_DIRECT3X3S2) {
         if (pw.direct_cfg != cfg) { aq_set_error("conv op %d has no direct 3x3/s2 form", oi); return AQ_ERR_INVALID; }
         return aq_conv3x3s2_direct(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,

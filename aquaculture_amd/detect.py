@@ -136,7 +136,15 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     labels_dir = str(save_dir / "labels")
     # done-manifest: every rank records the tiles it has finished (fsync'd per batch); --resume skips what ANY rank of the
     # interrupted run recorded (reference idiom: skip-if-exists, src/load_data/tile_tifs.py:40-41 -- which label files cannot express)
-    from .manifest import DoneManifest
+    from .manifest import DoneManifest, check_run_params, file_digest, fsync_dir
+    durable = not tile_scenes and os.environ.get("AQ_NO_FSYNC") != "1"     # (AQ_NO_FSYNC=1: only process kills are covered, as before round 3)
+    if rank == 0 and not tile_scenes:
+        # what the label bytes depend on; --resume refuses to continue a directory written with anything else
+        check_run_params(str(save_dir), {"weights_sha256": file_digest(weights) if os.path.isfile(str(weights)) else str(weights),
+                                         "conf_thres": float(conf_thres), "iou_thres": float(iou_thres), "max_det": int(max_det),
+                                         "imgsz": [int(v) for v in imgsz], "precision": precision, "save_conf": bool(save_conf)}, resume)
+    if world > 1:
+        aqdist.barrier()                                   # nobody processes a tile before rank 0 has accepted the directory
     done_before = DoneManifest.load(str(save_dir)) if resume else set()
     manifest = DoneManifest(str(save_dir), rank)
     if not tile_scenes:
@@ -182,13 +190,16 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                 H, W = hw
                 cnt = counts_h.numpy()
                 det_all = dets_h.numpy()
+                written = []
                 for b, p in enumerate(paths):
                     det = det_all[b, : cnt[b]]
                     ndet += det.shape[0]
                     rows = postprocess.detections_to_rows(det, (H, W), shapes0[b])
                     if save_txt and rows.shape[0]:       # no detections => no file (the consumer relies on it)
-                        with open(os.path.join(labels_dir, Path(p).stem + ".txt"), "wb") as f:     # "wb": a tile processed again after a crash leaves the same bytes
-                            f.write(format_label_rows(rows, save_conf))
+                        f = open(os.path.join(labels_dir, Path(p).stem + ".txt"), "wb")     # "wb": a tile processed again after a crash leaves the same bytes
+                        f.write(format_label_rows(rows, save_conf))
+                        f.flush()
+                        written.append(f)
                         nlab += 1
                     if not quiet:
                         s = f"image {gidx[b] + 1}/{dataset.total} {p}: {H}x{W} "
@@ -198,9 +209,15 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                         with gather_lock:
                             gather.add(torch.full((det.shape[0],), gidx[b], dtype=torch.int32), aqdist.pack_rows(torch.from_numpy(det.copy())))
                 slot_free[slot_id].release()
+                for f in written:                        # the manifest line below vouches for these bytes: on disk first, then their
+                    if durable:                          # directory entries, then the record (a node crash must not leave a recorded
+                        os.fsync(f.fileno())             # tile without its label file -- it would look like "no detections" for good)
+                    f.close()
                 if not tile_scenes:
+                    if durable and written:
+                        fsync_dir(labels_dir)
                     with manifest_lock:
-                        manifest.add(Path(p).stem for p in paths)      # the batch's label files are closed: durable from here on
+                        manifest.add(Path(p).stem for p in paths)
                 with lock:
                     stats["seen"] += len(paths)
                     stats["labels"] += nlab
@@ -273,76 +290,84 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         tune = False                                   # some rank may have no batch to meet the broadcast with
     tune_cache = os.environ.get("AQ_TUNE_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "aquaculture_amd", "tune.json")
     copy_done = []
-    for paths, host, shapes0, buf_i, gidx in source_iter:
-        if err:
-            break
-        t0 = time.perf_counter()
-        slot = k % depth
-        slot_free[slot].acquire()
-        st = streams[slot]
-        with torch.cuda.stream(st):
-            if isinstance(host, tuple):                # scene mode: one upload per scene, tiles cut by the letterbox kernel
-                _, spath, sarr, origins, thw = host
-                if spath != scene_path:                # page-locked source: async copy, its buffer goes back once the copy is done
-                    scene_dev, scene_path = torch.from_numpy(sarr).to(dev, non_blocking=True), spath
-                    scene_ev = torch.cuda.Event()
-                    scene_ev.record(st)
-                    dataset.uploaded(dataset.slot_of[spath], scene_ev)
+    try:
+        for paths, host, shapes0, buf_i, gidx in source_iter:
+            if err:
+                break
+            t0 = time.perf_counter()
+            slot = k % depth
+            slot_free[slot].acquire()
+            st = streams[slot]
+            with torch.cuda.stream(st):
+                if isinstance(host, tuple):                # scene mode: one upload per scene, tiles cut by the letterbox kernel
+                    _, spath, sarr, origins, thw = host
+                    if spath != scene_path:                # page-locked source: async copy, its buffer goes back once the copy is done
+                        scene_dev, scene_path = torch.from_numpy(sarr).to(dev, non_blocking=True), spath
+                        scene_ev = torch.cuda.Event()
+                        scene_ev.record(st)
+                        dataset.uploaded(dataset.slot_of[spath], scene_ev)
+                    else:
+                        st.wait_event(scene_ev)            # another stream uploaded this scene
+                    scene_dev.record_stream(st)
+                    tiles = letterbox_scene_tiles(scene_dev, origins, thw, tuple(imgsz), int(max(ck.stride)), True)
                 else:
-                    st.wait_event(scene_ev)            # another stream uploaded this scene
-                scene_dev.record_stream(st)
-                tiles = letterbox_scene_tiles(scene_dev, origins, thw, tuple(imgsz), int(max(ck.stride)), True)
-            else:
-                tiles = host.to(dev, non_blocking=True)
-                if buf_i is not None:                  # hand the pinned buffer back once its H2D copy has completed
-                    h2d = torch.cuda.Event()
-                    h2d.record(st)
-                    copy_done.append((h2d, buf_i))
-                tiles = letterbox_device(tiles, tuple(imgsz), int(max(ck.stride)), True)
-            if tune:                                   # once, before the pipeline fills
-                tune = False
-                geom = [int(tiles.shape[0]), int(tiles.shape[1]), int(tiles.shape[2])]
-                t_tune = time.perf_counter()
-                box = [geom, eng.autotune(tiles, cache=tune_cache) if rank == 0 else None]
-                if world > 1:
-                    torch.distributed.broadcast_object_list(box, src=0)
-                    if rank != 0 and box[0] == geom:
-                        eng.set_tuned_table(*geom, box[1])
-                if rank == 0:
-                    log(f"autotuned {sum(1 for c in box[1] if c >= 0)} conv layers for batch {geom[0]} x {geom[1]}x{geom[2]} in "
-                        f"{time.perf_counter() - t_tune:.1f}s (table: {tune_cache})")
-            t1 = time.perf_counter()
-            dets, counts = eng.infer(tiles, conf_thres, iou_thres, max_det, slot=slot)
-            B = tiles.shape[0]
-            if pinned[slot] is None or pinned[slot][0].shape[0] < B:
-                pinned[slot] = (torch.empty((max(B, batch_size),), dtype=torch.int32).pin_memory(),
-                                torch.empty((max(B, batch_size), max_det, 6), dtype=torch.float32).pin_memory())
-            counts_h, dets_h = pinned[slot][0][:B], pinned[slot][1][:B]
-            counts_h.copy_(counts, non_blocking=True)
-            dets_h.copy_(dets, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(st)
-        H, W = int(tiles.shape[1]), int(tiles.shape[2])
-        shape_str = f"(1, 3, {H}, {W})"
-        t2 = time.perf_counter()
-        q.put((ev, counts_h, dets_h, paths, shapes0, (H, W), list(gidx), t2 - t1, slot))
-        while copy_done and (copy_done[0][0].query() or len(copy_done) > depth):
-            ev_, bi_ = copy_done.pop(0)
-            ev_.synchronize()
-            (release_of[0] or dataset.release)(bi_)
-        t_pre += t1 - t0
-        t_inf += t2 - t1
-        k += 1
-        if world > 1 and k % flush_every == 0:         # bounded gather: rows leave the host lists every few batches (collective)
-            with gather_lock:
-                gather.flush(more=True, failed=bool(err))
+                    tiles = host.to(dev, non_blocking=True)
+                    if buf_i is not None:                  # hand the pinned buffer back once its H2D copy has completed
+                        h2d = torch.cuda.Event()
+                        h2d.record(st)
+                        copy_done.append((h2d, buf_i))
+                    tiles = letterbox_device(tiles, tuple(imgsz), int(max(ck.stride)), True)
+                if tune:                                   # once, before the pipeline fills
+                    tune = False
+                    geom = [int(tiles.shape[0]), int(tiles.shape[1]), int(tiles.shape[2])]
+                    t_tune = time.perf_counter()
+                    box = [geom, eng.autotune(tiles, cache=tune_cache) if rank == 0 else None]
+                    if world > 1:
+                        torch.distributed.broadcast_object_list(box, src=0)
+                        if rank != 0 and box[0] == geom:
+                            eng.set_tuned_table(*geom, box[1])
+                    if rank == 0:
+                        log(f"autotuned {sum(1 for c in box[1] if c >= 0)} conv layers for batch {geom[0]} x {geom[1]}x{geom[2]} in "
+                            f"{time.perf_counter() - t_tune:.1f}s (table: {tune_cache})")
+                t1 = time.perf_counter()
+                dets, counts = eng.infer(tiles, conf_thres, iou_thres, max_det, slot=slot)
+                B = tiles.shape[0]
+                if pinned[slot] is None or pinned[slot][0].shape[0] < B:
+                    pinned[slot] = (torch.empty((max(B, batch_size),), dtype=torch.int32).pin_memory(),
+                                    torch.empty((max(B, batch_size), max_det, 6), dtype=torch.float32).pin_memory())
+                counts_h, dets_h = pinned[slot][0][:B], pinned[slot][1][:B]
+                counts_h.copy_(counts, non_blocking=True)
+                dets_h.copy_(dets, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(st)
+            H, W = int(tiles.shape[1]), int(tiles.shape[2])
+            shape_str = f"(1, 3, {H}, {W})"
+            t2 = time.perf_counter()
+            q.put((ev, counts_h, dets_h, paths, shapes0, (H, W), list(gidx), t2 - t1, slot))
+            while copy_done and (copy_done[0][0].query() or len(copy_done) > depth):
+                ev_, bi_ = copy_done.pop(0)
+                ev_.synchronize()
+                (release_of[0] or dataset.release)(bi_)
+            t_pre += t1 - t0
+            t_inf += t2 - t1
+            k += 1
+            if world > 1 and k % flush_every == 0:         # bounded gather: rows leave the host lists every few batches (collective)
+                with gather_lock:
+                    gather.flush(more=True, failed=bool(err))
+    except BaseException as e:   # anything the main loop raises (engine, autotune, a decode error, another rank's RankFailed) ends the sweep
+        err.append(e)            # HERE, but only after the writers are joined and the other ranks have been told (the collective tail below)
     for _ in wts:
         q.put(None)
     for w_ in wts:
         w_.join()
     if world > 1:                                      # collective tail; a failed rank takes the others down with it at once
-        gather.finish(failed=bool(err))
-    if err:
+        try:
+            with gather_lock:
+                gather.finish(failed=bool(err))
+        except aqdist.RankFailed:
+            if not err:                                # another rank failed: that IS this rank's error
+                raise
+    if err:                                            # this rank's own error, with its traceback (not the RankFailed its flag just raised here too)
         raise err[0]
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start

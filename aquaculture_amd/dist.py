@@ -74,6 +74,7 @@ class DetectionGather:
         self.total = 0
         self.flushes = 0
         self.max_rows_per_flush = 0
+        self.aborted = False          # a flush has raised RankFailed: every rank saw the same flag in the same all_gather, none flushes again
 
     def add(self, tile_index: torch.Tensor, rows: torch.Tensor) -> None:
         if rows.shape[0]:
@@ -88,6 +89,8 @@ class DetectionGather:
         idx = torch.cat(self._idx) if self._idx else torch.zeros((0,), dtype=torch.int32)
         rows = torch.cat(self._rows) if self._rows else torch.zeros((0, ROW), dtype=torch.float32)
         self._idx, self._rows = [], []
+        if self.aborted:              # the run is over on every rank; a later flush / finish (an error path's tail) must not start a collective
+            return False              # that the ranks which have already left would never join
         self.flushes += 1
         if not self.on:
             self._keep(idx, rows)
@@ -98,6 +101,7 @@ class DetectionGather:
         dist.all_gather(every, me)
         counts = [int(e[0]) for e in every]
         if any(int(e[2]) for e in every):
+            self.aborted = True
             raise RankFailed(f"rank(s) {[r for r, e in enumerate(every) if int(e[2])]} failed; rank {self.rank} stops at flush {self.flushes}")
         m = max(counts)
         self.max_rows_per_flush = max(self.max_rows_per_flush, m)

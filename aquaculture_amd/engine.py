@@ -311,6 +311,10 @@ class Engine:
         B, H, W = self._check_tiles(tiles)
         key = (f"{self.ck.variant}:nc{self.ck.nc}:p{self.precision}:{B}x{H}x{W}:n{self.lib.aq_conv_num_configs()}"
                f":v{self.lib.aq_version()}:ops{len(self.plan.ops)}")   # library version + plan shape: new kernels invalidate old tables
+        # kernels switched off by the environment are not in the candidate set: such a run has a table of its own
+        off = ",".join(sorted(f"{k}={v}" for k, v in os.environ.items() if k.startswith("AQ_DISABLE_") or k in ("AQ_PL_W8", "AQ_PL_ASM", "AQ_PL_NB")))
+        if off:
+            key += ":" + off
         table = {}
         if cache and os.path.exists(cache):
             try:
@@ -319,8 +323,11 @@ class Engine:
             except (OSError, ValueError):      # unreadable or half-written by another rank: tune again
                 table = {}
             if key in table and len(table[key]) == len(self.plan.ops):
-                self.set_tuned_table(B, H, W, table[key])
-                return list(table[key])
+                try:
+                    self.set_tuned_table(B, H, W, table[key])
+                    return list(table[key])
+                except RuntimeError:           # an entry this build / environment has no kernel for: tune again, replace the entry
+                    pass
         ws = self.workspace(B, H, W)
         _check(self.lib.aq_engine_autotune(self.handle, tiles.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(), reps, _stream_ptr()))
         cfgs = [self.lib.aq_engine_get_conv_config(self.handle, i) for i in range(len(self.plan.ops))]

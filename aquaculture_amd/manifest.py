@@ -8,12 +8,61 @@ in the run directory, fsync'd once per batch; `--resume` reads every rank's file
 drops those tiles from the listing before sharding.  A record is one line = one tile stem; a line cut short by a crash (no trailing
 newline) is ignored, so a tile is either recorded after its label file is complete or processed again (label files are written with
 "wb": processing a tile twice leaves the same bytes).
+
+Durability: the manifest line vouches for the label file, so the file must reach the disk first -- detect.py fsyncs every label file of
+a batch and then the labels directory (the new directory entries) before `add`, which fsyncs the manifest; a node crash or power loss
+can therefore lose unrecorded work but never leave a recorded tile without its label bytes.  `run_params.json` beside the manifests
+holds what the labels depend on (weights digest, thresholds, image size, precision); `--resume` refuses a directory written with
+other settings instead of mixing two runs' labels.
 """
 from __future__ import annotations
 
 import glob
+import hashlib
+import json
 import os
-from typing import Iterable, Set
+from typing import Dict, Iterable, Set
+
+
+def fsync_dir(path: str) -> None:
+    """New directory entries (files created in `path`) reach the disk."""
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        os.fsync(fd)
+    finally:
+        os.close(fd)
+
+
+def file_digest(path: str) -> str:
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for piece in iter(lambda: f.read(1 << 20), b""):
+            h.update(piece)
+    return h.hexdigest()
+
+
+class RunParamsMismatch(RuntimeError):
+    """--resume into a directory whose labels were written with other settings."""
+
+
+def check_run_params(directory: str, params: Dict, resume: bool) -> None:
+    """Rank 0, before any tile is processed: on --resume compare `params` with the interrupted run's record and refuse a mismatch
+    (a directory without a record -- written by an older build -- is accepted and gets one); otherwise (re)write the record."""
+    path = os.path.join(directory, "run_params.json")
+    if resume and os.path.exists(path):
+        with open(path) as f:
+            old = json.load(f)
+        diff = {k: (old.get(k), params.get(k)) for k in sorted(set(old) | set(params)) if old.get(k) != params.get(k)}
+        if diff:
+            raise RunParamsMismatch(f"--resume: {directory} was written with other settings (recorded, now): {diff}")
+        return
+    tmp = path + ".tmp"
+    with open(tmp, "w") as f:
+        json.dump(params, f, indent=1, sort_keys=True)
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(tmp, path)
+    fsync_dir(directory)
 
 
 class DoneManifest:
@@ -31,7 +80,8 @@ class DoneManifest:
         self._f = open(self.path, "ab")
 
     def add(self, stems: Iterable[str]) -> None:
-        """One batch: durable when this returns (the label files of these tiles must be closed before the call)."""
+        """One batch: durable when this returns (the label files of these tiles must be on disk -- fsync'd, and their directory too --
+        before the call)."""
         data = "".join(s + "\n" for s in stems).encode()
         if not data:
             return

@@ -56,6 +56,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle sample budget")
     p.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristic instead of timing configs")
     p.add_argument("--no-profile", action="store_true", help="skip per-op HIP events (roofline becomes null)")
+    p.add_argument("--launcher-selftest", action="store_true", help="run only the rank launch / rendezvous / reduction plumbing (no GPU work)")
     p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"),
                    help="optional PMC-derived HBM bytes per launch for the dominant kernel")
     return p.parse_args()
@@ -102,8 +103,81 @@ def cpu_baseline(ck, size: int, budget_s: float) -> dict:
                       f"median {1e3 * float(np.median(per)):.0f} ms/tile, {torch.get_num_threads()} threads of os.cpu_count()={os.cpu_count()}"}
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` typed by hand (no torchrun around it): the parent starts N children of this same command line, one
+    per GPU, with the torchrun-style environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), forwards rank 0's JSON
+    line and exits with the worst child's code.  The parent itself never touches a GPU (no HIP call, no torch.cuda query) and never
+    exec()s; a failed child is reported, the others are stopped by PID, nothing is retried."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                       # a free rendezvous port (closed again before the children bind it)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this image
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    got = []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)    # rank 0 prints the one line
+    reader.start()
+    rcs = [None] * n
+    deadline = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad and deadline is None:
+            deadline = time.monotonic() + 30.0        # the survivors get half a minute to notice (RankFailed / backend error) ...
+        if deadline is not None and time.monotonic() > deadline:
+            for r, p in enumerate(procs):             # ... then are stopped, each by its own PID
+                if rcs[r] is None:
+                    p.kill()
+                    rcs[r] = p.wait()
+        time.sleep(0.05)
+    worst = max(rcs, key=lambda rc: (rc != 0, abs(rc)))
+    if worst != 0:
+        print(f"bench: rank exit codes {rcs}", file=sys.stderr)
+        return worst if worst > 0 else 1
+    reader.join(10.0)
+    for line in (got[0].decode() if got else "").splitlines():
+        # the JSON line to stdout; whatever a backend chose to print on rank 0's stdout (gloo's connection notes) to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
+    sys.stdout.flush()
+    return 0
+
+
+def launcher_selftest() -> int:
+    """--launcher-selftest: what the N > 1 launch path does around the GPU work -- rendezvous, barrier, max-over-ranks reduction, one
+    line from rank 0 -- with nothing that needs a GPU in between (tests/test_bench_launcher.py runs it on the CPU with gloo)."""
+    from aquaculture_amd import dist as aqdist
+    a = parse()
+    rank, world, _ = aqdist.init(os.environ.get("AQ_DIST_BACKEND") or "gloo")
+    if world != a.gpus:
+        print(f"bench: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    if os.environ.get("AQ_SELFTEST_FAIL_RANK") == str(rank):
+        return 7
+    aqdist.barrier()
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    aqdist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "launcher selftest", "n_gpus": world, "max_over_ranks": float(t[0])}), flush=True)
+    return 0
+
+
 def main() -> int:
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a.gpus)
+    if a.launcher_selftest:
+        return launcher_selftest()
     from aquaculture_amd import checkpoint, dist as aqdist, spec
     from aquaculture_amd import engine as aqengine
     from aquaculture_amd.engine import Engine

@@ -100,6 +100,49 @@ def test_failed_rank_aborts_the_others(tmp_path):
     assert all(r.startswith("aborted after 1 flush") for r in res), res
 
 
+def _main_loop_failure_worker(rank, world, port, out):
+    """The tail of detect.run: the failing rank's error comes from its MAIN loop, is recorded, reported through the gather
+    inside try/except RankFailed, and then re-raised as itself; the others see RankFailed at their next flush and their own tail's
+    finish() starts no further collective (the failing rank has left by then)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    aqdist.init("gloo")
+    g = aqdist.DetectionGather(torch.device("cpu"))
+    err = []
+    try:
+        for k in range(40):
+            if rank == 1 and k == 5:
+                raise ValueError("engine error in the main loop")
+            g.add(torch.zeros(2, dtype=torch.int32), torch.ones(2, aqdist.ROW))
+            if (k + 1) % 4 == 0:
+                g.flush(more=True)
+    except BaseException as e:
+        err.append(e)
+    res = "finished"
+    try:
+        try:
+            g.finish(failed=bool(err))
+        except aqdist.RankFailed:
+            if not err:
+                raise
+        if err:
+            raise err[0]
+    except BaseException as e:
+        res = f"{type(e).__name__}: {e} [flushes {g.flushes}, aborted {g.aborted}]"
+    with open(f"{out}.{rank}", "w") as f:
+        f.write(res)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_main_loop_failure_keeps_its_own_exception(tmp_path):
+    out = str(tmp_path / "res")
+    mp.spawn(_main_loop_failure_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    res = [open(f"{out}.{r}").read() for r in range(3)]
+    assert res[1].startswith("ValueError: engine error in the main loop") and "aborted True" in res[1], res
+    for r in (0, 2):                                  # stopped at the flush the failing rank answered (its 2nd: one periodic flush, then finish)
+        assert res[r].startswith("RankFailed") and "flushes 2" in res[r], res
+
+
 def test_shard_is_a_partition():
     for n, w in ((10, 1), (10, 3), (7, 8), (1000003, 8)):
         parts = [aqdist.shard_indices(n, r, w) for r in range(w)]

@@ -284,6 +284,13 @@ def test_cli_resume_skips_recorded_tiles(workdir, lib):
     for f in os.listdir(full):
         assert open(labels / f, "rb").read() == open(full / f, "rb").read(), f
     assert sorted(open(run / "done.rank0.txt").read().split()) == sorted(n[:-5] for n in names)
+    # a resume with other settings is refused before any tile is touched: the labels of two configurations never mix
+    import json
+    assert json.load(open(run / "run_params.json"))["conf_thres"] == 0.25
+    before = {f: open(labels / f, "rb").read() for f in os.listdir(labels)}
+    r = subprocess.run(cmd[:-4] + ["--name", "resume_run", "--batch-size", "4", "--resume", "--conf-thres", "0.6"], capture_output=True, text=True, timeout=420)
+    assert r.returncode != 0 and "RunParamsMismatch" in r.stderr and "conf_thres" in r.stderr, r.stderr[-2000:]
+    assert {f: open(labels / f, "rb").read() for f in os.listdir(labels)} == before
 
 
 def test_cli_mixed_tile_sizes_do_not_end_the_sweep(tmp_path, lib, workdir):

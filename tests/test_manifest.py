@@ -116,3 +116,30 @@ def test_loadimages_skip_keeps_global_numbering_and_subset(tmp_path):
     assert sizes.count((8, 8)) == 10 and sizes[10] == (9, 5)
     sub = ds.subset([10, 2])
     assert sub.indices == [10, 2] and [os.path.basename(f) for f in sub.files] == ["TILE_0010.png", "TILE_0002.png"] and len(ds) == 11
+
+
+def test_run_params_record_refuses_a_resume_with_other_settings(tmp_path):
+    """labels written with different weights / thresholds / image size must not be mixed in one directory."""
+    import json
+    import pytest
+    from aquaculture_amd.manifest import RunParamsMismatch, check_run_params, file_digest
+    run = str(tmp_path / "run")
+    os.makedirs(run)
+    w = str(tmp_path / "w.pt")
+    open(w, "wb").write(b"weights v1")
+    params = {"weights_sha256": file_digest(w), "conf_thres": 0.25, "iou_thres": 0.45, "max_det": 1000, "imgsz": [640, 640], "precision": "bf16", "save_conf": True}
+    check_run_params(run, params, resume=False)
+    assert json.load(open(os.path.join(run, "run_params.json"))) == params
+    check_run_params(run, dict(params), resume=True)                         # same settings: accepted
+    with pytest.raises(RunParamsMismatch, match="conf_thres"):
+        check_run_params(run, dict(params, conf_thres=0.5), resume=True)
+    open(w, "wb").write(b"weights v2")
+    with pytest.raises(RunParamsMismatch, match="weights_sha256"):
+        check_run_params(run, dict(params, weights_sha256=file_digest(w)), resume=True)
+    assert json.load(open(os.path.join(run, "run_params.json"))) == params   # a refused resume leaves the record alone
+    check_run_params(run, dict(params, conf_thres=0.5), resume=False)        # a fresh run (--exist-ok) overwrites it
+    assert json.load(open(os.path.join(run, "run_params.json")))["conf_thres"] == 0.5
+    old = str(tmp_path / "old_run")                                          # a directory from before the record existed: accepted, recorded
+    os.makedirs(old)
+    check_run_params(old, params, resume=True)
+    assert os.path.exists(os.path.join(old, "run_params.json"))
