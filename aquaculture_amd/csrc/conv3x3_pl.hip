@@ -391,8 +391,9 @@ struct PlAsmArgs {                 // must match ARG in gen_conv3x3_pl_asm.py
     int CC, mt_log2, ntiles, G;
     float inv_hw, inv_w, inv_hpwp, inv_wp;
     unsigned long long* debug;
+    long long in_row;                 // stride-2 family: bytes per INPUT image row (H, W, npix are the OUTPUT's there)
 };
-static_assert(sizeof(PlAsmArgs) == 136, "kernel argument block");
+static_assert(sizeof(PlAsmArgs) == 144, "kernel argument block");
 const unsigned char kPlAsmCode[] = {
 #include "conv3x3_pl_asm_hsaco.inc"
 };
@@ -402,6 +403,8 @@ const PlAsmFamily kPlAsm[] = {{13, 384, 1}, {7, 256, 2}, {8, 256, 2}};
 constexpr int kNumPlAsm = sizeof(kPlAsm) / sizeof(kPlAsm[0]);
 hipModule_t g_pl_asm_mod[64];
 hipFunction_t g_pl_asm_fn[64][kNumPlAsm][5];     // res0, res1, res1 stamped, and (NB = 13 only) the fp8-weight res0, res1
+hipFunction_t g_pl_s2_fn[64][2];                 // stride-2 family (s2nb13): plain, stamped
+constexpr int PL_S2_NB = 13, PL_S2_ROWS = 304;   // gen_conv3x3_pl_asm.py CONFIGS["s2nb13"]
 
 struct PlKernel { int nb; void (*plain)(const PlParams); void (*res)(const PlParams); };
 struct PlAblation { int abl; void (*fn)(const PlParams); };
@@ -416,7 +419,7 @@ int g_pl_cus[64];
 // widest run of padded coordinates any tile of bn pixels needs, halo included.  O(npix / bn) divisions: remembered per geometry, because
 // every launch asks several times (~1 ms of launch-thread time per step otherwise, invisible to the event-timed tuner)
 int pl_region_rows_uncached(int B, int H, int W, int bn);
-int pl_region_rows(int B, int H, int W, int bn) {
+int pl_region_rows(int B, int H, int W, int bn) {          // (bn < 0: the one-sided halo of the stride-2 family, -bn pixels per tile)
     struct Entry { int B, H, W, bn, rows; };
     static Entry cache[64];
     static int used = 0, next = 0;
@@ -431,15 +434,34 @@ int pl_region_rows(int B, int H, int W, int bn) {
     return rows;
 }
 int pl_region_rows_uncached(int B, int H, int W, int bn) {
+    const int halos = bn < 0 ? 1 : 2;
+    if (bn < 0) bn = -bn;
     const long long npix = (long long)B * H * W;
     auto pp = [&](long long P) { const long long b = P / (H * W), y = (P % (H * W)) / W; return P + b * (H + W + 1) + y; };
     long long worst = 0;
     for (long long n0 = 0; n0 < npix; n0 += bn) {
         const long long n1 = (n0 + bn - 1 < npix - 1) ? n0 + bn - 1 : npix - 1;
-        const long long span = pp(n1) - pp(n0) + 1 + 2 * (W + 2);
+        const long long span = pp(n1) - pp(n0) + 1 + halos * (W + 2);
         if (span > worst) worst = span;
     }
     return (int)worst;
+}
+
+int pl_load_module(int dev) {
+    if (g_pl_asm_mod[dev]) return AQ_OK;
+    hipModule_t mod = nullptr;
+    AQ_CHECK_HIP(hipModuleLoadData(&mod, kPlAsmCode));
+    for (int i = 0; i < kNumPlAsm; ++i)
+        for (int v = 0; v < (kPlAsm[i].nb == 13 ? 5 : 3); ++v) {
+            char name[64];
+            snprintf(name, sizeof name, "conv3x3_pl_asm_nb%d_res%d%s", kPlAsm[i].nb, v == 0 || v == 3 ? 0 : 1,
+                     v == 2 ? "_stamped" : v >= 3 ? "_w8" : "");
+            AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_asm_fn[dev][i][v], mod, name));
+        }
+    AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_s2_fn[dev][0], mod, "conv3x3_pl_asm_s2nb13_res0"));
+    AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_s2_fn[dev][1], mod, "conv3x3_pl_asm_s2nb13_res0_stamped"));
+    g_pl_asm_mod[dev] = mod;
+    return AQ_OK;
 }
 
 }  // namespace
@@ -552,16 +574,7 @@ static int pl_conv(const void* in_dev, long long in_sp, long long in_ss, int cin
     AQ_REQUIRE(ntiles > 0 && ntiles < (1LL << 30), "conv3x3_pl: bad tile count");
     p.ntiles = (int)ntiles;
     if (fam >= 0) {
-        if (!g_pl_asm_mod[dev]) {
-            AQ_CHECK_HIP(hipModuleLoadData(&g_pl_asm_mod[dev], kPlAsmCode));
-            for (int i = 0; i < kNumPlAsm; ++i)
-                for (int v = 0; v < (kPlAsm[i].nb == 13 ? 5 : 3); ++v) {
-                    char name[64];
-                    snprintf(name, sizeof name, "conv3x3_pl_asm_nb%d_res%d%s", kPlAsm[i].nb, v == 0 || v == 3 ? 0 : 1,
-                             v == 2 ? "_stamped" : v >= 3 ? "_w8" : "");
-                    AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_asm_fn[dev][i][v], g_pl_asm_mod[dev], name));
-                }
-        }
+        { const int rc = pl_load_module(dev); if (rc) return rc; }
         long long grid = (long long)g_pl_cus[dev] * kPlAsm[fam].occ;
         if (grid > ntiles) grid = ntiles;
         PlAsmArgs a{};
@@ -706,4 +719,107 @@ extern "C" int aq_conv3x3_pl_w8(const void* in_dev, long long in_sp, long long i
                                 const float* scale_bias_dev, int B, int H, int W, int act, void* stream) {
     return pl_conv(in_dev, in_sp, in_ss, cin, out_dev, out_ld, out_choff, cout, res_dev, res_ld, res_choff, packed_w8_dev, scale_bias_dev, B, H, W,
                    act, stream, true);
+}
+
+
+// ---- stride 2 (round 3): the same planar scheme on the four PARITY planes of the input (gen_conv3x3_pl_asm.py, family s2nb13) --------------
+// 3x3 / stride 2 / pad 1, bf16, Cin a multiple of 32 (32-channel chunks, one k-step per tap), Cout a multiple of 192 with Cout / 192 a power
+// of two, even H and W: yolov5m's model.5 / 7 / 18 / 21 ([UPSTREAM models/common.py Conv.forward_fuse], reference README.md:77).  Assembly
+// only: the implicit-GEMM kernels remain the fallback and the comparand (tests/test_gpu_conv.py).
+extern "C" int aq_conv3x3_pl_s2_supported(int cin, int cout, int B, int H, int W) {
+    if (cin < 64 || cin % 32 || cout % PL_BM || cout > 960 || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return 0;
+    const int n_mt = cout / PL_BM;
+    if (n_mt & (n_mt - 1)) return 0;
+    if ((long long)B * (H / 2 + 1) * (W / 2 + 1) + W / 2 + 2 >= (1LL << 23)) return 0;
+    return pl_region_rows(B, H / 2, W / 2, -PL_S2_NB * 16) <= PL_S2_ROWS;
+}
+
+// [M tile][wave][32-channel chunk][tap][M block i][lane] x 8 bf16: lane (r = lane & 15, g = lane >> 4) holds output channel
+// 192 mt + 48 wave + 16 i + r and input channels 32 chunk + 8 g .. + 7 of that tap (KRSC source, as aq_pack_conv3x3_pl)
+extern "C" int aq_pack_conv3x3_pl_s2(const float* w_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream) {
+    AQ_REQUIRE(w_host && bytes && cin % 32 == 0 && cout % PL_BM == 0, "pack_conv3x3_pl_s2: unsupported %d -> %d", cin, cout);
+    const int n_mt = cout / PL_BM, CC = cin / 32;
+    *bytes = (size_t)n_mt * 4 * CC * 9 * 3072;
+    if (!packed_dev) return AQ_OK;
+    bf16_t* host = (bf16_t*)calloc(1, *bytes);
+    AQ_REQUIRE(host, "pack_conv3x3_pl_s2: out of host memory");
+    bf16_t* dst = host;
+    for (int mt = 0; mt < n_mt; ++mt)
+        for (int wv = 0; wv < 4; ++wv)
+            for (int c = 0; c < CC; ++c)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int i = 0; i < 3; ++i)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int co = mt * PL_BM + wv * 48 + i * 16 + (lane & 15);
+                            const int ci = 32 * c + 8 * (lane >> 4);
+                            const float* src = w_host + ((size_t)co * 9 + tap) * cin + ci;
+                            for (int e = 0; e < 8; ++e) *dst++ = aq_f2bf(src[e]);
+                        }
+    hipError_t e = hipMemcpyAsync(packed_dev, host, *bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    free(host);
+    AQ_CHECK_HIP(e);
+    return AQ_OK;
+}
+
+// in: NHWC bf16, B x H x W pixels of in_ld channels, the conv's cin channels from in_choff (a multiple of 8); out: NHWC bf16
+// B x H/2 x W/2 x out_ld, cout channels from out_choff.
+extern "C" int aq_conv3x3_pl_s2(const void* in_dev, int in_ld, int in_choff, int cin, void* out_dev, int out_ld, int out_choff, int cout,
+                                const void* packed_w_dev, const float* bias_dev, int B, int H, int W, int act, void* stream) {
+    AQ_REQUIRE(in_dev && out_dev && packed_w_dev && bias_dev, "conv3x3_pl_s2: null pointer");
+    AQ_REQUIRE(aq_conv3x3_pl_s2_supported(cin, cout, B, H, W), "conv3x3_pl_s2: unsupported %d -> %d on %d x %d x %d", cin, cout, B, H, W);
+    AQ_REQUIRE(in_choff % 8 == 0 && in_choff + cin <= in_ld && in_ld % 8 == 0 && out_ld % 4 == 0 && out_choff % 4 == 0 && out_choff + cout <= out_ld,
+               "conv3x3_pl_s2: slices must be 16-byte (input) / 8-byte (output) aligned and inside their rows");
+    const int Ho = H / 2, Wo = W / 2;
+    AQ_REQUIRE((long long)B * Ho * Wo * out_ld * 2 < (1LL << 31) && (long long)B * H * W * in_ld * 2 < (1LL << 32),
+               "conv3x3_pl_s2: tensors beyond the 32-bit offset range");
+    int dev = 0;
+    AQ_CHECK_HIP(hipGetDevice(&dev));
+    AQ_REQUIRE(dev >= 0 && dev < 64, "conv3x3_pl_s2: device ordinal %d", dev);
+    if (g_pl_cus[dev] == 0) {
+        int cus = 256;
+        AQ_CHECK_HIP(aq_query_cus(&cus, dev));
+        g_pl_cus[dev] = cus;
+    }
+    { const int rc = pl_load_module(dev); if (rc) return rc; }
+    PlAsmArgs a{};
+    a.in = (const char*)in_dev + (size_t)in_choff * 2; a.in_sp = (long long)in_ld * 2; a.in_ss = 16;
+    a.in_row = (long long)W * in_ld * 2;
+    a.out = (char*)out_dev + (size_t)out_choff * 2; a.out_ld_b = out_ld * 2;
+    a.w = (const char*)packed_w_dev; a.bias = bias_dev;
+    a.zero = aq_zero_page();
+    AQ_REQUIRE(a.zero, "conv3x3_pl_s2: zero page allocation failed");
+    a.B = B; a.H = Ho; a.W = Wo; a.npix = B * Ho * Wo; a.cout = cout; a.act = act;
+    a.CC = cin / 32;
+    const int n_mt = cout / PL_BM;
+    while ((1 << a.mt_log2) < n_mt) ++a.mt_log2;
+    const int bn = PL_S2_NB * 16;
+    const long long ntiles = ((long long)a.npix + bn - 1) / bn * n_mt;
+    AQ_REQUIRE(ntiles > 0 && ntiles < (1LL << 30), "conv3x3_pl_s2: bad tile count");
+    a.ntiles = (int)ntiles;
+    long long grid = g_pl_cus[dev];
+    if (grid > ntiles) grid = ntiles;
+    a.G = (int)grid;
+    a.inv_hw = 1.0f / (float)(Ho * Wo); a.inv_w = 1.0f / (float)Wo;
+    a.inv_hpwp = 1.0f / (float)((Ho + 1) * (Wo + 1)); a.inv_wp = 1.0f / (float)(Wo + 1);
+    hipFunction_t fn = g_pl_s2_fn[dev][0];
+    const char* use_asm = getenv("AQ_PL_ASM");
+    if (use_asm && *use_asm == '2') {                          // stamped diagnostic build (tools/time_conv3x3.py --stamp): per-wave phase cycle sums
+        size_t sbytes = 0;
+        unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
+        if (sbuf && sbytes >= (size_t)grid * 4 * 64) {
+            a.debug = sbuf;
+            fn = g_pl_s2_fn[dev][1];
+            const char* asm_abl = getenv("AQ_PL_ASM_ABL");    // timing-only ablations of the stamped build (wrong results)
+            if (asm_abl && *asm_abl) {
+                char name[80];
+                snprintf(name, sizeof name, "conv3x3_pl_asm_s2nb13_res0_stamped_abl%d", atoi(asm_abl));
+                AQ_CHECK_HIP(hipModuleGetFunction(&fn, g_pl_asm_mod[dev], name));
+            }
+        }
+    }
+    size_t asz = sizeof(a);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+    AQ_CHECK_HIP(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
+    return AQ_OK;
 }

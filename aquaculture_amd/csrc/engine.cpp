@@ -62,7 +62,7 @@ struct PackedW {
     float* bias = nullptr;  // [cout_rows]
     int kgroups = 0, kgroups_pad = 0, G = 0, cout_rows = 0;
     void* w_direct = nullptr;   // layers a direct kernel supports: its A-fragment image (csrc/conv1x1_direct.hip, csrc/downblock.hip)
-    int direct_cfg = -1;        // AQ_CONV_CFG_DIRECT1X1 / AQ_CONV_CFG_DIRECT3X3S2 / AQ_CONV_CFG_PL3X3
+    int direct_cfg = -1;        // AQ_CONV_CFG_DIRECT1X1 / AQ_CONV_CFG_DIRECT3X3S2 / AQ_CONV_CFG_PL3X3 / AQ_CONV_CFG_PL3X3S2
     void* w_head = nullptr;     // bf16 engines, Detect head convs with a small head: aq_pack_head_weights image (csrc/head_decode.hip)
     void* w_pl8 = nullptr;      // AQ_BF16_W8 engines, planar 3x3 layers: the e4m3 code stream and its float[2048] bias x 2^-e | 2^e
     float* sb_pl8 = nullptr;
@@ -217,6 +217,16 @@ int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStr
                              op.res.tensor >= 0 ? tptr(e, ws, tiles, op.res.tensor) : nullptr,
                              op.res.tensor >= 0 ? e->tensors[op.res.tensor].channels : 0, op.res.ch_off,
                              pw.w_direct, pw.bias, B, ps.h, ps.w, op.act, stream);
+    }
+    if (cfg == AQ_CONV_CFG_PL3X3S2) {
+        if (pw.direct_cfg != cfg) { aq_set_error("conv op %d has no planar 3x3/s2 form", oi); return AQ_ERR_INVALID; }
+        if (!aq_conv3x3_pl_s2_supported(op.src.channels, op.dst.channels, B, ps.h, ps.w)) {      // (the tile's region depends on the image width)
+            aq_set_error("conv op %d: planar 3x3/s2 does not fit %d x %d x %d", oi, B, ps.h, ps.w);
+            return AQ_ERR_INVALID;
+        }
+        return aq_conv3x3_pl_s2(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off, op.src.channels,
+                                tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off, op.dst.channels,
+                                pw.w_direct, pw.bias, B, ps.h, ps.w, op.act, stream);
     }
     if (cfg == AQ_CONV_CFG_DIRECT1X1) {
         if (pw.direct_cfg != cfg) { aq_set_error("conv op %d has no direct 1x1 form", oi); return AQ_ERR_INVALID; }
@@ -570,6 +580,19 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
                 return fail(AQ_ERR_HIP);
             }
             pw.direct_cfg = AQ_CONV_CFG_DIRECT3X3S2;
+        }
+        const char* no_pl2 = getenv("AQ_DISABLE_PL3X3S2");   // A/B switch: keep the planar 3x3/s2 kernel out of the candidate list
+        if (d->precision == AQ_BF16 && op.k == 3 && op.stride == 2 && op.pad == 1 && op.res.tensor < 0 && e->tensors[op.dst.tensor].dtype == AQ_T_ACT &&
+            pw.direct_cfg < 0 && op.src.ch_off % 8 == 0 && e->tensors[op.src.tensor].channels % 8 == 0 && !(no_pl2 && *no_pl2 == '1') &&
+            aq_conv3x3_pl_s2_supported(op.src.channels, op.dst.channels, 1, 2, 2)) {       // channel counts only: the geometry is checked per launch
+            size_t nb = 0;
+            if (aq_pack_conv3x3_pl_s2(op.weight, op.src.channels, op.dst.channels, nullptr, &nb, nullptr) != AQ_OK ||
+                hipMalloc(&pw.w_direct, nb) != hipSuccess ||
+                aq_pack_conv3x3_pl_s2(op.weight, op.src.channels, op.dst.channels, pw.w_direct, &nb, nullptr) != AQ_OK) {
+                aq_set_error("engine_create: planar 3x3/s2 weight upload failed (op %zu)", oi);
+                return fail(AQ_ERR_HIP);
+            }
+            pw.direct_cfg = AQ_CONV_CFG_PL3X3S2;
         }
         const char* no_pl = getenv("AQ_DISABLE_PL3X3");      // A/B switch: keep the planar 3x3 kernel out of the candidate list
         if (d->precision == AQ_BF16 && op.k == 3 && op.stride == 1 && op.pad == 1 && e->tensors[op.dst.tensor].dtype == AQ_T_ACT &&

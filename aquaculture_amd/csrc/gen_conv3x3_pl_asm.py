@@ -48,12 +48,23 @@ import sys
 # residual load (HBM / MALL latency) holds back the weight loads issued behind it: with LOOK = 2 such a load has two taps (2.5 k cycles)
 # before it stalls the stream, and the stamped builds showed exactly that stall; the one-workgroup family keeps its FOUR sets in the
 # accumulator half of the register file (100 AGPRs are free there), which also frees 72 VGPRs for a deeper B ring.
+# KS = k-steps (of 32 channels) per chunk: 2 = the 64-channel chunks of the stride-1 families; 1 = 32-channel chunks.
+# S2 = the stride-2 family (round 3).  A 3x3 / stride 2 / pad 1 convolution reads input pixel (2 oy + dy - 1, 2 ox + dx - 1): split the input
+# into its four PARITY planes (y odd / even x x odd / even), each an image of the OUTPUT's size, and tap (dy, dx) reads plane
+# (dy != 1, dx != 1) at output pixel (oy - (dy == 0), ox - (dx == 0)) -- offsets -1 and 0 only.  So the region is laid out exactly as for
+# stride 1 (padded OUTPUT coordinates, one zero pixel after every row, one zero row after every image; region row 0 = the upper left
+# neighbour of the tile's first pixel), once per parity plane: a chunk = 4 parity planes x 4 slot planes (32 channels) x ROWS rows, the
+# parity split happens in the LDS-DMA's per-lane source address (input pixel 4 P' - 2 x' + 2 W py + px for padded output pixel P' = (b, y',
+# x')), wave w loads parity plane w, and a tap is an immediate LDS offset (parity plane, column) plus ONE address update per chunk (kernel
+# row 0 -> rows 1, 2).  ROWS = 304 = 208 pixels + row pads + an image seam + one-sided halo for W = 20 and 40; the fifth LDS-DMA group
+# overlaps the fourth by 16 rows (GROUPS), so no EXEC mask is needed; two ring buffers (2 x 76 KB + bias = 156 KB).
 CONFIGS = {
-    13: dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False),    # SPLIT=7, DMA_FRONT: measured slower, below
-    7: dict(NB=7, PD=8, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False),
-    8: dict(NB=8, PD=7, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False),
+    13: dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False),    # SPLIT=7, DMA_FRONT: measured slower, below
+    7: dict(NB=7, PD=8, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False),
+    8: dict(NB=8, PD=7, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False),
+    "s2nb13": dict(NB=13, PD=8, ROWS=304, RING=2, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=1, S2=True),
 }
-STEP_B = 6 * 1024          # weight bytes per (wave, tap-step): six 1 KB bf16 fragments ...
+STEP_B = 6 * 1024          # weight bytes per (wave, tap-step): six 1 KB bf16 fragments (KS = 1: three) ...
 W8 = False                 # ... or, in the fp8-weight kernels (set per kernel by gen_kernel), three 1 KB pairs of e4m3 fragments
 
 
@@ -61,21 +72,29 @@ def configure(nb):
     """Sets the module-level tile constants and (re)allocates the registers of one family."""
     g = globals()
     g.update(CONFIGS[nb])
-    g["NE"] = 18 * NB
-    g["NG"] = ROWS // 64
+    g["FAMILY"] = f"nb{nb}" if isinstance(nb, int) else nb
+    g["NE"] = 9 * KS * NB
+    g["GROUPS"] = list(range(0, ROWS - 63, 64)) + ([ROWS - 64] if ROWS % 64 else [])      # first region row of every LDS-DMA group
+    g["NG"] = len(GROUPS)
     g["PS"] = ROWS * 16
-    g["CHUNK"] = 8 * PS
+    g["NPAR"] = 4 if S2 else 1
+    g["SL"] = 4 * KS                           # slot planes (8 channels each) per chunk and parity plane
+    g["PPW"] = NPAR * SL // 4                  # planes each wave loads per chunk
+    g["CHUNK"] = NPAR * SL * PS
     g["BIAS_OFF"] = RING * CHUNK
     g["LDS_BYTES"] = BIAS_OFF + 4096
-    assert ROWS % 64 == 0 and NB >= 6 and NG + 2 <= 8
+    # where in a tap's element list its LDS-DMA instructions go (one region-row group per tap, PPW planes): behind the weight loads
+    g["DPOS"] = [12, 12 + (2 * NB - 12) // 2] if KS == 2 else [6 + 2 * i for i in range(PPW)]
+    assert PS % 256 == 0 and NB >= 6 and NG + 2 <= 8 and len(DPOS) == PPW and DPOS[-1] < KS * NB
+    assert KS == 2 or (not SPLIT and not DMA_FRONT and not A_IN_ACC and RES_EARLY)
     assert 9 % (LOOK + 1) == 0, "a chunk has 9 taps: the weight sets must come round at its end"
     allocate_registers()
 
 
 # ---- kernel argument block (must match PlAsmArgs in conv3x3_pl.hip) ----
 ARG = dict(inp=0, in_sp=8, in_ss=16, out=24, res=32, w=40, bias=48, zero=56, out_ld=64, res_ld=68, B=72, H=76, W=80, npix=84, cout=88, act=92,
-           CC=96, mt_log2=100, ntiles=104, G=108, inv_hw=112, inv_w=116, inv_hpwp=120, inv_wp=124, debug=128)
-ARG_BYTES = 136
+           CC=96, mt_log2=100, ntiles=104, G=108, inv_hw=112, inv_w=116, inv_hpwp=120, inv_wp=124, debug=128, in_row=136)
+ARG_BYTES = 144
 
 
 class Regs:
@@ -109,6 +128,8 @@ def allocate_registers():
     for nm in ("out_ld", "res_ld", "B", "H", "W", "npix", "cout", "act", "CC", "mt_log2", "ntiles", "G", "inv_hw", "inv_w", "inv_hpwp", "inv_wp"):
         S.alloc(nm)
     S.alloc("debug", 2, 2)
+    if S2:
+        S.alloc("in_row", 2, 2)   # stride-2 family: bytes per INPUT image row (H, W, npix describe the OUTPUT there)
     for nm in ("HW", "Wp", "HpWp", "lead", "Hpad", "tile", "next_tile", "has_next", "n0", "cbase", "c", "buf", "cd", "bd", "lastc", "extra",
                "rs", "rs_dma", "delta0", "dRow", "wave", "first", "tmp0", "tmp1", "tmp2", "tmp3", "dlds", "lim", "par", "rlim"):
         S.alloc(nm)
@@ -118,7 +139,8 @@ def allocate_registers():
     S.alloc("a_nxt", 2, 2)
     S.alloc("a_ld", 2, 2)         # base of the weight loads being issued
     S.alloc("dbase", 2, 2)        # LDS-DMA: input base of (chunk, this wave's first plane) ...
-    S.alloc("dbase1", 2, 2)       # ... and of its second plane
+    if KS == 2:
+        S.alloc("dbase1", 2, 2)   # ... and of its second plane (32-channel chunks: one base, the planes are immediate offsets)
     S.alloc("t64", 2, 2)
     S.alloc("actm", 2, 2)         # all ones when the layer has an activation (in-stream epilogue blocks select instead of branching)
     S.alloc("st_acc", 12, 2)      # stamped build only: cycle sums of six phases
@@ -135,10 +157,12 @@ def allocate_registers():
     V.alloc("zero_lo")
     V.alloc("zero_hi")
     if not A_IN_ACC:
-        V.alloc("A", 24 * (LOOK + 1), 4)
+        V.alloc("A", 12 * KS * (LOOK + 1), 4)
     V.alloc("B", 4 * (PD + 1), 4)
     V.alloc("addr", NB)
     V.alloc("prow", NG)
+    if KS == 1:
+        V.alloc("dadr", 2, 2)     # source address of the LDS-DMA group being issued (KS = 1 families: shared by the PPW planes of a group)
     if RES_EARLY:
         V.alloc("R", 6 * NB, 2)
     V.alloc("oo", NB)
@@ -178,11 +202,11 @@ def rreg(b):
 
 def areg(set_idx, k):
     """The four registers of fragment k (0 .. 5) of weight set set_idx."""
-    assert 0 <= set_idx <= LOOK and 0 <= k < 6
+    assert 0 <= set_idx <= LOOK and 0 <= k < 3 * KS
     if A_IN_ACC:
         b = 12 * NB + 24 * set_idx + 4 * k
         return f"a[{b}:{b + 3}]"
-    return vr("A", 24 * set_idx + 4 * k, 4)
+    return vr("A", 12 * KS * set_idx + 4 * k, 4)
 
 
 # fp8-weight kernels: the 72 weight registers hold three RAW sets of 12 (e4m3 codes as loaded), two converted bf16 half-sets of 12
@@ -304,6 +328,10 @@ def emit_unpad(dst, src, t0, t1, t2, t3, t4):
     E(f"v_mul_lo_u32 {t1}, {t0}, {s('HW')}")
     E(f"v_mad_u32_u24 {t1}, {t2}, {s('W')}, {t1}")
     E(f"v_add_u32 {dst}, {t1}, {t3}")
+    if S2:                                   # the INPUT pixel of parity plane (0, 0): (b, 2 y, 2 x) = 4 P - 2 x  (input image = 2 H x 2 W)
+        E(f"v_lshlrev_b32 {t1}, 1, {t3}")
+        E(f"v_lshl_add_u32 {dst}, {dst}, 2, 0")
+        E(f"v_sub_u32 {dst}, {dst}, {t1}")
     # valid: Pq >= 0 and b < B and x < W and y < H   (b >= 0 follows from Pq >= 0)
     E(f"v_cmp_gt_i32 vcc, 0, {t4}")
     E(f"v_cndmask_b32 {dst}, {dst}, -1, vcc")
@@ -328,13 +356,13 @@ def emit_rs_of_tile(tile_s, dst_s):
 
 
 def emit_region_rows(tile_s):
-    """prow[k] = unpad(rs(tile) + 64 k + lane) for k = 0 .. NG - 1."""
+    """prow[k] = unpad(rs(tile) + GROUPS[k] + lane) for k = 0 .. NG - 1."""
     emit_rs_of_tile(tile_s, s("rs_dma"))
     T = [v("t", i) for i in range(6)]
     for k in range(NG):
         E(f"v_add_u32 {T[5]}, {s('rs_dma')}, {v('lane')}")
         if k:
-            E(f"v_add_u32 {T[5]}, {64 * k}, {T[5]}")
+            E(f"v_add_u32 {T[5]}, {GROUPS[k]}, {T[5]}")
         emit_unpad(v("prow", k), T[5], T[0], T[1], T[2], T[3], T[4])
 
 
@@ -347,6 +375,32 @@ def emit_dma_base(cd_s, bd_s):
     """Per chunk: dbase = inp + (8 cd + 2 wave) * in_ss (plane 2 wave of chunk cd) and dlds = bd * CHUNK + 2 wave * PS, the operands every
     LDS-DMA instruction of that chunk starts from.  (Computing them inside each of the 12 instructions' sequences cost 13 scalar
     instructions apiece, in a stream that is bound by instruction issue.)"""
+    if KS == 1:
+        # 32-channel chunks: wave w loads the PPW planes [w PPW, (w + 1) PPW) of the chunk -- stride 2: parity plane w = (py, px), all four
+        # slots; the slots of a parity plane are 16 bytes apart in the source (in_ss == 16, the host checks), so ONE address per region-row
+        # group serves its PPW instructions through the immediate offset.  dbase = inp + (SL cd [+ wave]) * 16 [+ py in_row + px in_sp]
+        E(f"s_mul_i32 {s('tmp0')}, {cd_s}, {SL * 16}")
+        if not S2:
+            E(f"s_mul_i32 {s('tmp1')}, {s('wave')}, {PPW * 16}")
+            E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {s('tmp1')}")
+        E(f"s_add_u32 {s('dbase')}, {s('inp')}, {s('tmp0')}")
+        E(f"s_addc_u32 {s('dbase', 1)}, {s('inp', 1)}, 0")
+        if S2:
+            lp, lq = uid("py"), uid("px")
+            E(f"s_bitcmp0_b32 {s('wave')}, 1")
+            E(f"s_cbranch_scc1 {lp}")
+            E(f"s_add_u32 {s('dbase')}, {s('dbase')}, {s('in_row')}")
+            E(f"s_addc_u32 {s('dbase', 1)}, {s('dbase', 1)}, {s('in_row', 1)}")
+            label(lp)
+            E(f"s_bitcmp0_b32 {s('wave')}, 0")
+            E(f"s_cbranch_scc1 {lq}")
+            E(f"s_add_u32 {s('dbase')}, {s('dbase')}, {s('in_sp')}")
+            E(f"s_addc_u32 {s('dbase', 1)}, {s('dbase', 1)}, {s('in_sp', 1)}")
+            label(lq)
+        E(f"s_mul_i32 {s('tmp2')}, {bd_s}, {CHUNK}")
+        E(f"s_mul_i32 {s('tmp1')}, {s('wave')}, {PPW * PS}")
+        E(f"s_add_u32 {s('dlds')}, {s('tmp2')}, {s('tmp1')}", "the ring starts at LDS address 0")
+        return
     E(f"s_lshl_b32 {s('tmp0')}, {cd_s}, 3")
     E(f"s_lshl_b32 {s('tmp1')}, {s('wave')}, 1")
     E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {s('tmp1')}", "slot of this wave's first plane")
@@ -363,15 +417,39 @@ def emit_dma_base(cd_s, bd_s):
 
 def emit_dma(k, s2i, cd_s=None, bd_s=None):
     """One LDS-DMA instruction: plane 2 wave + s2i of the chunk emit_dma_base was called for, region rows 64 k .. 64 k + 63."""
+    if KS == 1:
+        # (the m0 write and the DMA are emitted by the stream around an element's MFMAs: emit_dma_m0 / emit_dma_issue)
+        emit_dma_m0(k, s2i)
+        if s2i:
+            E("s_nop 0", "hz: m0 write -> LDS-DMA")
+        emit_dma_issue(k, s2i)
+        return
     T = [v("t", i) for i in range(8, 12)]
     base = s2("dbase1") if s2i else s2("dbase")
-    E(f"s_add_u32 m0, {s('dlds')}, {s2i * PS + k * 1024}", "hz: m0 write -> LDS-DMA: the address arithmetic below sits in between")
+    E(f"s_add_u32 m0, {s('dlds')}, {s2i * PS + GROUPS[k] * 16}", "hz: m0 write -> LDS-DMA: the address arithmetic below sits in between")
     # (an invalid row, prow = -1, multiplies out to a wild address that the select below replaces: no clamp needed)
     E(f"v_mad_u64_u32 v[{V.names['t'][0] + 8}:{V.names['t'][0] + 9}], vcc, {v('prow', k)}, {v('insp')}, {base}")
     E(f"v_cmp_gt_i32 vcc, 0, {v('prow', k)}")
     E(f"v_cndmask_b32 {T[0]}, {T[0]}, {v('zero_lo')}, vcc")
     E(f"v_cndmask_b32 {T[1]}, {T[1]}, {v('zero_hi')}, vcc")
     E(f"global_load_lds_dwordx4 v[{V.names['t'][0] + 8}:{V.names['t'][0] + 9}], off")
+
+
+def emit_dma_m0(k, s2i):
+    """KS = 1 families, first half of an LDS-DMA: its LDS address, and for the first plane of a region-row group the group's source address."""
+    E(f"s_add_u32 m0, {s('dlds')}, {s2i * PS + GROUPS[k] * 16}", "hz: m0 write -> LDS-DMA: at least one instruction before the DMA")
+    if s2i == 0:
+        d0 = V.names["dadr"][0]
+        # (an invalid row, prow = -1, multiplies out to a wild address that the select below replaces: no clamp needed)
+        E(f"v_mad_u64_u32 v[{d0}:{d0 + 1}], vcc, {v('prow', k)}, {v('insp')}, {s2('dbase')}")
+        E(f"v_cmp_gt_i32 vcc, 0, {v('prow', k)}")
+        E(f"v_cndmask_b32 v{d0}, v{d0}, {v('zero_lo')}, vcc")
+        E(f"v_cndmask_b32 v{d0 + 1}, v{d0 + 1}, {v('zero_hi')}, vcc")
+
+
+def emit_dma_issue(k, s2i):
+    d0 = V.names["dadr"][0]
+    E(f"global_load_lds_dwordx4 v[{d0}:{d0 + 1}], off offset:{16 * s2i}")      # (the zero page holds 256 zero bytes)
 
 
 def emit_load_a(set_idx, k, base_s2, extra_off):
@@ -439,10 +517,12 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     global out, W8, STEP_B
     out = []
     STAMPED[0] = stamped
-    W8, STEP_B = w8, (3 if w8 else 6) * 1024
-    assert not w8 or (RES_EARLY and LOOK == 2 and not A_IN_ACC and NB >= 12)
+    NLOAD = 3 if (w8 or KS == 1) else 6       # weight load instructions per tap: 1 KB fragments (or e4m3 fragment pairs)
+    W8, STEP_B = w8, NLOAD * 1024
+    assert not w8 or (RES_EARLY and LOOK == 2 and not A_IN_ACC and NB >= 12 and KS == 2)
+    assert not (S2 and RES), "the stride-2 layers have no shortcut"
     _uid[0], _uid[1] = 0, name.split("asm_", 1)[1].replace("_", "")
-    E(f"; conv3x3_pl assembly, NB = {NB}, {OCC} workgroup(s) per CU, RES = {int(RES)}: generated by gen_conv3x3_pl_asm.py -- do not edit")
+    E(f"; conv3x3_pl assembly, family {FAMILY}, NB = {NB}, {OCC} workgroup(s) per CU, RES = {int(RES)}: generated by gen_conv3x3_pl_asm.py -- do not edit")
     label(name)
     # ---- arguments ----
     E(f"s_load_dwordx8 s[{S.names['inp'][0]}:{S.names['inp'][0] + 7}], {s2('karg')}, 0x0", "inp, in_sp, in_ss, out")
@@ -450,6 +530,8 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_load_dwordx8 s[{S.names['out_ld'][0]}:{S.names['out_ld'][0] + 7}], {s2('karg')}, 0x40", "out_ld .. act")
     E(f"s_load_dwordx8 s[{S.names['CC'][0]}:{S.names['CC'][0] + 7}], {s2('karg')}, 0x60", "CC .. inv_wp")
     E(f"s_load_dwordx2 {s2('debug')}, {s2('karg')}, 0x80")
+    if S2:
+        E(f"s_load_dwordx2 {s2('in_row')}, {s2('karg')}, 0x88")
     assert S.names['in_sp'][0] == S.names['inp'][0] + 2 and S.names['out'][0] == S.names['inp'][0] + 6
     assert S.names['zero'][0] == S.names['res'][0] + 6 and S.names['act'][0] == S.names['out_ld'][0] + 7
     assert S.names['inv_wp'][0] == S.names['CC'][0] + 7 and S.names['inp'][0] % 4 == 0 and S.names['res'][0] % 4 == 0
@@ -508,14 +590,14 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     emit_a_stream_base("a_cur", s("tile"), s("c"))
     for tap in range(LOOK):                        # offsets beyond a tap-step exceed the immediate range, so move the base
         emit_set_a_base("a_ld", tap)
-        for k in range(3 if w8 else 6):
+        for k in range(NLOAD):
             emit_load_a(tap, k, s2("a_ld"), 0)
     emit_region_rows(s("tile"))
     E(f"s_mov_b32 {s('cd')}, 0")
     E(f"s_mov_b32 {s('bd')}, 0")
     emit_dma_base(s("cd"), s("bd"))
     for k in range(NG):
-        for s2i in range(2):
+        for s2i in range(PPW):
             emit_dma(k, s2i, s("cd"), s("bd"))
     # bias: 256 floats per wave by LDS-DMA (lane: floats wave * 256 + 4 lane .. + 3, or zeros beyond cout)
     T = [v("t", i) for i in range(8)]
@@ -559,7 +641,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         E(f"s_mov_b32 {s('bd')}, 1")
         emit_dma_base(s("cd"), s("bd"))
         for k in range(NG):
-            for s2i in range(2):
+            for s2i in range(PPW):
                 emit_dma(k, s2i, s("cd"), s("bd"))
     stamp(PH_PROLOGUE)
     E(f"s_mov_b32 {s('buf')}, 0")
@@ -927,21 +1009,29 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         # first B fragments
         def b_read(n):
             h, j = divmod(n, NB)
-            t, ks = divmod(h, 2)
+            t, ks = divmod(h, KS)
             # the pixel block's address moves once per kernel ROW (taps 0, 3, 6); the column and the k-step are immediate offsets
             if ks == 0 and t == 0:
                 E(f"v_add_u32 {v('addr', j)}, {s('delta0')}, {v('addr', j)}")
-            elif ks == 0 and t % 3 == 0:
+            elif ks == 0 and (t == 3 if S2 else t % 3 == 0):
                 E(f"v_add_u32 {v('addr', j)}, {s('dRow')}, {v('addr', j)}")
+            if S2:
+                # tap (dy, dx) = divmod(t, 3): parity plane (dy != 1, dx != 1) -- plane index as the waves load them, 2 py + px --, column dx >= 1;
+                # the row (dy >= 1) is in the address: it moves once per chunk, at tap 3
+                dy, dx = divmod(t, 3)
+                off = (2 * (dy != 1) + (dx != 1)) * SL * PS + 16 * (dx >= 1)
+            else:
+                off = 16 * (t % 3) + (4 * PS if ks else 0)
+            assert off < 65536
             if not abl & 4:
-                E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)} offset:{16 * (t % 3) + (4 * PS if ks else 0)}")
+                E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)} offset:{off}")
 
         for n in range(PD):
             b_read(n)
         # ---- the element stream ----
         # Vector-memory operations of one tap, in issue order: (element, kind, ...).  Weights of tap t + 2 at the odd elements 1 .. 11,
         # two LDS-DMA instructions in the first NG taps, residual loads (one or two pixel blocks of three) in taps 0 .. 6.
-        kD0, kD1 = 12, 12 + (2 * NB - 12) // 2
+        kD0, kD1 = DPOS[0], DPOS[-1]
         in_stream_res = RES and RES_EARLY
         res_groups = []                       # res_groups[t] = pixel blocks whose residual is loaded in tap t
         if in_stream_res:
@@ -953,12 +1043,12 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             assert nxt == NB and kD1 + 2 < 2 * NB
 
         def tap_ops(t, last=True):
-            ops = [(2 * k + 1, "A", (t + LOOK) % 9, k) for k in range(3 if w8 else 6) if not abl & 1]
+            ops = [(2 * k + 1, "A", (t + LOOK) % 9, k) for k in range(NLOAD) if not abl & 1]
             if DMA_FRONT and t == 0 and not abl & 2:
                 assert 12 + 2 * NG <= 2 * NB
                 ops += [(12 + 2 * k + h, "D", k, h) for k in range(NG) for h in range(2)]
             elif not DMA_FRONT and t < NG and not abl & 2:
-                ops += [(kD0, "D", t, 0), (kD1, "D", t, 1)]
+                ops += [(DPOS[h], "D", t, h) for h in range(PPW)]
             if in_stream_res and last:
                 for g, j in enumerate(res_groups[t]):
                     ops += [((kD0, kD1)[g] + 2, "R", j, i) for i in range(3)]
@@ -997,8 +1087,9 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
 
         for n in range(NE):
             h, j = divmod(n, NB)
-            t, ks = divmod(h, 2)
+            t, ks = divmod(h, KS)
             e = ks * NB + j
+            post = []                                         # KS = 1 families: the LDS-DMA itself, behind this element's MFMAs
             if n + PD < NE:
                 b_read(n + PD)
             if j == 0 and not w8:
@@ -1014,6 +1105,9 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
                     if op[3] == 0:
                         emit_set_a_base("a_ld", t + LOOK)
                     emit_load_a((t + LOOK) % (LOOK + 1), op[3], s2("a_ld"), 0)
+                elif op[1] == "D" and KS == 1:
+                    emit_dma_m0(op[2], op[3])
+                    post.append((op[2], op[3]))
                 elif op[1] == "D":
                     emit_dma(op[2], op[3], s("cd"), s("bd"))
                 elif op[1] == "R" and op[3] == 0:
@@ -1036,6 +1130,10 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             for i in range(3 if not abl & 8 else 0):
                 srca = bfreg(ks, i) if w8 else areg(t % (LOOK + 1), 3 * ks + i)
                 E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {srca}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
+            for k_, h_ in post:
+                if abl & 8:
+                    E("s_nop 0", "hz: m0 write -> LDS-DMA (no MFMAs in between in this ablation)")
+                emit_dma_issue(k_, h_)
             if w8 and j < 12:
                 # one quarter of a fragment of the NEXT half-tap per element: two VALU instructions in the shadow of three MFMAs
                 if ks == 0:
@@ -1050,7 +1148,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_cselect_b32 {s('tmp0')}, 0, {s('tmp0')}", "next buffer")
     E(f"s_sub_i32 {s('tmp1')}, {s('tmp0')}, {s('buf')}")
     E(f"s_mul_i32 {s('tmp1')}, {s('tmp1')}, {CHUNK}")
-    E(f"s_lshl_b32 {s('tmp2')}, {s('Wp')}, 5", "2 Wp * 16: back from kernel row 2 to row 0")
+    E(f"s_lshl_b32 {s('tmp2')}, {s('Wp')}, {4 if S2 else 5}", "2 Wp * 16: back from kernel row 2 to row 0 (stride 2: one row step per chunk)")
     E(f"s_sub_i32 {s('delta0')}, {s('tmp1')}, {s('tmp2')}")
     E(f"s_mov_b32 {s('buf')}, {s('tmp0')}")
     E(f"s_mov_b32 {s('first')}, 0")
@@ -1302,20 +1400,22 @@ def main():
     path = sys.argv[1] if len(sys.argv) > 1 else "conv3x3_pl_asm.s"
     text = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.text"]
     entries = []
-    for nb in sorted(CONFIGS):
+    for nb in sorted(CONFIGS, key=str):
         configure(nb)
         variants = [(False, False, 0, False), (True, False, 0, False), (True, True, 0, False)]
+        if S2:
+            variants = [(False, False, 0, False), (False, True, 0, False)] + ([(False, True, a, False) for a in (1, 2, 3, 4, 7, 8)] if DIAG else [])
         if nb == 13:
             variants += [(False, False, 0, True), (True, False, 0, True), (True, True, 0, True)]     # fp8-weight stream
         if DIAG and nb in (7, 13):
             variants += [(True, True, a, False) for a in (1, 2, 3, 4, 7, 8)]
         for RES, stamped, abl, w8 in variants:
-            name = f"conv3x3_pl_asm_nb{NB}_res{int(RES)}" + ("_w8" if w8 else "") + ("_stamped" if stamped else "") + (f"_abl{abl}" if abl else "")
+            name = f"conv3x3_pl_asm_{FAMILY}_res{int(RES)}" + ("_w8" if w8 else "") + ("_stamped" if stamped else "") + (f"_abl{abl}" if abl else "")
             text += [f"\t.globl\t{name}", "\t.p2align\t8", f"\t.type\t{name},@function"]
             text += gen_kernel(name, RES, stamped, abl, w8)
             entries.append(metadata_entry(name))
             text += [f".Lfend_{name}:", f"\t.size\t{name}, .Lfend_{name}-{name}", descriptor(name)]
-        print(f"NB = {NB}: {V.next} VGPRs + {n_acc()} AGPRs, {S.next} SGPRs, {LDS_BYTES} B LDS, {OCC} workgroup(s) per CU")
+        print(f"{FAMILY}: {V.next} VGPRs + {n_acc()} AGPRs, {S.next} SGPRs, {LDS_BYTES} B LDS, {OCC} workgroup(s) per CU")
     text.append(metadata(entries))
     with open(path, "w") as f:
         f.write("\n".join(text) + "\n")

@@ -69,7 +69,7 @@ EXPORTS = (
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
     "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_stemdown_supported", "aq_stemdown", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
     "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct",
-    "aq_conv3x3_pl_supported", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
+    "aq_conv3x3_pl_supported", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_s2_supported", "aq_pack_conv3x3_pl_s2", "aq_conv3x3_pl_s2", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_letterbox_tiles_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
 
@@ -125,6 +125,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_conv3x3_pl_w8.argtypes = lib.aq_conv3x3_pl.argtypes
     lib.aq_pack_conv3x3_pl_w8.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), i32, i32, vp, C.POINTER(C.c_size_t), vp, vp]
     lib.aq_conv3x3_pl_w8_supported.argtypes = [i32] * 5
+    lib.aq_conv3x3_pl_s2_supported.argtypes = [i32] * 5
+    lib.aq_pack_conv3x3_pl_s2.argtypes = [C.POINTER(f32), i32, i32, vp, C.POINTER(sz), vp]
+    lib.aq_conv3x3_pl_s2.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp]
     lib.aq_preprocess_s2d.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.aq_sppf_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.aq_upsample2x.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -578,6 +581,7 @@ def downblock_nhwc(x: torch.Tensor, wa_oihw: torch.Tensor, ba: torch.Tensor, wb_
 CONV_CFG_DIRECT1X1 = 1000   # AQ_CONV_CFG_DIRECT1X1
 CONV_CFG_DIRECT3X3S2 = 1001  # AQ_CONV_CFG_DIRECT3X3S2
 CONV_CFG_PL3X3 = 1002       # AQ_CONV_CFG_PL3X3
+CONV_CFG_PL3X3S2 = 1003     # AQ_CONV_CFG_PL3X3S2
 CONV_CFG_ONE_TILE_PER_WG = 4096  # AQ_CONV_CFG_ONE_TILE_PER_WG (OR-ed into a tile configuration id)
 
 
@@ -663,6 +667,34 @@ def conv3x3s2_direct_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Ten
         out = torch.empty((B, H // 2, W // 2, cout), dtype=torch.bfloat16, device=x.device)
     _check(lib.aq_conv3x3s2_direct(x.data_ptr(), ld, 0, out.data_ptr(), out.stride(2), 0, cin, cout, wbuf.data_ptr(), bbuf.data_ptr(), B, H, W, int(act),
                                    _stream_ptr()))
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
+def conv3x3_pl_s2_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, act: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 NHWC [B,H,W,cin] (may be a channel slice) -> SiLU(conv3x3/s2/p1(x) + b) [B,H/2,W/2,cout] (may be a channel slice) through
+    aq_conv3x3_pl_s2, the planar stride-2 kernel (tests, tools)."""
+    _require_gpu()
+    lib = load_library()
+    assert x.dtype == torch.bfloat16 and x.stride(3) == 1
+    B, H, W, cin = x.shape
+    cout = w_oihw.shape[0]
+    ld = x.stride(2)
+    assert x.stride(1) == W * ld and x.stride(0) == H * W * ld, "x must be a channel slice of a dense NHWC tensor"
+    w = np.ascontiguousarray(w_oihw.permute(0, 2, 3, 1).float().cpu().numpy())
+    n = C.c_size_t()
+    wp = w.ctypes.data_as(C.POINTER(C.c_float))
+    _check(lib.aq_pack_conv3x3_pl_s2(wp, cin, cout, None, C.byref(n), None))
+    wbuf = torch.empty(n.value, dtype=torch.uint8, device=x.device)
+    _check(lib.aq_pack_conv3x3_pl_s2(wp, cin, cout, wbuf.data_ptr(), C.byref(n), _stream_ptr()))
+    bbuf = torch.zeros((cout + 255) // 256 * 256 + 1024, dtype=torch.float32, device=x.device)    # the kernel's bias tile over-reads up to 1024 floats
+    bbuf[:cout] = bias.float().to(x.device)
+    if out is None:
+        out = torch.empty((B, H // 2, W // 2, cout), dtype=torch.bfloat16, device=x.device)
+    assert out.stride(3) == 1 and out.stride(1) == (W // 2) * out.stride(2)
+    # channel offsets are expressed through the base pointers (slices): in_choff = out_choff = 0
+    _check(lib.aq_conv3x3_pl_s2(x.data_ptr(), ld, 0, cin, out.data_ptr(), out.stride(2), 0, cout, wbuf.data_ptr(), bbuf.data_ptr(), B, H, W, int(act),
+                                _stream_ptr()))
     torch.cuda.current_stream().synchronize()
     return out
 

@@ -217,6 +217,18 @@ int aq_pack_conv3x3_pl(const float* w_krsc_host, int cin, int cout, void* packed
 int aq_conv3x3_pl(const void* in_dev, long long in_pixel_stride_b, long long in_group_stride_b, int cin,
                   void* out_dev, int out_ld, int out_choff, int cout, const void* res_dev, int res_ld, int res_choff,
                   const void* packed_w_dev, const float* bias_dev, int B, int H, int W, int act, void* stream);
+/* 3x3 / stride 2 / pad 1 on the same planar scheme (round 3; bf16, Cin a multiple of 32 and >= 64, Cout a multiple of 192 with Cout / 192 a
+ * power of two, even H and W, and an output row short enough for the tile's region: yolov5m's model.5 / 7 / 18 / 21, i.e.
+ * [UPSTREAM models/common.py Conv.forward_fuse] with k = 3, s = 2): the input region is staged in LDS as the four PARITY planes of the
+ * input (y, x odd / even), each in padded OUTPUT coordinates, so a tap is a plane plus an offset of -1 or 0 and every fragment read
+ * stays conflict-free; 32-channel chunks, two ring buffers, one barrier per chunk, weights L2 -> registers.  Generated gfx950 assembly
+ * (csrc/gen_conv3x3_pl_asm.py, family s2nb13).  Same operation as aq_conv2d with k = 3, stride = 2, pad = 1; autotuner candidate
+ * AQ_CONV_CFG_PL3X3S2.  H, W: the INPUT's size. */
+#define AQ_CONV_CFG_PL3X3S2 1003
+int aq_conv3x3_pl_s2_supported(int cin, int cout, int B, int H, int W);
+int aq_pack_conv3x3_pl_s2(const float* w_krsc_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream);
+int aq_conv3x3_pl_s2(const void* in_dev, int in_ld, int in_choff, int cin, void* out_dev, int out_ld, int out_choff, int cout,
+                     const void* packed_w_dev, const float* bias_dev, int B, int H, int W, int act, void* stream);
 /* The same kernel streaming e4m3fn weight codes (AQ_BF16_W8): bit-identical outputs to aq_conv3x3_pl on the dequantised weights.
  * `w` must lie on a per-output-channel grid code x 2^e (AQ_ERR_INVALID otherwise); scale_bias_dev: float[2048] written by the packer
  * (bias x 2^-e, then 2^e).  _supported: NB = 13 tiles fit the image and cout / 192 is a power of two. */

@@ -290,6 +290,56 @@ def test_direct_conv3x3s2_matches_reference(lib, shape):
         torch.testing.assert_close(got, ref.bfloat16().float(), rtol=2 ** -7, atol=4e-3)
 
 
+PL_S2_CASES = [
+    # B, H, W (input), Cin, Cout, act
+    (3, 80, 80, 192, 384, True),      # yolov5m model.5: several tiles per image, batch seams inside tiles, two M tiles, six 32-channel chunks
+    (2, 40, 40, 384, 768, True),      # model.7: four M tiles, twelve chunks
+    (5, 80, 80, 192, 192, True),      # model.18
+    (3, 40, 40, 384, 384, False),     # model.21, no activation
+    (1, 18, 14, 64, 192, True),       # sub-tile ragged image: every border case inside one tile; two chunks (the ring wraps at once)
+    (2, 26, 48, 96, 192, True),       # three chunks, odd output sizes (13 x 24)
+    (40, 80, 80, 192, 192, True),     # more tiles than CUs: persistent workgroups walk several tiles (prefetch across the tile seam)
+    (70, 40, 40, 128, 384, True),     # the same with two M tiles
+    (2, 4, 4, 64, 192, False),        # 2 x 2 outputs per image: every tap of every pixel touches padding or another parity plane's border
+]
+
+
+@pytest.mark.parametrize("case", PL_S2_CASES)
+def test_planar_conv3x3_s2_matches_reference(lib, case):
+    """aq_conv3x3_pl_s2 (generated assembly, family s2nb13: parity planes of the input in padded output coordinates) vs F.conv2d with
+    stride 2 on bf16-rounded operands; input and output are channel slices of wider tensors."""
+    from aquaculture_amd import engine
+    B, H, W, cin, c, act = case
+    assert engine.load_library().aq_conv3x3_pl_s2_supported(cin, c, B, H, W)
+    g = torch.Generator().manual_seed(c * 5 + H * 3 + cin)
+    xw = (torch.randn(B, H, W, cin + 16, generator=g) * 0.8).bfloat16().cuda()
+    x = xw[..., 8:8 + cin]
+    w = torch.randn(c, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(c, generator=g) * 0.2
+    outw = torch.full((B, H // 2, W // 2, c + 24), 7.0, dtype=torch.bfloat16, device="cuda")
+    out = outw[..., 16:16 + c]
+    engine.conv3x3_pl_s2_nhwc(x, w, b, act, out=out)
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.bfloat16().float(), b, stride=2, padding=1)
+    ref = (F.silu(ref) if act else ref).permute(0, 2, 3, 1)
+    got = out.float().cpu()
+    assert (outw[..., :16] == 7.0).all() and (outw[..., 16 + c:] == 7.0).all(), "wrote outside its channel slice"
+    torch.testing.assert_close(got, ref.bfloat16().float(), rtol=2 ** -7, atol=4e-3)
+
+
+def test_planar_conv3x3_s2_rejects_what_it_cannot_tile(lib):
+    """Odd image sizes, channel counts off the 32 / 192 grids and output rows too long for the tile's region are refused (the engine
+    then keeps the implicit-GEMM kernels), not mis-computed."""
+    from aquaculture_amd import engine
+    L = engine.load_library()
+    assert L.aq_conv3x3_pl_s2_supported(192, 384, 64, 80, 80) and L.aq_conv3x3_pl_s2_supported(384, 768, 64, 40, 40)
+    assert not L.aq_conv3x3_pl_s2_supported(192, 384, 2, 81, 80) and not L.aq_conv3x3_pl_s2_supported(192, 384, 2, 80, 82 + 1)
+    assert not L.aq_conv3x3_pl_s2_supported(48, 192, 2, 80, 80) and not L.aq_conv3x3_pl_s2_supported(192, 200, 2, 80, 80)
+    assert not L.aq_conv3x3_pl_s2_supported(96, 192, 64, 160, 160)        # model.3: an 80-pixel output row does not fit the 304-row region
+    x = torch.zeros(1, 160, 160, 96, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError, match="unsupported"):
+        engine.conv3x3_pl_s2_nhwc(x, torch.zeros(192, 96, 3, 3), torch.zeros(192))
+
+
 PL_CASES = [
     # B, H, W, Cin, Cout, residual mode (None / "sep" / "inplace"), act
     (3, 40, 40, 192, 192, "inplace", True),    # yolov5m model.6 Bottleneck.cv2: several tiles, batch seams inside tiles, in-place shortcut
