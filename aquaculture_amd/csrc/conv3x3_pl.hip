@@ -771,8 +771,9 @@ extern "C" int aq_conv3x3_pl_s2(const void* in_dev, int in_ld, int in_choff, int
     AQ_REQUIRE(in_choff % 8 == 0 && in_choff + cin <= in_ld && in_ld % 8 == 0 && out_ld % 4 == 0 && out_choff % 4 == 0 && out_choff + cout <= out_ld,
                "conv3x3_pl_s2: slices must be 16-byte (input) / 8-byte (output) aligned and inside their rows");
     const int Ho = H / 2, Wo = W / 2;
-    AQ_REQUIRE((long long)B * Ho * Wo * out_ld * 2 < (1LL << 31) && (long long)B * H * W * in_ld * 2 < (1LL << 32),
-               "conv3x3_pl_s2: tensors beyond the 32-bit offset range");
+    // (the input goes through a buffer descriptor with num_records = 2^31: valid offsets must stay below it, the padding rows' 2^31 is beyond)
+    AQ_REQUIRE((long long)B * Ho * Wo * out_ld * 2 < (1LL << 31) && (long long)B * H * W * in_ld * 2 < (1LL << 31) && in_ld * 2 < (1 << 24),
+               "conv3x3_pl_s2: tensors beyond the 31-bit offset range");
     int dev = 0;
     AQ_CHECK_HIP(hipGetDevice(&dev));
     AQ_REQUIRE(dev >= 0 && dev < 64, "conv3x3_pl_s2: device ordinal %d", dev);

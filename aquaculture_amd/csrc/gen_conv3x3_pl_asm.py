@@ -51,13 +51,22 @@ import sys
 # KS = k-steps (of 32 channels) per chunk: 2 = the 64-channel chunks of the stride-1 families; 1 = 32-channel chunks.
 # S2 = the stride-2 family (round 3).  A 3x3 / stride 2 / pad 1 convolution reads input pixel (2 oy + dy - 1, 2 ox + dx - 1): split the input
 # into its four PARITY planes (y odd / even x x odd / even), each an image of the OUTPUT's size, and tap (dy, dx) reads plane
-# (dy != 1, dx != 1) at output pixel (oy - (dy == 0), ox - (dx == 0)) -- offsets -1 and 0 only.  So the region is laid out exactly as for
-# stride 1 (padded OUTPUT coordinates, one zero pixel after every row, one zero row after every image; region row 0 = the upper left
-# neighbour of the tile's first pixel), once per parity plane: a chunk = 4 parity planes x 4 slot planes (32 channels) x ROWS rows, the
-# parity split happens in the LDS-DMA's per-lane source address (input pixel 4 P' - 2 x' + 2 W py + px for padded output pixel P' = (b, y',
-# x')), wave w loads parity plane w, and a tap is an immediate LDS offset (parity plane, column) plus ONE address update per chunk (kernel
-# row 0 -> rows 1, 2).  ROWS = 304 = 208 pixels + row pads + an image seam + one-sided halo for W = 20 and 40; the fifth LDS-DMA group
-# overlaps the fourth by 16 rows (GROUPS), so no EXEC mask is needed; two ring buffers (2 x 76 KB + bias = 156 KB).
+# (dy != 1, dx != 1) at output pixel (oy - (dy == 0), ox - (dx == 0)) -- offsets -1 and 0 only.  So the region uses the stride-1 families'
+# padded OUTPUT coordinates (one zero pixel after every row, one zero row after every image; region row 0 = the upper left neighbour
+# of the tile's first pixel), once per parity plane, and wave w loads parity plane w.
+# The first build kept the stride-1 families' slot-major planes (one LDS-DMA instruction = 64 rows x 16 B of one channel group): correct,
+# and bound by the vector-memory front end -- every lane of every instruction touches a different cache line, a chunk needs 20
+# instructions per wave for 351 MFMAs, and the stamped build without the DMA ran its stream in half the time (284 k -> 146 k cycles,
+# model.7).  Hence the layout of THIS family: a region row is the 64 contiguous bytes of a pixel's 32-channel chunk; one LDS-DMA
+# instruction moves 16 rows x 64 B (four lanes per pixel: a quarter of the cache-line look-ups), through a buffer descriptor whose
+# out-of-range lanes write ZEROS to LDS (measured: tools/ubench/lds_dma_buffer_oob.hip) -- the padding rows cost no zero page, no 64-bit
+# address arithmetic and no select: per instruction one s_add m0 and one buffer_load ... lds with a per-tile offset register.  A
+# pixel-major row would make the fragment reads 4-way bank-conflicted (16 lanes, 64 B apart), so the 16-byte channel group q of region
+# row r sits at position q ^ 2 ((r >> 2) & 1) of its row (byte address bit 5 ^= bit 8): with ds_read_b128's real lane groups
+# ({0-3, 12-15, 20-27}, ...: two channel groups per group) every group then covers all 64 banks exactly once, for any starting row.
+# The LDS-DMA writes lane-linearly, so the XOR is applied on the SOURCE side (which channel group a lane fetches) and on the read side
+# (four address registers per pixel block -- one per (row, column) offset of the taps, since an XOR does not commute with the add).
+# ROWS = 304 = 208 pixels + row pads + an image seam + one-sided halo for W = 20 and 40; two ring buffers (2 x 76 KB + bias = 156 KB).
 CONFIGS = {
     13: dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False),    # SPLIT=7, DMA_FRONT: measured slower, below
     7: dict(NB=7, PD=8, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False),
@@ -84,8 +93,22 @@ def configure(nb):
     g["BIAS_OFF"] = RING * CHUNK
     g["LDS_BYTES"] = BIAS_OFF + 4096
     # where in a tap's element list its LDS-DMA instructions go (one region-row group per tap, PPW planes): behind the weight loads
-    g["DPOS"] = [12, 12 + (2 * NB - 12) // 2] if KS == 2 else [6 + 2 * i for i in range(PPW)]
-    assert PS % 256 == 0 and NB >= 6 and NG + 2 <= 8 and len(DPOS) == PPW and DPOS[-1] < KS * NB
+    g["DPOS"] = [12, 12 + (2 * NB - 12) // 2]
+    if S2:
+        g["GROUPS"] = list(range(0, ROWS, 64))             # groups of 64 rows whose source pixels are computed (then dealt to the instructions)
+        g["NG"] = len(GROUPS)
+        g["PSTR"] = ROWS * 64                              # one parity plane: ROWS pixel-major rows of 64 B
+        g["CHUNK"] = NPAR * PSTR
+        g["BIAS_OFF"] = RING * CHUNK
+        g["LDS_BYTES"] = BIAS_OFF + 4096
+        g["NDMA"] = ROWS // 16                             # LDS-DMA instructions per wave (= parity plane) and chunk
+        # which of them go into which tap: all within taps 0 .. 5, so that the wait for tap 8's weights (loaded in tap 6) covers them
+        per = [-(-NDMA // 6)] * (NDMA % 6 or 6) + [NDMA // 6] * (6 - (NDMA % 6 or 6))
+        g["DMA_TAPS"] = [list(range(sum(per[:t]), sum(per[:t + 1]))) for t in range(6)] + [[], [], []]
+        g["DPOS"] = [6 + 2 * i for i in range(max(per))]
+        assert ROWS % 16 == 0 and sum(len(x) for x in DMA_TAPS) == NDMA and DPOS[-1] < NB and 3 * PSTR + 16 < 65536
+    assert (KS == 1) == bool(S2)
+    assert PS % 256 == 0 and NB >= 6 and NG + 2 <= 8
     assert KS == 2 or (not SPLIT and not DMA_FRONT and not A_IN_ACC and RES_EARLY)
     assert 9 % (LOOK + 1) == 0, "a chunk has 9 taps: the weight sets must come round at its end"
     allocate_registers()
@@ -131,21 +154,27 @@ def allocate_registers():
     if S2:
         S.alloc("in_row", 2, 2)   # stride-2 family: bytes per INPUT image row (H, W, npix describe the OUTPUT there)
     for nm in ("HW", "Wp", "HpWp", "lead", "Hpad", "tile", "next_tile", "has_next", "n0", "cbase", "c", "buf", "cd", "bd", "lastc", "extra",
-               "rs", "rs_dma", "delta0", "dRow", "wave", "first", "tmp0", "tmp1", "tmp2", "tmp3", "dlds", "lim", "par", "rlim"):
+               "rs", "rs_dma", "delta0", "dRow", "wave", "first", "tmp0", "tmp1", "tmp2", "tmp3", "dlds", "lim") + (("coff",) if S2 else ("par", "rlim")):
         S.alloc(nm)
     S.alloc("klog2e2", 2, 2)      # (-log2 e, -log2 e) for v_pk_mul_f32
     S.alloc("kone2", 2, 2)        # (1.0, 1.0)
     S.alloc("a_cur", 2, 2)
     S.alloc("a_nxt", 2, 2)
     S.alloc("a_ld", 2, 2)         # base of the weight loads being issued
-    S.alloc("dbase", 2, 2)        # LDS-DMA: input base of (chunk, this wave's first plane) ...
+    if S2:
+        S.alloc("srd", 4, 4)      # buffer descriptor of this wave's parity plane of the input (constant for the kernel)
+    else:
+        S.alloc("dbase", 2, 2)    # LDS-DMA: input base of (chunk, this wave's first plane) ...
     if KS == 2:
         S.alloc("dbase1", 2, 2)   # ... and of its second plane (32-channel chunks: one base, the planes are immediate offsets)
     S.alloc("t64", 2, 2)
     S.alloc("actm", 2, 2)         # all ones when the layer has an activation (in-stream epilogue blocks select instead of branching)
     S.alloc("st_acc", 12, 2)      # stamped build only: cycle sums of six phases
-    S.alloc("st_last", 2, 2)
-    S.alloc("st_rt0", 2, 2)
+    if S2:                        # (arguments the stride-2 kernels never read: no shortcut, channel groups 16 bytes apart)
+        S.names["st_last"], S.names["st_rt0"] = S.names["res"], S.names["in_ss"]
+    else:
+        S.alloc("st_last", 2, 2)
+        S.alloc("st_rt0", 2, 2)
     # ---------------- VGPRs ----------------
     V.alloc("tid")                # v0 on entry
     V.alloc("lane")
@@ -159,11 +188,13 @@ def allocate_registers():
     if not A_IN_ACC:
         V.alloc("A", 12 * KS * (LOOK + 1), 4)
     V.alloc("B", 4 * (PD + 1), 4)
-    V.alloc("addr", NB)
+    V.alloc("addr", 4 * NB if S2 else NB)      # (stride 2: per pixel block one swizzled address per (row, column) offset of the taps)
     V.alloc("prow", NG)
-    if KS == 1:
-        V.alloc("dadr", 2, 2)     # source address of the LDS-DMA group being issued (KS = 1 families: shared by the PPW planes of a group)
-    if RES_EARLY:
+    if S2:
+        V.alloc("voff", NDMA)     # per LDS-DMA instruction of a chunk: this lane's byte offset into the parity plane, or beyond the descriptor
+        V.alloc("bpa", 4)         # ds_bpermute addresses: lane (16 m + lane / 4) * 4, m = 0 .. 3
+        V.alloc("qoff")           # 16 x the channel group this lane fetches: (lane & 3) ^ 2 ((lane >> 4) & 1)
+    if RES_EARLY and not S2:
         V.alloc("R", 6 * NB, 2)
     V.alloc("oo", NB)
     V.alloc("t", 24, 4)           # temporaries
@@ -178,6 +209,12 @@ def s(name, i=0):
 def s2(name, i=0):
     b, n = S.names[name]
     return f"s[{b + i}:{b + i + 1}]"
+
+
+def s4(name):
+    b, n = S.names[name]
+    assert n == 4 and b % 4 == 0
+    return f"s[{b}:{b + 3}]"
 
 
 def v(name, i=0):
@@ -364,9 +401,24 @@ def emit_region_rows(tile_s):
         if k:
             E(f"v_add_u32 {T[5]}, {GROUPS[k]}, {T[5]}")
         emit_unpad(v("prow", k), T[5], T[0], T[1], T[2], T[3], T[4])
+    if S2:
+        # deal the 64-row groups to the 16-row instructions: lane L of instruction g fetches for region row 16 g + L / 4, whose source pixel
+        # sits in lane 16 (g & 3) + L / 4 of prow[g >> 2]; then offset = pixel * in_sp + 16 * (channel group), or out of the descriptor's range
+        for g_ in range(NDMA):
+            E(f"ds_bpermute_b32 {v('voff', g_)}, {v('bpa', g_ & 3)}, {v('prow', g_ >> 2)}")
+        E("s_waitcnt lgkmcnt(0)")
+        E(f"v_bfrev_b32 {T[0]}, 1", "0x80000000: beyond num_records")
+        for g_ in range(NDMA):
+            E(f"v_cmp_gt_i32 vcc, 0, {v('voff', g_)}")
+            E(f"v_mad_u32_u24 {v('voff', g_)}, {v('voff', g_)}, {v('insp')}, {v('qoff')}")
+            E(f"v_cndmask_b32 {v('voff', g_)}, {v('voff', g_)}, {T[0]}, vcc")
 
 
 def emit_no_rows():
+    if S2:
+        for g_ in range(NDMA):
+            E(f"v_bfrev_b32 {v('voff', g_)}, 1")
+        return
     for k in range(NG):
         E(f"v_mov_b32 {v('prow', k)}, -1")
 
@@ -375,30 +427,11 @@ def emit_dma_base(cd_s, bd_s):
     """Per chunk: dbase = inp + (8 cd + 2 wave) * in_ss (plane 2 wave of chunk cd) and dlds = bd * CHUNK + 2 wave * PS, the operands every
     LDS-DMA instruction of that chunk starts from.  (Computing them inside each of the 12 instructions' sequences cost 13 scalar
     instructions apiece, in a stream that is bound by instruction issue.)"""
-    if KS == 1:
-        # 32-channel chunks: wave w loads the PPW planes [w PPW, (w + 1) PPW) of the chunk -- stride 2: parity plane w = (py, px), all four
-        # slots; the slots of a parity plane are 16 bytes apart in the source (in_ss == 16, the host checks), so ONE address per region-row
-        # group serves its PPW instructions through the immediate offset.  dbase = inp + (SL cd [+ wave]) * 16 [+ py in_row + px in_sp]
-        E(f"s_mul_i32 {s('tmp0')}, {cd_s}, {SL * 16}")
-        if not S2:
-            E(f"s_mul_i32 {s('tmp1')}, {s('wave')}, {PPW * 16}")
-            E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {s('tmp1')}")
-        E(f"s_add_u32 {s('dbase')}, {s('inp')}, {s('tmp0')}")
-        E(f"s_addc_u32 {s('dbase', 1)}, {s('inp', 1)}, 0")
-        if S2:
-            lp, lq = uid("py"), uid("px")
-            E(f"s_bitcmp0_b32 {s('wave')}, 1")
-            E(f"s_cbranch_scc1 {lp}")
-            E(f"s_add_u32 {s('dbase')}, {s('dbase')}, {s('in_row')}")
-            E(f"s_addc_u32 {s('dbase', 1)}, {s('dbase', 1)}, {s('in_row', 1)}")
-            label(lp)
-            E(f"s_bitcmp0_b32 {s('wave')}, 0")
-            E(f"s_cbranch_scc1 {lq}")
-            E(f"s_add_u32 {s('dbase')}, {s('dbase')}, {s('in_sp')}")
-            E(f"s_addc_u32 {s('dbase', 1)}, {s('dbase', 1)}, {s('in_sp', 1)}")
-            label(lq)
+    if S2:
+        # chunk cd = bytes 64 cd .. + 63 of every pixel (the descriptor's soffset); this wave's parity plane of ring buffer bd
+        E(f"s_lshl_b32 {s('coff')}, {cd_s}, 6")
         E(f"s_mul_i32 {s('tmp2')}, {bd_s}, {CHUNK}")
-        E(f"s_mul_i32 {s('tmp1')}, {s('wave')}, {PPW * PS}")
+        E(f"s_mul_i32 {s('tmp1')}, {s('wave')}, {PSTR}")
         E(f"s_add_u32 {s('dlds')}, {s('tmp2')}, {s('tmp1')}", "the ring starts at LDS address 0")
         return
     E(f"s_lshl_b32 {s('tmp0')}, {cd_s}, 3")
@@ -417,12 +450,11 @@ def emit_dma_base(cd_s, bd_s):
 
 def emit_dma(k, s2i, cd_s=None, bd_s=None):
     """One LDS-DMA instruction: plane 2 wave + s2i of the chunk emit_dma_base was called for, region rows 64 k .. 64 k + 63."""
-    if KS == 1:
-        # (the m0 write and the DMA are emitted by the stream around an element's MFMAs: emit_dma_m0 / emit_dma_issue)
-        emit_dma_m0(k, s2i)
-        if s2i:
-            E("s_nop 0", "hz: m0 write -> LDS-DMA")
-        emit_dma_issue(k, s2i)
+    if S2:
+        # (k = the instruction's number 0 .. NDMA - 1; in the stream the two halves sit around an element's MFMAs)
+        emit_dma_m0(k, 0)
+        E("s_nop 0", "hz: m0 write -> LDS-DMA")
+        emit_dma_issue(k, 0)
         return
     T = [v("t", i) for i in range(8, 12)]
     base = s2("dbase1") if s2i else s2("dbase")
@@ -435,21 +467,13 @@ def emit_dma(k, s2i, cd_s=None, bd_s=None):
     E(f"global_load_lds_dwordx4 v[{V.names['t'][0] + 8}:{V.names['t'][0] + 9}], off")
 
 
-def emit_dma_m0(k, s2i):
-    """KS = 1 families, first half of an LDS-DMA: its LDS address, and for the first plane of a region-row group the group's source address."""
-    E(f"s_add_u32 m0, {s('dlds')}, {s2i * PS + GROUPS[k] * 16}", "hz: m0 write -> LDS-DMA: at least one instruction before the DMA")
-    if s2i == 0:
-        d0 = V.names["dadr"][0]
-        # (an invalid row, prow = -1, multiplies out to a wild address that the select below replaces: no clamp needed)
-        E(f"v_mad_u64_u32 v[{d0}:{d0 + 1}], vcc, {v('prow', k)}, {v('insp')}, {s2('dbase')}")
-        E(f"v_cmp_gt_i32 vcc, 0, {v('prow', k)}")
-        E(f"v_cndmask_b32 v{d0}, v{d0}, {v('zero_lo')}, vcc")
-        E(f"v_cndmask_b32 v{d0 + 1}, v{d0 + 1}, {v('zero_hi')}, vcc")
+def emit_dma_m0(g_, _=0):
+    """Stride-2 family, first half of LDS-DMA instruction g_ (region rows 16 g_ .. + 15 of this wave's parity plane): its LDS address."""
+    E(f"s_add_u32 m0, {s('dlds')}, {1024 * g_}", "hz: m0 write -> LDS-DMA: at least one instruction before the DMA")
 
 
-def emit_dma_issue(k, s2i):
-    d0 = V.names["dadr"][0]
-    E(f"global_load_lds_dwordx4 v[{d0}:{d0 + 1}], off offset:{16 * s2i}")      # (the zero page holds 256 zero bytes)
+def emit_dma_issue(g_, _=0):
+    E(f"buffer_load_dwordx4 {v('voff', g_)}, {s4('srd')}, {s('coff')} offen lds")
 
 
 def emit_load_a(set_idx, k, base_s2, extra_off):
@@ -544,19 +568,50 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"v_and_b32 {v('l15')}, 15, {v('lane')}")
     E(f"v_lshrrev_b32 {v('q')}, 4, {v('lane')}")
     E(f"v_lshlrev_b32 {v('aoff')}, 4, {v('lane')}")
-    E(f"v_mul_u32_u24 {v('qps')}, {PS}, {v('q')}")
+    if S2:
+        E(f"v_lshlrev_b32 {v('qps')}, 4, {v('q')}", "stride-2 family: channel group q is 16 q bytes into a (pixel-major) region row")
+    else:
+        E(f"v_mul_u32_u24 {v('qps')}, {PS}, {v('q')}")
     E("s_waitcnt lgkmcnt(0)")
     E(f"v_mov_b32 {v('insp')}, {s('in_sp')}")
     E(f"v_mov_b32 {v('zero_lo')}, {s('zero')}")
     E(f"v_mov_b32 {v('zero_hi')}, {s('zero', 1)}")
+    if S2:
+        # descriptor of this wave's parity plane (py, px) = (wave >> 1, wave & 1): base = inp + py in_row + px in_sp, raw buffer (stride 0),
+        # num_records 2^31 (every valid offset is below it -- the host checks the tensor's size --, the padding rows' 0x80000000 is not)
+        lp, lq = uid("py"), uid("px")
+        E(f"s_mov_b32 {s('srd', 0)}, {s('inp')}")
+        E(f"s_mov_b32 {s('srd', 1)}, {s('inp', 1)}")
+        E(f"s_bitcmp0_b32 {s('wave')}, 1")
+        E(f"s_cbranch_scc1 {lp}")
+        E(f"s_add_u32 {s('srd', 0)}, {s('srd', 0)}, {s('in_row')}")
+        E(f"s_addc_u32 {s('srd', 1)}, {s('srd', 1)}, {s('in_row', 1)}")
+        label(lp)
+        E(f"s_bitcmp0_b32 {s('wave')}, 0")
+        E(f"s_cbranch_scc1 {lq}")
+        E(f"s_add_u32 {s('srd', 0)}, {s('srd', 0)}, {s('in_sp')}")
+        E(f"s_addc_u32 {s('srd', 1)}, {s('srd', 1)}, {s('in_sp', 1)}")
+        label(lq)
+        E(f"s_and_b32 {s('srd', 1)}, {s('srd', 1)}, 0xffff")
+        E(f"s_mov_b32 {s('srd', 2)}, 0x80000000")
+        E(f"s_mov_b32 {s('srd', 3)}, 0x00020000")
+        E(f"v_lshrrev_b32 {v('t', 0)}, 2, {v('lane')}", "lane / 4: the row of an instruction's 16 this lane fetches for")
+        for m_ in range(4):
+            E(f"v_add_u32 {v('bpa', m_)}, {16 * m_}, {v('t', 0)}")
+            E(f"v_lshlrev_b32 {v('bpa', m_)}, 2, {v('bpa', m_)}")
+        E(f"v_bfe_u32 {v('t', 1)}, {v('lane')}, 4, 1", "bit 2 of that row (instructions start at multiples of 16 rows)")
+        E(f"v_and_b32 {v('qoff')}, 3, {v('lane')}")
+        E(f"v_lshl_add_u32 {v('t', 1)}, {v('t', 1)}, 1, 0")
+        E(f"v_xor_b32 {v('qoff')}, {v('qoff')}, {v('t', 1)}", "position (lane & 3) of a row holds channel group (lane & 3) ^ 2 bit2(row)")
+        E(f"v_lshlrev_b32 {v('qoff')}, 4, {v('qoff')}")
     E(f"s_mul_i32 {s('HW')}, {s('H')}, {s('W')}")
     E(f"s_add_u32 {s('Wp')}, {s('W')}, 1")
     E(f"s_add_u32 {s('tmp0')}, {s('H')}, 1")
     E(f"s_mul_i32 {s('HpWp')}, {s('tmp0')}, {s('Wp')}")
     E(f"s_add_u32 {s('lead')}, {s('W')}, 2")
     E(f"s_add_u32 {s('Hpad')}, {s('tmp0')}, {s('W')}", "H + W + 1")
-    E(f"s_lshl_b32 {s('tmp0')}, {s('Wp')}, 4")
-    E(f"s_mov_b32 {s('dRow')}, {s('tmp0')}", "kernel row r -> r + 1: Wp * 16 bytes")
+    E(f"s_lshl_b32 {s('tmp0')}, {s('Wp')}, {6 if S2 else 4}")
+    E(f"s_mov_b32 {s('dRow')}, {s('tmp0')}", "kernel row r -> r + 1: Wp * 16 bytes (stride-2 family: Wp * 64)")
     E(f"s_mov_b32 {s('klog2e2')}, 0xbfb8aa3b", "-log2(e)")
     E(f"s_mov_b32 {s('klog2e2', 1)}, 0xbfb8aa3b")
     E(f"s_mov_b32 {s('kone2')}, 1.0")
@@ -596,7 +651,10 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_mov_b32 {s('cd')}, 0")
     E(f"s_mov_b32 {s('bd')}, 0")
     emit_dma_base(s("cd"), s("bd"))
-    for k in range(NG):
+    if S2:
+        for g_ in range(NDMA):
+            emit_dma(g_, 0)
+    for k in range(NG if not S2 else 0):
         for s2i in range(PPW):
             emit_dma(k, s2i, s("cd"), s("bd"))
     # bias: 256 floats per wave by LDS-DMA (lane: floats wave * 256 + 4 lane .. + 3, or zeros beyond cout)
@@ -665,6 +723,8 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_add_u32 {s('tmp2')}, {s('rs')}, {s('Wp')}")
     E(f"s_add_u32 {s('tmp2')}, {s('tmp2')}, 1", "rs + Wp + 1")
     E(f"s_mul_i32 {s('tmp3')}, {s('buf')}, {CHUNK}")
+    if S2:
+        E(f"s_add_u32 {s('tmp0')}, {s('dRow')}, 64", "one row down and one column right")
     E(f"v_lshl_add_u32 {T[7]}, {v('q')}, 2, {s('cbase')}", "cbase + 4 q")
     E(f"v_lshlrev_b32 {T[7]}, 1, {T[7]}", "bytes")
     for j in range(NB):
@@ -676,6 +736,19 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         E(f"v_add_u32 {v('oo', j)}, {v('oo', j)}, {T[7]}")
         emit_pp_of(T[5], T[4], T[0], T[1], T[2], T[3])
         E(f"v_subrev_u32 {T[5]}, {s('tmp2')}, {T[5]}")
+        if S2:
+            # four swizzled addresses per pixel block: region row (upper left neighbour) + (ry Wp + rx), 64 B per row, channel group q at
+            # position q ^ 2 bit2(row): byte bit 5 ^= byte bit 8; + the ring buffer
+            E(f"v_lshl_add_u32 {T[5]}, {T[5]}, 6, {v('qps')}", "linear byte address of (row, group q): qps = 16 q here")
+            for o in range(4):
+                src = T[5]
+                if o:
+                    E(f"v_add_u32 {T[0]}, {s('dRow') if o == 2 else (64 if o == 1 else s('tmp0'))}, {T[5]}")
+                    src = T[0]
+                E(f"v_lshrrev_b32 {T[1]}, 3, {src}")
+                E(f"v_and_b32 {T[1]}, 32, {T[1]}")
+                E(f"v_xad_u32 {v('addr', 4 * j + o)}, {src}, {T[1]}, {s('tmp3')}")
+            continue
         E(f"v_lshl_add_u32 {v('addr', j)}, {T[5]}, 4, {v('qps')}")
         E(f"v_add_u32 {v('addr', j)}, {s('tmp3')}, {v('addr', j)}")
     # accumulators start from the bias: LDS reads straight into the accumulator registers (3 NB reads instead of 12 NB register moves)
@@ -1011,18 +1084,22 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             h, j = divmod(n, NB)
             t, ks = divmod(h, KS)
             # the pixel block's address moves once per kernel ROW (taps 0, 3, 6); the column and the k-step are immediate offsets
+            if S2:
+                # tap (dy, dx) = divmod(t, 3): parity plane (dy != 1, dx != 1) -- plane index as the waves load them, 2 py + px -- as the
+                # immediate offset; the (row, column) offset (dy >= 1, dx >= 1) picks one of the block's four swizzled addresses, each of
+                # which moves to the chunk's ring buffer at its first use (taps 0, 1, 3, 4)
+                dy, dx = divmod(t, 3)
+                o = 2 * (dy >= 1) + (dx >= 1)
+                if t in (0, 1, 3, 4):
+                    E(f"v_add_u32 {v('addr', 4 * j + o)}, {s('delta0')}, {v('addr', 4 * j + o)}")
+                if not abl & 4:
+                    E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', 4 * j + o)} offset:{(2 * (dy != 1) + (dx != 1)) * PSTR}")
+                return
             if ks == 0 and t == 0:
                 E(f"v_add_u32 {v('addr', j)}, {s('delta0')}, {v('addr', j)}")
-            elif ks == 0 and (t == 3 if S2 else t % 3 == 0):
+            elif ks == 0 and t % 3 == 0:
                 E(f"v_add_u32 {v('addr', j)}, {s('dRow')}, {v('addr', j)}")
-            if S2:
-                # tap (dy, dx) = divmod(t, 3): parity plane (dy != 1, dx != 1) -- plane index as the waves load them, 2 py + px --, column dx >= 1;
-                # the row (dy >= 1) is in the address: it moves once per chunk, at tap 3
-                dy, dx = divmod(t, 3)
-                off = (2 * (dy != 1) + (dx != 1)) * SL * PS + 16 * (dx >= 1)
-            else:
-                off = 16 * (t % 3) + (4 * PS if ks else 0)
-            assert off < 65536
+            off = 16 * (t % 3) + (4 * PS if ks else 0)
             if not abl & 4:
                 E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)} offset:{off}")
 
@@ -1047,7 +1124,9 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             if DMA_FRONT and t == 0 and not abl & 2:
                 assert 12 + 2 * NG <= 2 * NB
                 ops += [(12 + 2 * k + h, "D", k, h) for k in range(NG) for h in range(2)]
-            elif not DMA_FRONT and t < NG and not abl & 2:
+            elif S2 and not abl & 2:
+                ops += [(DPOS[i_], "D", g_, 0) for i_, g_ in enumerate(DMA_TAPS[t])]
+            elif not S2 and not DMA_FRONT and t < NG and not abl & 2:
                 ops += [(DPOS[h], "D", t, h) for h in range(PPW)]
             if in_stream_res and last:
                 for g, j in enumerate(res_groups[t]):
@@ -1148,8 +1227,11 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_cselect_b32 {s('tmp0')}, 0, {s('tmp0')}", "next buffer")
     E(f"s_sub_i32 {s('tmp1')}, {s('tmp0')}, {s('buf')}")
     E(f"s_mul_i32 {s('tmp1')}, {s('tmp1')}, {CHUNK}")
-    E(f"s_lshl_b32 {s('tmp2')}, {s('Wp')}, {4 if S2 else 5}", "2 Wp * 16: back from kernel row 2 to row 0 (stride 2: one row step per chunk)")
-    E(f"s_sub_i32 {s('delta0')}, {s('tmp1')}, {s('tmp2')}")
+    if S2:
+        E(f"s_mov_b32 {s('delta0')}, {s('tmp1')}", "stride-2 family: the row offsets live in separate address registers")
+    else:
+        E(f"s_lshl_b32 {s('tmp2')}, {s('Wp')}, 5", "2 Wp * 16: back from kernel row 2 to row 0")
+        E(f"s_sub_i32 {s('delta0')}, {s('tmp1')}, {s('tmp2')}")
     E(f"s_mov_b32 {s('buf')}, {s('tmp0')}")
     E(f"s_mov_b32 {s('first')}, 0")
     E(f"s_add_u32 {s('c')}, {s('c')}, 1")

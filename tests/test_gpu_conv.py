@@ -335,7 +335,7 @@ def test_planar_conv3x3_s2_rejects_what_it_cannot_tile(lib):
     assert not L.aq_conv3x3_pl_s2_supported(192, 384, 2, 81, 80) and not L.aq_conv3x3_pl_s2_supported(192, 384, 2, 80, 82 + 1)
     assert not L.aq_conv3x3_pl_s2_supported(48, 192, 2, 80, 80) and not L.aq_conv3x3_pl_s2_supported(192, 200, 2, 80, 80)
     assert not L.aq_conv3x3_pl_s2_supported(96, 192, 64, 160, 160)        # model.3: an 80-pixel output row does not fit the 304-row region
-    x = torch.zeros(1, 160, 160, 96, dtype=torch.bfloat16, device="cuda")
+    x = torch.zeros(2, 160, 160, 96, dtype=torch.bfloat16, device="cuda")       # (a single image has no seam and would still fit)
     with pytest.raises(RuntimeError, match="unsupported"):
         engine.conv3x3_pl_s2_nhwc(x, torch.zeros(192, 96, 3, 3), torch.zeros(192))
 
