@@ -28,7 +28,7 @@ void aq_set_error(const char* fmt, ...);
         }                                                                               \
     } while (0)
 
-static inline int aq_elem_bytes(int precision) { return precision == AQ_FP32 ? 4 : 2; }
+static inline int aq_elem_bytes(int precision) { return (precision == AQ_FP32 || precision == AQ_F16X3) ? 4 : 2; }
 
 // f32 -> bf16 round-to-nearest-even (finite inputs; NaN stays NaN via the quiet bit)
 __host__ __device__ static inline bf16_t aq_f2bf(float f) {
@@ -60,6 +60,7 @@ struct ConvParams {
     int act;
     int n_tiles_m, n_tiles_n;
     int bias_n;          // bias entries staged into LDS (filled by aq_launch_conv)
+    int x3_off;          // AQ_F16X3: the per-channel 2^-s follow the (scaled) bias at this float offset of `bias`
     unsigned long long* debug;   // diagnostic (stamped) builds only: per-wave phase cycle sums
     int halo, xrows, nixr, xper;   // conv_halo.hip: W + 1, region rows in LDS, region rows / 8, loads per step part
     float inv_hw, inv_wo;        // reciprocals for division-free pixel decode (filled by aq_launch_conv)

@@ -330,6 +330,7 @@ int aq_launch_conv_halo(const ConvParams& p_in, int precision, int out_f32, int 
     if (hcfg < 0 || hcfg >= kNumHalo) { aq_set_error("halo conv: bad config %d", hcfg); return AQ_ERR_INVALID; }
     const HaloConfig& k = kHalo[hcfg];
     ConvParams p = p_in;
+    if (precision == AQ_F16X3) { aq_set_error("halo conv: no split-mode (AQ_F16X3) build"); return AQ_ERR_INVALID; }
     if (p.k != 3 || p.stride != 1 || p.pad != 1 || p.H != p.Ho || p.W != p.Wo || (out_f32 && precision != AQ_FP32)) {
         aq_set_error("halo conv: only 3x3 / stride 1 / pad 1 layers with same-precision output");
         return AQ_ERR_INVALID;

@@ -19,6 +19,16 @@
 //
 // fp32 parity mode uses the same byte geometry (a 16-byte group = 4 floats) on v_mfma_f32_32x32x2_f32,
 // which is bit-for-bit an fmaf chain (exact fp32 products, fp32 accumulate).
+//
+// AQ_F16X3 ("split" mode, round 3): fp32 activations in HBM and LDS exactly as in fp32 mode, but every product is THREE fp16 MFMAs on
+// hi / lo halves -- x = xh + xl with xh = fp16(x), xl = fp16(x - xh) (22 significant bits), the weights split the same way on the
+// host after a per-output-channel power-of-two scale that keeps both halves in fp16's normal range, and
+// acc += wh xh + wh xl + wl xh (the dropped wl xl is 2^-22 of the product) into the fp32 accumulator.  v_mfma_f32_32x32x16_f16 runs at
+// 16x the f32-input MFMA's rate, so a 32-channel chunk costs 2 x 3 x 32 cycles per 32x32 block instead of 16 x 64; the activations are
+// split in registers between the LDS read and the MFMAs (five VALU instructions per pair of values).  A weight row holds, per 8
+// channels, 16 bytes of hi halves then 16 bytes of lo halves -- the same bytes per channel as fp32, so the loader, the K walk and
+// the LDS image are those of fp32 mode; a lane reads slots (4 ks + 2 h, + 1) of both operands: hi / lo of its 8 channels (weights),
+// 2 x 4 floats of the same 8 channels (activations).  Epilogue: (acc + bias 2^s) 2^-s, which is exact, then fp32 mode's.
 #include "aq_common.h"
 #include <type_traits>
 
@@ -64,8 +74,24 @@ constexpr int conv_min_waves(int bm, int bn, int nw, int nstage) {
     return w > 8 ? 8 : w;
 }
 
-template <bool F32, int BM, int BN, int WM, int WN, bool OUT_F32, int NSTAGE, bool BIAS_LDS, bool STAMP = false>
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+// x[0..7] (fp32) -> hi = fp16(x) and lo = fp16(x - hi), element-wise (v_cvt_pk_f16_f32, v_cvt_f32_f16 x 2, v_pk_add_f32, v_cvt_pk_f16_f32
+// per pair).  x - float(hi) is exact in fp32 (hi keeps x's leading 11 bits), so hi + lo carries 22 bits of x.
+__device__ __forceinline__ void split_f16(const f32x4& x0, const f32x4& x1, f16x8& hi, f16x8& lo) {
+    const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h = (_Float16)x[e];
+        hi[e] = h;
+        lo[e] = (_Float16)(x[e] - (float)h);
+    }
+}
+
+template <bool F32, int BM, int BN, int WM, int WN, bool OUT_F32, int NSTAGE, bool BIAS_LDS, bool STAMP = false, bool X3 = false>
 __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAGE)) void conv_igemm_kernel(const ConvParams p) {
+    static_assert(!X3 || (F32 && OUT_F32), "split mode keeps fp32 activations");
     constexpr int NW = WM * WN;
     static_assert(NSTAGE == 2 || NSTAGE == 3, "pipeline depth");
     constexpr int ROWB = 128;                 // LDS bytes per row = one K chunk
@@ -119,10 +145,15 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
     // so nothing in it makes the compiler drain the in-flight LDS-DMA prefetches (vmcnt is in-order).
     // (BIAS_LDS = false for the one shape whose two resident workgroups use all 160 KiB already.)
     const float* sbias = p.bias;
+    const float* sscale = p.bias + p.x3_off;                  // split mode: 2^-s per output channel, behind the (scaled) bias
     if constexpr (BIAS_LDS) {
         float* sb = (float*)(smem + NSTAGE * BUF);
         for (int i = tid; i < p.bias_n; i += NW * 64) sb[i] = p.bias[i];
         sbias = sb;
+        if constexpr (X3) {
+            for (int i = tid; i < p.bias_n; i += NW * 64) sb[p.bias_n + i] = p.bias[p.x3_off + i];
+            sscale = sb + p.bias_n;
+        }
     }
 
     // ---------------- loader state (for the tile being staged) ----------------
@@ -239,6 +270,34 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
     // Fragment reads are software-pipelined: the ds_read_b128s of k-step ks+1 are issued before the MFMAs of k-step ks
     // (second register set), so the matrix pipe does not wait on LDS latency between k-steps.
     auto compute = [&](const char* buf, const StageCtx& nx) {
+        if constexpr (X3) {
+            // two k-steps of 16 channels; this lane's 8 channels of a step sit in slots 4 ks + 2 h and 4 ks + 2 h + 1 of both operands
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int s0 = (((4 * ks + 2 * h) ^ sw) << 4), s1 = (((4 * ks + 2 * h + 1) ^ sw) << 4);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *(const f16x8*)(buf + a_off + i * 32 * ROWB + s0);
+                    al[i] = *(const f16x8*)(buf + a_off + i * 32 * ROWB + s1);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    split_f16(*(const f32x4*)(buf + b_off + j * 32 * ROWB + s0), *(const f32x4*)(buf + b_off + j * 32 * ROWB + s1), bh[j], bl[j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);   // small terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int i = 0; i < NL; ++i)
+                    if ((i * 2) / NL == ks) stage_slot(nx, i);     // this k-step's share of the next stage's LDS-DMA
+            }
+            return;
+        }
         using frag_t = typename std::conditional<F32, f32x4, bf16x8>::type;
         frag_t a[2][TM], b[2][TN];
         auto load_frags = [&](int ks, frag_t (&fa)[TM], frag_t (&fb)[TN]) {
@@ -309,9 +368,12 @@ __global__ __launch_bounds__(WM * WN * 64, conv_min_waves(BM, BN, WM * WN, NSTAG
                     const f32x4 bv = *(const f32x4*)(sbias + cblk + cl);
                     f32x4 v;
                     if constexpr (F32) {
+                        f32x4 sv = {1.0f, 1.0f, 1.0f, 1.0f};
+                        if constexpr (X3) sv = *(const f32x4*)(sscale + cblk + cl);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float t = acc[i][j][4 * g + e] + bv[e];
+                            if constexpr (X3) t *= sv[e];          // (acc + b 2^s) 2^-s: exact
                             if (p.act) t = silu<true>(t);
                             v[e] = t;
                         }
@@ -462,11 +524,13 @@ struct ConvConfig {
     void (*bf16)(const ConvParams);
     void (*bf16_f32out)(const ConvParams);
     void (*f32)(const ConvParams);
+    void (*x3)(const ConvParams);      // AQ_F16X3: fp32 activations, products as three fp16 MFMAs on hi / lo halves
 };
 
 #define CFG(BM, BN, WM, WN, NS, BL)                                                                    \
     { BM, BN, WM * WN * 64, BM / WM / 32, NS, BL, conv_igemm_kernel<false, BM, BN, WM, WN, false, NS, BL>, \
-      conv_igemm_kernel<false, BM, BN, WM, WN, true, NS, BL>, conv_igemm_kernel<true, BM, BN, WM, WN, true, NS, BL> }
+      conv_igemm_kernel<false, BM, BN, WM, WN, true, NS, BL>, conv_igemm_kernel<true, BM, BN, WM, WN, true, NS, BL>,      \
+      conv_igemm_kernel<true, BM, BN, WM, WN, true, NS, BL, false, true> }
 
 const ConvConfig kConfigs[] = {
     CFG(256, 256, 2, 4, 2, true),   // 0: per-wave 128x64
@@ -507,9 +571,9 @@ size_t g_stamp_bytes = 0;
 
 // dynamic LDS: NSTAGE K-chunk buffers (the epilogue staging lives inside the just-consumed one)
 size_t conv_lds_bytes(const ConvConfig& k, int bias_n) { return (size_t)k.nstage * (k.bm + k.bn) * 128 + (k.bias_lds ? (size_t)bias_n * 4 : 0); }
-bool g_attr_set[kNumConfigs][3];
+bool g_attr_set[kNumConfigs][4];
 struct OccEntry { size_t lds; int blocks; };
-OccEntry g_occ[kNumConfigs][3][8];   // resident blocks per CU by dynamic-LDS size (a handful of sizes per kernel)
+OccEntry g_occ[kNumConfigs][4][8];   // resident blocks per CU by dynamic-LDS size (a handful of sizes per kernel)
 int g_num_cus = 0;
 
 }  // namespace
@@ -589,10 +653,14 @@ int aq_launch_conv(const ConvParams& p_in, int precision, int out_f32, int cfg_i
     p.magic_k = (unsigned)(0x100000000ull / (unsigned)p.k) + 1u;
     p.n_tiles_m = (p.cout + k.bm - 1) / k.bm;
     p.n_tiles_n = (p.npix + k.bn - 1) / k.bn;
-    const int variant = precision == AQ_FP32 ? 2 : (out_f32 ? 1 : 0);
-    auto fn = variant == 2 ? k.f32 : (variant == 1 ? k.bf16_f32out : k.bf16);
+    const int variant = precision == AQ_F16X3 ? 3 : precision == AQ_FP32 ? 2 : (out_f32 ? 1 : 0);
+    auto fn = variant == 3 ? k.x3 : variant == 2 ? k.f32 : (variant == 1 ? k.bf16_f32out : k.bf16);
     p.bias_n = ((p.cout + k.bm - 1) / k.bm) * k.bm;   // every tile row has a bias slot (bias buffer is zero padded)
-    const size_t lds = conv_lds_bytes(k, p.bias_n);
+    if (variant == 3 && (p.x3_off < p.bias_n || (p.G % 2) != 0)) {
+        aq_set_error("conv: split mode needs the packer's bias / scale buffer and Cin %% 8 == 0");
+        return AQ_ERR_INVALID;
+    }
+    const size_t lds = conv_lds_bytes(k, variant == 3 ? 2 * p.bias_n : p.bias_n);
     if (lds > 160 * 1024) { aq_set_error("conv: config %d needs %zu B of LDS", cfg, lds); return AQ_ERR_INVALID; }
     if (!g_attr_set[cfg][variant]) {
         AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

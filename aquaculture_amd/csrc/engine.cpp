@@ -61,6 +61,7 @@ struct PackedW {
     void* w = nullptr;      // [cout_rows][kgroups_pad] x 16 B
     float* bias = nullptr;  // [cout_rows]
     int kgroups = 0, kgroups_pad = 0, G = 0, cout_rows = 0;
+    bool x3 = false;            // AQ_F16X3 engine: this conv runs in split mode (weights as fp16 hi / lo halves; bias = [bias 2^s | 2^-s])
     void* w_direct = nullptr;   // layers a direct kernel supports: its A-fragment image (csrc/conv1x1_direct.hip, csrc/downblock.hip)
     int direct_cfg = -1;        // AQ_CONV_CFG_DIRECT1X1 / AQ_CONV_CFG_DIRECT3X3S2 / AQ_CONV_CFG_PL3X3 / AQ_CONV_CFG_PL3X3S2
     void* w_head = nullptr;     // bf16 engines, Detect head convs with a small head: aq_pack_head_weights image (csrc/head_decode.hip)
@@ -86,6 +87,58 @@ void pack_host(const float* w, int cout, int k, int cin, int precision, std::vec
         } else {
             bf16_t* d = (bf16_t*)dst;
             for (int e = 0; e < kelems; ++e) d[e] = aq_f2bf(src[e]);
+        }
+    }
+    *kgroups = kg; *kgroups_pad = kgp; *G = g; *cout_rows = rows;
+}
+
+// fp32 -> fp16 bits, round to nearest even (finite inputs inside fp16's range; subnormal results included)
+uint16_t f2h(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+float h2f(uint16_t u) {
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return (float)h;
+}
+
+// AQ_F16X3: row co of the packed image holds, per 8 input channels of a tap, 8 fp16 hi halves then 8 fp16 lo halves of w * 2^s[co]
+// (the same bytes per channel as fp32, so kgroups / G / the K walk are fp32 mode's); bias_scale = [bias * 2^s | 2^-s], `rows` each.
+void pack_host_x3(const float* w, const float* bias, int cout, int k, int cin, std::vector<unsigned char>& out, std::vector<float>& bias_scale,
+                  int* kgroups, int* kgroups_pad, int* G, int* cout_rows) {
+    const int g = cin * 4 / 16;
+    const int kg = k * k * g;
+    const int kgp = (kg + 7) / 8 * 8;
+    const int rows = (cout + kCoutSlack + 31) / 32 * 32;
+    out.assign((size_t)rows * kgp * 16, 0);
+    bias_scale.assign((size_t)2 * rows, 0.0f);
+    for (int r = 0; r < rows; ++r) bias_scale[rows + r] = 1.0f;
+    const int kelems = k * k * cin;
+    for (int co = 0; co < cout; ++co) {
+        const float* src = w + (size_t)co * kelems;
+        float amax = 0.0f;
+        for (int e = 0; e < kelems; ++e) amax = fmaxf(amax, fabsf(src[e]));
+        int sexp = 0;
+        if (amax > 0.0f && std::isfinite(amax)) {
+            int ex = 0;
+            frexpf(amax, &ex);                    // amax = f * 2^ex, f in [0.5, 1)
+            sexp = 15 - ex;                       // amax * 2^s in [2^14, 2^15)
+            sexp = sexp > 60 ? 60 : (sexp < -60 ? -60 : sexp);
+        }
+        const float sc = ldexpf(1.0f, sexp);
+        bias_scale[co] = bias ? bias[co] * sc : 0.0f;
+        bias_scale[rows + co] = ldexpf(1.0f, -sexp);
+        uint16_t* dst = (uint16_t*)(out.data() + (size_t)co * kgp * 16);
+        for (int e0 = 0; e0 < kelems; e0 += 8) {  // (cin % 8 == 0: a group of 8 never straddles taps)
+            for (int e = 0; e < 8; ++e) {
+                const float v = src[e0 + e] * sc;
+                const uint16_t hi = f2h(v);
+                dst[2 * e0 + e] = hi;
+                dst[2 * e0 + 8 + e] = f2h(v - h2f(hi));
+            }
         }
     }
     *kgroups = kg; *kgroups_pad = kgp; *G = g; *cout_rows = rows;
@@ -235,7 +288,8 @@ int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStr
                                  op.src.channels, op.dst.channels, pw.w_direct, pw.bias, (long long)B * pd.h * pd.w, op.act, stream);
     }
     if (cfg < 0) cfg = aq_conv_pick_config(p.cout, p.npix, prec);
-    return aq_launch_conv(p, prec, out_f32, cfg, stream);
+    if (pw.x3) p.x3_off = pw.cout_rows;
+    return aq_launch_conv(p, pw.x3 ? (int)AQ_F16X3 : prec, out_f32, cfg, stream);
 }
 
 int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, size_t ws_bytes,
@@ -402,20 +456,40 @@ extern "C" int aq_pack_conv_weights(const float* w, int cout, int k, int cin, in
     return AQ_OK;
 }
 
+extern "C" int aq_pack_conv_weights_x3(const float* w, const float* bias, int cout, int k, int cin, void* packed_dev, size_t* bytes,
+                                       float* bias_scale_dev, size_t* bias_floats, void* stream) {
+    AQ_REQUIRE(w && bytes && bias_floats, "pack_conv_weights_x3: null pointer");
+    AQ_REQUIRE(cout > 0 && k > 0 && cin > 0 && cin % 8 == 0, "pack_conv_weights_x3: cin %d is not a multiple of 8", cin);
+    std::vector<unsigned char> host;
+    std::vector<float> bs;
+    int kg, kgp, g, rows;
+    pack_host_x3(w, bias, cout, k, cin, host, bs, &kg, &kgp, &g, &rows);
+    *bytes = host.size();
+    *bias_floats = bs.size();
+    if (!packed_dev) return AQ_OK;
+    AQ_REQUIRE(bias && bias_scale_dev, "pack_conv_weights_x3: null pointer");
+    AQ_CHECK_HIP(hipMemcpyAsync(packed_dev, host.data(), host.size(), hipMemcpyHostToDevice, (hipStream_t)stream));
+    AQ_CHECK_HIP(hipMemcpyAsync(bias_scale_dev, bs.data(), bs.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    AQ_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return AQ_OK;
+}
+
 extern "C" int aq_conv2d(const void* in_dev, int in_ld, int in_choff, int cin, void* out_dev, int out_ld, int out_choff,
                          int cout, const void* res_dev, int res_ld, int res_choff, const void* packed_w_dev,
                          const float* bias_dev, int B, int H, int W, int k, int stride, int pad, int act, int precision,
                          int out_f32, const void* zero_page_dev, void* stream) {
     AQ_REQUIRE(in_dev && out_dev && packed_w_dev && bias_dev && zero_page_dev, "conv2d: null pointer");
     const int eb = aq_elem_bytes(precision);
-    const int oeb = (precision == AQ_FP32 || out_f32) ? 4 : 2;
+    const int oeb = (eb == 4 || out_f32) ? 4 : 2;
     AQ_REQUIRE((cin * eb) % 16 == 0 && (in_ld * eb) % 16 == 0 && (in_choff * eb) % 16 == 0,
                "conv2d: input channels must be whole 16-byte groups (cin=%d ld=%d off=%d)", cin, in_ld, in_choff);
     AQ_REQUIRE(cout % 8 == 0 && out_choff % 8 == 0 && out_ld % 8 == 0, "conv2d: cout/out_choff/out_ld must be multiples of 8");
     AQ_REQUIRE(!res_dev || (res_choff % 8 == 0 && res_ld % 8 == 0), "conv2d: residual slice must be 8-channel aligned");
     AQ_REQUIRE(k >= 1 && k * k <= 25 && stride >= 1 && pad >= 0, "conv2d: unsupported k=%d stride=%d pad=%d", k, stride, pad);
-    AQ_REQUIRE(precision == AQ_BF16 || precision == AQ_FP32, "conv2d: bad precision %d", precision);
+    AQ_REQUIRE(precision == AQ_BF16 || precision == AQ_FP32 || precision == AQ_F16X3, "conv2d: bad precision %d", precision);
+    AQ_REQUIRE(precision != AQ_F16X3 || cin % 8 == 0, "conv2d: split mode needs cin %% 8 == 0");
     ConvParams p{};
+    p.x3_off = precision == AQ_F16X3 ? (cout + kCoutSlack + 31) / 32 * 32 : 0;      // bias_dev = aq_pack_conv_weights_x3's bias / scale buffer
     p.in = (const char*)in_dev + (size_t)in_choff * eb; p.in_ld_b = in_ld * eb;
     p.out = (char*)out_dev + (size_t)out_choff * oeb; p.out_ld_b = out_ld * oeb;
     if (res_dev) { p.res = (const char*)res_dev + (size_t)res_choff * eb; p.res_ld_b = res_ld * eb; }
@@ -436,7 +510,8 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
     AQ_REQUIRE(d && out, "engine_create: null pointer");
     AQ_REQUIRE(d->n_ops > 0 && d->n_tensors > 0 && d->ops && d->tensors, "engine_create: empty plan");
     AQ_REQUIRE(d->nl == 3 && d->na >= 1 && d->na <= 8 && d->nc >= 1, "engine_create: unsupported head nl=%d na=%d nc=%d", d->nl, d->na, d->nc);
-    AQ_REQUIRE(d->precision == AQ_BF16 || d->precision == AQ_FP32 || d->precision == AQ_BF16_W8, "engine_create: bad precision %d", d->precision);
+    AQ_REQUIRE(d->precision == AQ_BF16 || d->precision == AQ_FP32 || d->precision == AQ_BF16_W8 || d->precision == AQ_F16X3,
+               "engine_create: bad precision %d", d->precision);
     {   // One device per process (one process per GPU is how every entry point of this package runs): the kernels' launch-attribute,
         // CU-count and occupancy caches in conv_igemm / conv_halo / downblock / conv1x1_direct / detect_nms are process-global, and
         // hipFuncSetAttribute is per device -- a second device would skip it and fail to launch anything above 64 KiB of LDS.
@@ -451,6 +526,10 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
     aq_model_desc compute_desc = *d;                   // AQ_BF16_W8 computes exactly as AQ_BF16; only the planar 3x3 weight stream differs
     const bool w8 = d->precision == AQ_BF16_W8;
     if (w8) compute_desc.precision = AQ_BF16;
+    // AQ_F16X3 is AQ_FP32 everywhere (tensors, stem, pools, head, decode) except inside the implicit-GEMM convs, which take their
+    // products as three fp16 MFMAs on split operands (conv_igemm.hip); a conv whose Cin is not a multiple of 8 stays on the fp32 kernel
+    const bool x3 = d->precision == AQ_F16X3;
+    if (x3) compute_desc.precision = AQ_FP32;
     d = &compute_desc;
     e->desc = *d;
     e->tensors.assign(d->tensors, d->tensors + d->n_tensors);
@@ -547,9 +626,15 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
         }
         std::vector<unsigned char> host;
         PackedW& pw = e->packed[oi];
-        pack_host(op.weight, op.dst.channels, op.k, op.src.channels, d->precision, host, &pw.kgroups, &pw.kgroups_pad, &pw.G, &pw.cout_rows);
-        std::vector<float> bias(pw.cout_rows, 0.0f);
-        memcpy(bias.data(), op.bias, sizeof(float) * op.dst.channels);
+        std::vector<float> bias;
+        if (x3 && op.src.channels % 8 == 0) {
+            pack_host_x3(op.weight, op.bias, op.dst.channels, op.k, op.src.channels, host, bias, &pw.kgroups, &pw.kgroups_pad, &pw.G, &pw.cout_rows);
+            pw.x3 = true;
+        } else {
+            pack_host(op.weight, op.dst.channels, op.k, op.src.channels, d->precision, host, &pw.kgroups, &pw.kgroups_pad, &pw.G, &pw.cout_rows);
+            bias.assign(pw.cout_rows, 0.0f);
+            memcpy(bias.data(), op.bias, sizeof(float) * op.dst.channels);
+        }
         if (hipMalloc(&pw.w, host.size()) != hipSuccess || hipMalloc((void**)&pw.bias, bias.size() * sizeof(float)) != hipSuccess) {
             aq_set_error("engine_create: weight allocation failed (op %zu, %zu bytes)", oi, host.size());
             return fail(AQ_ERR_NOMEM);

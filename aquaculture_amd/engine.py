@@ -22,11 +22,11 @@ import torch
 from . import spec as _spec
 from .checkpoint import Checkpoint, pack_plan_weights
 
-AQ_BF16, AQ_FP32, AQ_BF16_W8 = 0, 1, 2
-PRECISIONS = {"bf16": AQ_BF16, "fp32": AQ_FP32, "fp8w": AQ_BF16}
+AQ_BF16, AQ_FP32, AQ_BF16_W8, AQ_F16X3 = 0, 1, 2, 3
+PRECISIONS = {"bf16": AQ_BF16, "fp32": AQ_FP32, "fp8w": AQ_BF16, "f16x3": AQ_F16X3}
 """Compute precision of the single-op helpers.  fp8w = fp8 (OCP e4m3fn) weights with per-output-channel power-of-two scales, bf16
 activations (quant.py): values bf16 holds exactly, so every bf16 kernel runs them as they are."""
-ENGINE_PRECISIONS = {"bf16": AQ_BF16, "fp32": AQ_FP32, "fp8w": AQ_BF16_W8}
+ENGINE_PRECISIONS = {"bf16": AQ_BF16, "fp32": AQ_FP32, "fp8w": AQ_BF16_W8, "f16x3": AQ_F16X3}
 """aq_model_desc.precision.  AQ_BF16_W8 computes as AQ_BF16; kernels with an fp8-weight stream (the planar 3x3) load the e4m3 codes."""
 _DTYPE_CODE = {"act": 0, "f32": 1, "u8": 2}
 
@@ -67,7 +67,7 @@ EXPORTS = (
     "aq_engine_infer", "aq_engine_forward_raw", "aq_engine_tensor_ptr", "aq_engine_profile",
     "aq_engine_op_times", "aq_engine_num_ops", "aq_engine_set_conv_config", "aq_engine_autotune", "aq_engine_set_tuned_table",
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
-    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_stemdown_supported", "aq_stemdown", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
+    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_pack_conv_weights_x3", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_stemdown_supported", "aq_stemdown", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
     "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct",
     "aq_conv3x3_pl_supported", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_s2_supported", "aq_pack_conv3x3_pl_s2", "aq_conv3x3_pl_s2", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_letterbox_tiles_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
@@ -105,6 +105,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_debug_mfma_peak.argtypes = [i32, i32, vp, vp]
     lib.aq_conv_config_tiles.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
     lib.aq_pack_conv_weights.argtypes = [C.POINTER(f32), i32, i32, i32, i32, vp, C.POINTER(sz), vp]
+    lib.aq_pack_conv_weights_x3.argtypes = [C.POINTER(f32), C.POINTER(f32), i32, i32, i32, vp, C.POINTER(sz), vp, C.POINTER(sz), vp]
     lib.aq_conv2d.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, i32, vp, vp,
                               i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.aq_pack_stem_weights.argtypes = [C.POINTER(f32), i32, i32, vp, C.POINTER(sz), vp]
@@ -159,7 +160,7 @@ def _require_gpu() -> None:
 
 
 def _act_dtype(precision: int) -> torch.dtype:
-    return torch.float32 if precision == AQ_FP32 else torch.bfloat16
+    return torch.float32 if precision in (AQ_FP32, AQ_F16X3) else torch.bfloat16
 
 
 class Engine:
@@ -176,7 +177,7 @@ class Engine:
         self.device = torch.device("cuda", device)
         if fused_bottleneck is None:
             fused_bottleneck = precision in ("bf16", "fp8w")
-        if fused_bottleneck and precision == "fp32":
+        if fused_bottleneck and precision in ("fp32", "f16x3"):
             raise ValueError("the fused Bottleneck kernel is bf16 only")
         self.plan = _spec.build_plan(ck.variant, ck.nc, ck.na, fused_stem=fused_stem, fused_bottleneck=fused_bottleneck)
         self.no = ck.nc + 5
@@ -410,10 +411,20 @@ def conv2d_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, strid
     cout, _, k, _ = w_oihw.shape
     pad = k // 2 if pad is None else pad
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    wbuf = pack_conv_weights(w_oihw, precision, x.device)
-    bbuf = torch.zeros(cout + 512, dtype=torch.float32, device=x.device)
-    bbuf[:cout] = bias.float().to(x.device)
-    odt = torch.float32 if (out_f32 or prec == AQ_FP32) else torch.bfloat16
+    if prec == AQ_F16X3:          # split mode: the packer writes the weights' fp16 halves and the bias / scale buffer the kernel reads
+        wk = np.ascontiguousarray(w_oihw.permute(0, 2, 3, 1).float().cpu().numpy())
+        bh = np.ascontiguousarray(bias.float().cpu().numpy())
+        n, nb = C.c_size_t(), C.c_size_t()
+        wp_, bp_ = wk.ctypes.data_as(C.POINTER(C.c_float)), bh.ctypes.data_as(C.POINTER(C.c_float))
+        _check(lib.aq_pack_conv_weights_x3(wp_, bp_, cout, k, cin, None, C.byref(n), None, C.byref(nb), None))
+        wbuf = torch.empty(n.value, dtype=torch.uint8, device=x.device)
+        bbuf = torch.empty(nb.value, dtype=torch.float32, device=x.device)
+        _check(lib.aq_pack_conv_weights_x3(wp_, bp_, cout, k, cin, wbuf.data_ptr(), C.byref(n), bbuf.data_ptr(), C.byref(nb), _stream_ptr()))
+    else:
+        wbuf = pack_conv_weights(w_oihw, precision, x.device)
+        bbuf = torch.zeros(cout + 512, dtype=torch.float32, device=x.device)
+        bbuf[:cout] = bias.float().to(x.device)
+    odt = torch.float32 if (out_f32 or prec in (AQ_FP32, AQ_F16X3)) else torch.bfloat16
     out = torch.empty((B, Ho, Wo, cout), dtype=odt, device=x.device)
     res_ptr = residual.data_ptr() if residual is not None else None
     old = os.environ.get("AQ_CONV_CFG")

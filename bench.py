@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--batch", type=int, default=64)
     p.add_argument("--size", type=int, default=640)
     p.add_argument("--variant", default="yolov5m")
-    p.add_argument("--precision", default="bf16", choices=("bf16", "fp32", "fp8w"),
+    p.add_argument("--precision", default="bf16", choices=("bf16", "fp32", "fp8w", "f16x3"),
                    help="fp8w = BASELINE.json configs[3]: OCP e4m3 weights with per-channel power-of-two scales, bf16 activations and MFMA")
     p.add_argument("--pool", type=int, default=8, help="distinct synthetic batches kept in HBM and cycled (8 x 64 tiles = 629 MB of input, "
                                                        "beyond the 256 MB Infinity Cache)")
@@ -318,6 +318,8 @@ def main() -> int:
             shape = cbest & (aqengine.CONV_CFG_ONE_TILE_PER_WG - 1)
             if not one_per_wg and cbest == aqengine.CONV_CFG_PL3X3:
                 kname = "conv3x3_pl_asm_nb13 / conv3x3_pl_kernel (planar 3x3/s1: weights streamed to registers, slot-major region in LDS; generated gfx950 assembly build, HIP-source fallback)"
+            elif not one_per_wg and cbest == aqengine.CONV_CFG_PL3X3S2:
+                kname = "conv3x3_pl_asm_s2nb13 (planar 3x3/s2: parity planes of the input as pixel-major swizzled region rows, LDS-DMA through a buffer descriptor; generated gfx950 assembly)"
             elif not one_per_wg and cbest >= 1000:
                 kname = "downblock_kernel<96, 192> (direct 3x3/s2)"
             else:
@@ -353,7 +355,7 @@ def main() -> int:
             pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": f"conv3x3_pl_asm_nb13 (planar 3x3/s1, assembly build) / conv3x3_halo_kernel / conv_igemm_kernel / downblock_kernel (3x3 convs, kernel and tile shape autotuned per layer) on the {len(idx3)} 3x3 "
+                "kernel": f"conv3x3_pl_asm_nb13 (planar 3x3/s1, assembly build) / conv3x3_pl_asm_s2nb13 (planar 3x3/s2, assembly) / downblock_kernel / conv_igemm_kernel (3x3 convs, kernel and tile shape autotuned per layer) on the {len(idx3)} 3x3 "
                           f"layers launched as plain convs ({len(idxb)} Bottlenecks run in bottleneck_kernel, reported separately)",
                 "launches_per_step": len(idx3), "avg_launch_ms": round(1e3 * t3 / len(idx3), 4),
                 "flops_per_step": f3, "steps_timed": calls,
@@ -362,6 +364,14 @@ def main() -> int:
                                      "tflops": round(fb / tb / 1e12, 1) if tb > 0 else None},
                 "pass": f"{calls} single-stream steps with HIP events right after the timed region (same process, same buffers; "
                         f"the timed region keeps {a.streams} batches in flight)",
+                # every kernel that CONTAINS a 3x3 layer (the 19 plain launches, the 8 fused Bottlenecks, the down-block with model.1): all 28
+                # 3x3 layers of the network, priced with the whole FLOPs of those launches (their fused 1x1 stages included) over their time
+                "all_3x3": (lambda ii: {"launches_per_step": len(ii), "layers_3x3": len(idx3) + len(idxb) + sum(1 for i in ii if plan.ops[i].kind == spec.OP_DOWNBLOCK),
+                                         "flops_per_step": float(sum(plan.ops[i].flops_per_tile for i in ii)) * B,
+                                         "ms_per_step": round(float(ms[ii].sum()), 3),
+                                         "tflops": round(float(sum(plan.ops[i].flops_per_tile for i in ii)) * B / (float(ms[ii].sum()) * 1e-3) / 1e12, 1),
+                                         "frac": round(float(sum(plan.ops[i].flops_per_tile for i in ii)) * B / (float(ms[ii].sum()) * 1e-3) / 1e12 / peak, 4)})(
+                    idx3 + idxb + [i for i, o in enumerate(plan.ops) if o.kind == spec.OP_DOWNBLOCK]),
                 "all_conv_tflops": round((fl["total"]) * B / tc / 1e12, 1),
                 "step_ms_by_kind": {"conv3x3": round(1e3 * t3, 3), "conv_other": round(1e3 * (tc - t3), 3),
                                     "rest": round(float(ms.sum()) - 1e3 * tc, 3)}}

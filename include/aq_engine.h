@@ -42,8 +42,12 @@ typedef enum aq_status {
 typedef enum aq_precision {
     AQ_BF16 = 0,   /* bf16 weights + activations, fp32 accumulate/epilogue/head (throughput mode) */
     AQ_FP32 = 1,   /* fp32 everywhere on f32-input MFMA (parity mode: detect.py without --half) */
-    AQ_BF16_W8 = 2 /* AQ_BF16 whose conv weights lie on an OCP e4m3fn x 2^e[cout] grid (BASELINE.json configs[3], "fp8 weights"):
+    AQ_BF16_W8 = 2,/* AQ_BF16 whose conv weights lie on an OCP e4m3fn x 2^e[cout] grid (BASELINE.json configs[3], "fp8 weights"):
                     * kernels that have an fp8-weight stream (the planar 3x3) load the 1-byte codes, the others the same values as bf16 */
+    AQ_F16X3 = 3   /* fp32 activations, epilogues and head as AQ_FP32; every conv product as THREE fp16 MFMAs on hi / lo halves of both
+                    * operands (22 significant bits each, fp32 accumulate): fp32-grade results at several times the f32-input MFMA's
+                    * rate -- the fast parity mode (north_star: boxes / conf within 1e-4 of detect.py's fp32 output).  Domain: activations
+                    * within fp16's range (|x| < 65504), as upstream's own --half. */
 } aq_precision;
 
 typedef enum aq_op_kind {
@@ -146,6 +150,11 @@ int aq_pack_conv_weights(const float* w_krsc_host, int cout, int k, int cin, int
 /* Implicit-GEMM convolution, NHWC, fused bias + SiLU + residual.  in/out/res element type = precision
  * (out is fp32 when out_f32 != 0).  Replaces Conv.forward_fuse / Bottleneck.forward of the reference's
  * yolov5 dependency [UPSTREAM models/common.py]. */
+/* AQ_F16X3 packing: weights as fp16 hi / lo halves of w * 2^s[cout] (s: the power of two that puts the row's largest weight in
+ * [2^14, 2^15)), per 8 channels 16 bytes of hi then 16 bytes of lo; bias_scale_dev receives float[2 * rows]: bias * 2^s, then 2^-s
+ * (rows = *bias_floats / 2, the padded row count).  aq_conv2d with precision AQ_F16X3 takes THAT buffer as bias_dev.  cin % 8 == 0. */
+int aq_pack_conv_weights_x3(const float* w_krsc_host, const float* bias_host, int cout, int k, int cin, void* packed_dev, size_t* bytes,
+                            float* bias_scale_dev, size_t* bias_floats, void* stream);
 int aq_conv2d(const void* in_dev, int in_ld, int in_choff, int cin,
               void* out_dev, int out_ld, int out_choff, int cout,
               const void* res_dev, int res_ld, int res_choff,

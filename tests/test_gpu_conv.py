@@ -76,6 +76,54 @@ def test_conv_matches_reference(lib, case, precision):
     assert ran >= 10
 
 
+@pytest.mark.parametrize("case", [c for c in CASES if c[3] % 8 == 0])
+def test_conv_split_mode_is_fp32_grade(lib, case):
+    """AQ_F16X3 (fp32 activations, every product as three fp16 MFMAs on hi / lo halves, fp32 accumulate) against an fp64 reference:
+    the error must be of fp32's own order -- within 4x the exact-fp32 kernel's error on the same layer, and inside fp32 mode's
+    tolerance -- on every tile shape; weights spanning four orders of magnitude across output channels exercise the per-channel scale."""
+    from aquaculture_amd import engine
+    B, H, W, cin, cout, k, stride, act, use_res = case
+    g = torch.Generator().manual_seed(4321 + cin + cout)
+    x = torch.randn(B, H, W, cin, generator=g) * 2.0
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    w = w * (10.0 ** torch.linspace(-3, 1, cout)).view(-1, 1, 1, 1)            # rows from 1e-3 to 10 times the usual scale
+    b = torch.randn(cout, generator=g) * 0.1
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Ho, Wo, cout, generator=g) if use_res else None
+    xd = x.cuda()
+    rd = res.cuda() if res is not None else None
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), stride=stride, padding=pad)
+    if act:
+        y = F.silu(y)
+    if res is not None:
+        y = y + res.double().permute(0, 3, 1, 2)
+    ref = y.permute(0, 2, 3, 1)
+    scale = ref.abs().amax(dim=(0, 1, 2), keepdim=True).clamp_min(1e-30)           # per output channel: the rows differ by 1e4
+    ran = 0
+    for cfg in range(lib.aq_conv_num_configs()):
+        try:
+            out = engine.conv2d_nhwc(xd, w, b, stride=stride, act=act, residual=rd, precision="f16x3", cfg=cfg).cpu().double()
+        except RuntimeError as err:
+            assert "halo conv" in str(err), err
+            continue
+        ran += 1
+        e3 = ((out - ref).abs() / scale).max().item()
+        if ran == 1:
+            o32 = engine.conv2d_nhwc(xd, w, b, stride=stride, act=act, residual=rd, precision="fp32", cfg=cfg).cpu().double()
+            e32 = ((o32 - ref).abs() / scale).max().item()
+        assert e3 <= max(4.0 * e32, 2e-6), (cfg, e3, e32)
+        torch.testing.assert_close(out.float(), ref.float(), rtol=2e-5, atol=2e-5 * float(scale.max()))
+    assert ran >= 10
+
+
+def test_conv_split_mode_refuses_what_it_cannot_split(lib):
+    from aquaculture_amd import engine
+    x = torch.randn(1, 8, 8, 12).cuda()
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        engine.conv2d_nhwc(x, torch.randn(16, 12, 3, 3), torch.zeros(16), precision="f16x3")
+
+
 def test_conv_f32_out_head(lib):
     """Detect-head form: bf16 inputs, fp32 output, no activation, cout padded to 32."""
     from aquaculture_amd import engine

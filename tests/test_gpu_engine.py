@@ -96,6 +96,21 @@ def test_infer_fp32_matches_oracle_detections(lib, synth_ck, tiles_640):
     assert sum(r.shape[0] for r in ref) > 100   # the case actually exercises NMS
 
 
+def test_infer_f16x3_matches_oracle_detections(lib, synth_ck, tiles_640):
+    """The same north-star gate on the FAST parity mode (--precision f16x3: fp32 activations, conv products as three fp16 MFMAs on
+    hi / lo halves): identical post-NMS box counts, boxes / conf within 1e-4 of the fp32 oracle."""
+    from oracle import yolov5_oracle as O
+    eng = _engine(synth_ck, "f16x3")
+    m = O.model_from_checkpoint(synth_ck)
+    ref = O.detect_tiles(m, tiles_640)
+    dets, counts = eng.infer(torch.from_numpy(tiles_640).cuda())
+    _match(dets.cpu().numpy(), counts.cpu().numpy(), ref, box_tol=640 * 1e-4, conf_tol=1e-4)
+    pred = eng.forward_raw(torch.from_numpy(tiles_640).cuda()).cpu()
+    refp = m.forward(O.preprocess(tiles_640))
+    assert (pred[..., 4:] - refp[..., 4:]).abs().max().item() <= 1e-4
+    assert (pred[..., :4] - refp[..., :4]).abs().max().item() <= 640 * 1e-4
+
+
 def test_nms_kernel_bitexact_on_oracle_pred(lib, synth_ck, tiles_640):
     """S2 alone: feed the ORACLE's pred to the HIP NMS; output must equal the oracle's NMS bit for bit."""
     from aquaculture_amd import engine
