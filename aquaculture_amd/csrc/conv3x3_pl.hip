@@ -404,6 +404,7 @@ constexpr int kNumPlAsm = sizeof(kPlAsm) / sizeof(kPlAsm[0]);
 hipModule_t g_pl_asm_mod[64];
 hipFunction_t g_pl_asm_fn[64][kNumPlAsm][5];     // res0, res1, res1 stamped, and (NB = 13 only) the fp8-weight res0, res1
 hipFunction_t g_pl_s2_fn[64][2];                 // stride-2 family (s2nb13): plain, stamped
+hipFunction_t g_pl_f8_fn[64][3];                 // fp8 family (f8nb13): res0, res1, res1 stamped
 constexpr int PL_S2_NB = 13, PL_S2_ROWS = 304;   // gen_conv3x3_pl_asm.py CONFIGS["s2nb13"]
 
 struct PlKernel { int nb; void (*plain)(const PlParams); void (*res)(const PlParams); };
@@ -460,6 +461,9 @@ int pl_load_module(int dev) {
         }
     AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_s2_fn[dev][0], mod, "conv3x3_pl_asm_s2nb13_res0"));
     AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_s2_fn[dev][1], mod, "conv3x3_pl_asm_s2nb13_res0_stamped"));
+    AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_f8_fn[dev][0], mod, "conv3x3_pl_asm_f8nb13_res0"));
+    AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_f8_fn[dev][1], mod, "conv3x3_pl_asm_f8nb13_res1"));
+    AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_f8_fn[dev][2], mod, "conv3x3_pl_asm_f8nb13_res1_stamped"));
     g_pl_asm_mod[dev] = mod;
     return AQ_OK;
 }
@@ -815,6 +819,147 @@ extern "C" int aq_conv3x3_pl_s2(const void* in_dev, int in_ld, int in_choff, int
             if (asm_abl && *asm_abl) {
                 char name[80];
                 snprintf(name, sizeof name, "conv3x3_pl_asm_s2nb13_res0_stamped_abl%d", atoi(asm_abl));
+                AQ_CHECK_HIP(hipModuleGetFunction(&fn, g_pl_asm_mod[dev], name));
+            }
+        }
+    }
+    size_t asz = sizeof(a);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+    AQ_CHECK_HIP(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra));
+    return AQ_OK;
+}
+
+
+// ---- fp8 on both MFMA operands (round 3; BASELINE.json configs[3] "fp8 weights (CDNA4 fp8 MFMA)") -- gen_conv3x3_pl_asm.py, family f8nb13 ----
+// 3x3 / stride 1 / pad 1 with OCP e4m3fn activations AND weights on v_mfma_f32_16x16x128_f8f6f4 (twice the bf16 MFMA's rate):
+// y = (res +) SiLU(act_scale * w_scale[co] * sum(qx * qw) + bias), bf16 out.  The input tensor holds e4m3 codes (one byte per channel,
+// NHWC) written by the producing kernel with one scale per tensor; the weights are quantised here with one scale per output channel.
+
+// round-to-nearest-even fp32 -> e4m3fn code, saturating at +-448 (what v_cvt_pk_fp8_f32 and torch.float8_e4m3fn do inside the range)
+extern "C" unsigned char aq_f32_to_e4m3(float f) {
+    union { float f; uint32_t u; } v; v.f = f;
+    const unsigned sign = (v.u >> 24) & 0x80u;
+    const float a = std::fabs(f);
+    if (!(a == a)) return (unsigned char)(sign | 0x7f);
+    if (a >= 448.0f) return (unsigned char)(sign | 0x7e);
+    if (a < 0.015625f) {                                    // subnormals: multiples of 2^-9
+        const float m = std::nearbyint(a * 512.0f);         // default rounding mode: to nearest even
+        return (unsigned char)(sign | (unsigned)m);         // m == 8 is the smallest normal, code 0x08: the same formula
+    }
+    uint32_t u = v.u & 0x7fffffffu;
+    const uint32_t lsb = (u >> 20) & 1u;
+    u += 0x7ffffu + lsb;                                    // round the 23-bit mantissa to 3 bits, ties to even
+    u &= ~0xfffffu;
+    const int ex = (int)(u >> 23) - 127;                    // -6 .. 8
+    const unsigned mant = (u >> 20) & 7u;
+    return (unsigned char)(sign | ((unsigned)(ex + 7) << 3) | mant);
+}
+
+extern "C" int aq_conv3x3_pl_f8_supported(int cin, int cout, int B, int H, int W) {
+    if (cin < 64 || cin % 64 || cout % PL_BM || cout > 960 || B <= 0 || H <= 0 || W <= 0) return 0;
+    const int n_mt = cout / PL_BM;
+    if (n_mt & (n_mt - 1)) return 0;
+    if ((long long)B * (H + 1) * (W + 1) + W + 2 >= (1LL << 23)) return 0;
+    return pl_region_rows(B, H, W, 13 * 16) <= PL_ROWS;
+}
+
+// Weight codes in MFMA A-operand order: [M tile][wave][64-channel chunk][step p = 0..4][M block i][half][lane] x 16 codes; lane (r = lane & 15,
+// g = lane >> 4) holds output channel 192 mt + 48 wave + 16 i + r, tap 2 p + (g >> 1) (tap 9 of step 4: zeros) and input channels
+// 64 chunk + 32 (g & 1) + 16 half .. + 15.  scale_bias_dev: float[2048] = bias / (act_scale w_scale) (1024), then act_scale w_scale (1024),
+// w_scale[co] = max |w[co]| / 448.
+extern "C" int aq_pack_conv3x3_pl_f8(const float* w_host, const float* bias_host, int cin, int cout, float act_scale, void* packed_dev,
+                                     size_t* bytes, float* scale_bias_dev, void* stream) {
+    AQ_REQUIRE(w_host && bytes && cin % 64 == 0 && cout % PL_BM == 0 && cout <= 1024, "pack_conv3x3_pl_f8: unsupported %d -> %d", cin, cout);
+    const int CC = cin / 64, n_mt = cout / PL_BM;
+    *bytes = (size_t)n_mt * 4 * CC * 5 * 6144;
+    if (!packed_dev) return AQ_OK;
+    AQ_REQUIRE(bias_host && scale_bias_dev && act_scale > 0.0f && std::isfinite(act_scale), "pack_conv3x3_pl_f8: null pointer or bad activation scale");
+    std::vector<float> sb(2048, 0.0f), ws(cout, 1.0f);
+    const size_t kk = (size_t)9 * cin;
+    for (int co = 0; co < cout; ++co) {
+        const float* row = w_host + (size_t)co * kk;
+        float amax = 0.0f;
+        for (size_t i = 0; i < kk; ++i) amax = std::fmax(amax, std::fabs(row[i]));
+        ws[co] = amax > 0.0f ? amax / 448.0f : 1.0f;
+        const float sc = act_scale * ws[co];
+        sb[co] = bias_host[co] / sc;
+        sb[1024 + co] = sc;
+    }
+    unsigned char* host = (unsigned char*)calloc(1, *bytes);
+    AQ_REQUIRE(host, "pack_conv3x3_pl_f8: host allocation failed");
+    unsigned char* dst = host;
+    for (int mt = 0; mt < n_mt; ++mt)
+        for (int wv = 0; wv < 4; ++wv)
+            for (int c = 0; c < CC; ++c)
+                for (int p = 0; p < 5; ++p)
+                    for (int i = 0; i < 3; ++i)
+                        for (int half = 0; half < 2; ++half)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int co = mt * PL_BM + wv * 48 + i * 16 + (lane & 15), g = lane >> 4;
+                                const int tap = 2 * p + (g >> 1);
+                                const int ci = 64 * c + 32 * (g & 1) + 16 * half;
+                                for (int e = 0; e < 16; ++e)
+                                    *dst++ = tap < 9 ? aq_f32_to_e4m3(w_host[((size_t)co * 9 + tap) * cin + ci + e] / ws[co]) : (unsigned char)0;
+                            }
+    hipError_t err = hipMemcpyAsync(packed_dev, host, *bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(scale_bias_dev, sb.data(), sb.size() * 4, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (err == hipSuccess) err = hipStreamSynchronize((hipStream_t)stream);
+    free(host);
+    AQ_CHECK_HIP(err);
+    return AQ_OK;
+}
+
+// in: e4m3 codes, NHWC, in_ld BYTES per pixel, the conv's cin channels from byte in_choff (a multiple of 16); out / res: NHWC bf16 slices.
+extern "C" int aq_conv3x3_pl_f8(const void* in_dev, int in_ld, int in_choff, int cin, void* out_dev, int out_ld, int out_choff, int cout,
+                                const void* res_dev, int res_ld, int res_choff, const void* packed_w_dev, const float* scale_bias_dev,
+                                int B, int H, int W, int act, void* stream) {
+    AQ_REQUIRE(in_dev && out_dev && packed_w_dev && scale_bias_dev, "conv3x3_pl_f8: null pointer");
+    AQ_REQUIRE(aq_conv3x3_pl_f8_supported(cin, cout, B, H, W), "conv3x3_pl_f8: unsupported %d -> %d on %d x %d x %d", cin, cout, B, H, W);
+    AQ_REQUIRE(in_choff % 16 == 0 && in_ld % 16 == 0 && in_choff + cin <= in_ld && out_ld % 4 == 0 && out_choff % 4 == 0 && out_choff + cout <= out_ld,
+               "conv3x3_pl_f8: slices must be 16-byte (input) / 8-byte (output) aligned and inside their rows");
+    AQ_REQUIRE(!res_dev || (res_ld % 4 == 0 && res_choff % 4 == 0 && res_choff + cout <= res_ld), "conv3x3_pl_f8: bad residual slice");
+    AQ_REQUIRE((long long)B * H * W * out_ld * 2 < (1LL << 31) && (long long)B * H * W * res_ld * 2 < (1LL << 31) && (long long)B * H * W * in_ld < (1LL << 31) &&
+                   in_ld < (1 << 24), "conv3x3_pl_f8: tensors beyond the 31-bit offset range");
+    int dev = 0;
+    AQ_CHECK_HIP(hipGetDevice(&dev));
+    AQ_REQUIRE(dev >= 0 && dev < 64, "conv3x3_pl_f8: device ordinal %d", dev);
+    if (g_pl_cus[dev] == 0) {
+        int cus = 256;
+        AQ_CHECK_HIP(aq_query_cus(&cus, dev));
+        g_pl_cus[dev] = cus;
+    }
+    { const int rc = pl_load_module(dev); if (rc) return rc; }
+    PlAsmArgs a{};
+    a.in = (const char*)in_dev + in_choff; a.in_sp = in_ld; a.in_ss = 16;
+    a.out = (char*)out_dev + (size_t)out_choff * 2; a.out_ld_b = out_ld * 2;
+    if (res_dev) { a.res = (const char*)res_dev + (size_t)res_choff * 2; a.res_ld_b = res_ld * 2; }
+    a.w = (const char*)packed_w_dev; a.bias = scale_bias_dev;
+    a.zero = aq_zero_page();
+    AQ_REQUIRE(a.zero, "conv3x3_pl_f8: zero page allocation failed");
+    a.B = B; a.H = H; a.W = W; a.npix = B * H * W; a.cout = cout; a.act = act;
+    a.CC = cin / 64;
+    const int n_mt = cout / PL_BM;
+    while ((1 << a.mt_log2) < n_mt) ++a.mt_log2;
+    const long long ntiles = ((long long)a.npix + 207) / 208 * n_mt;
+    AQ_REQUIRE(ntiles > 0 && ntiles < (1LL << 30), "conv3x3_pl_f8: bad tile count");
+    a.ntiles = (int)ntiles;
+    long long grid = g_pl_cus[dev];
+    if (grid > ntiles) grid = ntiles;
+    a.G = (int)grid;
+    a.inv_hw = 1.0f / (float)(H * W); a.inv_w = 1.0f / (float)W;
+    a.inv_hpwp = 1.0f / (float)((H + 1) * (W + 1)); a.inv_wp = 1.0f / (float)(W + 1);
+    hipFunction_t fn = g_pl_f8_fn[dev][res_dev ? 1 : 0];
+    const char* use_asm = getenv("AQ_PL_ASM");
+    if (use_asm && *use_asm == '2' && res_dev) {              // stamped diagnostic build
+        size_t sbytes = 0;
+        unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
+        if (sbuf && sbytes >= (size_t)grid * 4 * 64) {
+            a.debug = sbuf;
+            fn = g_pl_f8_fn[dev][2];
+            const char* asm_abl = getenv("AQ_PL_ASM_ABL");
+            if (asm_abl && *asm_abl) {
+                char name[80];
+                snprintf(name, sizeof name, "conv3x3_pl_asm_f8nb13_res1_stamped_abl%d", atoi(asm_abl));
                 AQ_CHECK_HIP(hipModuleGetFunction(&fn, g_pl_asm_mod[dev], name));
             }
         }

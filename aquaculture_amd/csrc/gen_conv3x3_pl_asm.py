@@ -72,6 +72,17 @@ CONFIGS = {
     7: dict(NB=7, PD=8, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False),
     8: dict(NB=8, PD=7, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False),
     "s2nb13": dict(NB=13, PD=8, ROWS=304, RING=2, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=1, S2=True),
+    # F8 = the fp8 family of the stride-1 kernel (BASELINE.json configs[3], "fp8 weights (CDNA4 fp8 MFMA)"): OCP e4m3 on BOTH MFMA
+    # operands, v_mfma_f32_16x16x128_f8f6f4 (33.5 cycles for 4x the K of the 16-cycle bf16 form: tools/ubench/mfma_f8_layout.hip).
+    # A 64-channel chunk is 64 BYTES per pixel, so K = 128 spans two TAPS: MFMA step p multiplies taps 2 p and 2 p + 1 (step 4: tap 8
+    # and zeros), operand lanes 0-31 holding the first tap's 64 channels and lanes 32-63 the second's -- the B fragment is simply read
+    # at a per-lane tap offset.  Five steps per chunk instead of eighteen half-taps.  Region rows are the stride-2 family's: the pixel's
+    # 64 contiguous bytes, 16 rows per LDS-DMA instruction through a buffer descriptor, byte address bit 5 ^= bit 8 (a lane's 32 bytes
+    # stay contiguous; the two 16-byte reads of a fragment are 2-way bank conflicted, which the 96-cycle MFMA triple covers).  Each
+    # fragment address is computed where it is read (add, shift, and, xor): nine tap offsets would cost 117 address registers.
+    # LOOK = 4: five weight sets, one per step, each reloaded for the next chunk as soon as its step is done.  The residual waits in
+    # the accumulator half of the register file (78 of the 100 registers free there).
+    "f8nb13": dict(NB=13, PD=4, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=4, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=1, S2=False, F8=True),
 }
 STEP_B = 6 * 1024          # weight bytes per (wave, tap-step): six 1 KB bf16 fragments (KS = 1: three) ...
 W8 = False                 # ... or, in the fp8-weight kernels (set per kernel by gen_kernel), three 1 KB pairs of e4m3 fragments
@@ -80,9 +91,11 @@ W8 = False                 # ... or, in the fp8-weight kernels (set per kernel b
 def configure(nb):
     """Sets the module-level tile constants and (re)allocates the registers of one family."""
     g = globals()
+    g["F8"] = False
     g.update(CONFIGS[nb])
+    g["NT"] = 5 if F8 else 9                   # MFMA steps per chunk that take their own weight fragments: taps, or (fp8) tap pairs
     g["FAMILY"] = f"nb{nb}" if isinstance(nb, int) else nb
-    g["NE"] = 9 * KS * NB
+    g["NE"] = NT * KS * NB
     g["GROUPS"] = list(range(0, ROWS - 63, 64)) + ([ROWS - 64] if ROWS % 64 else [])      # first region row of every LDS-DMA group
     g["NG"] = len(GROUPS)
     g["PS"] = ROWS * 16
@@ -107,10 +120,22 @@ def configure(nb):
         g["DMA_TAPS"] = [list(range(sum(per[:t]), sum(per[:t + 1]))) for t in range(6)] + [[], [], []]
         g["DPOS"] = [6 + 2 * i for i in range(max(per))]
         assert ROWS % 16 == 0 and sum(len(x) for x in DMA_TAPS) == NDMA and DPOS[-1] < NB and 3 * PSTR + 16 < 65536
-    assert (KS == 1) == bool(S2)
+    if F8:
+        g["GROUPS"] = [0, 64]                              # per wave: the 96 region rows it loads, as two groups whose source pixels are computed
+        g["NG"] = 2
+        g["PSTR"] = ROWS * 64
+        g["CHUNK"] = PSTR
+        g["BIAS_OFF"] = RING * CHUNK
+        g["LDS_BYTES"] = BIAS_OFF + 8192                   # bias / scale, then scale * ... (two 4 KB vectors, as the fp8-weight kernels)
+        g["NDMA"] = ROWS // 16 // 4                        # LDS-DMA instructions per wave and chunk (the waves split the rows)
+        g["DMA_TAPS"] = [[0, 1], [2, 3], [4, 5], [], []]
+        g["DPOS"] = [6, 12]
+        g["RPOS"] = [0, 2, 4, 8, 10]                       # elements of a step whose residual loads may go (steps 0 .. 3 of a tile's last chunk)
+        assert ROWS % 64 == 0 and NDMA == 6 and NB == 13 and 2 * PD <= 15
+    assert (KS == 1) == bool(S2 or F8)
     assert PS % 256 == 0 and NB >= 6 and NG + 2 <= 8
     assert KS == 2 or (not SPLIT and not DMA_FRONT and not A_IN_ACC and RES_EARLY)
-    assert 9 % (LOOK + 1) == 0, "a chunk has 9 taps: the weight sets must come round at its end"
+    assert NT % (LOOK + 1) == 0, "the weight sets must come round at the end of a chunk"
     allocate_registers()
 
 
@@ -154,24 +179,26 @@ def allocate_registers():
     if S2:
         S.alloc("in_row", 2, 2)   # stride-2 family: bytes per INPUT image row (H, W, npix describe the OUTPUT there)
     for nm in ("HW", "Wp", "HpWp", "lead", "Hpad", "tile", "next_tile", "has_next", "n0", "cbase", "c", "buf", "cd", "bd", "lastc", "extra",
-               "rs", "rs_dma", "delta0", "dRow", "wave", "first", "tmp0", "tmp1", "tmp2", "tmp3", "dlds", "lim") + (("coff",) if S2 else ("par", "rlim")):
+               "rs", "rs_dma", "delta0", "dRow", "wave", "first", "tmp0", "tmp1", "tmp2", "tmp3", "dlds", "lim") + (("coff",) if S2 else ("coff", "rlim") if F8 else ("par", "rlim")):
         S.alloc(nm)
     S.alloc("klog2e2", 2, 2)      # (-log2 e, -log2 e) for v_pk_mul_f32
     S.alloc("kone2", 2, 2)        # (1.0, 1.0)
     S.alloc("a_cur", 2, 2)
     S.alloc("a_nxt", 2, 2)
     S.alloc("a_ld", 2, 2)         # base of the weight loads being issued
-    if S2:
-        S.alloc("srd", 4, 4)      # buffer descriptor of this wave's parity plane of the input (constant for the kernel)
+    if S2 or F8:
+        S.alloc("srd", 4, 4)      # buffer descriptor of (this wave's parity plane of) the input (constant for the kernel)
     else:
         S.alloc("dbase", 2, 2)    # LDS-DMA: input base of (chunk, this wave's first plane) ...
-    if KS == 2:
+    if KS == 2 and not F8:
         S.alloc("dbase1", 2, 2)   # ... and of its second plane (32-channel chunks: one base, the planes are immediate offsets)
     S.alloc("t64", 2, 2)
     S.alloc("actm", 2, 2)         # all ones when the layer has an activation (in-stream epilogue blocks select instead of branching)
     S.alloc("st_acc", 12, 2)      # stamped build only: cycle sums of six phases
     if S2:                        # (arguments the stride-2 kernels never read: no shortcut, channel groups 16 bytes apart)
         S.names["st_last"], S.names["st_rt0"] = S.names["res"], S.names["in_ss"]
+    elif F8:                      # (the zero page's address lives on in two VGPRs; channel groups are contiguous)
+        S.names["st_last"], S.names["st_rt0"] = S.names["zero"], S.names["in_ss"]
     else:
         S.alloc("st_last", 2, 2)
         S.alloc("st_rt0", 2, 2)
@@ -186,15 +213,18 @@ def allocate_registers():
     V.alloc("zero_lo")
     V.alloc("zero_hi")
     if not A_IN_ACC:
-        V.alloc("A", 12 * KS * (LOOK + 1), 4)
-    V.alloc("B", 4 * (PD + 1), 4)
+        V.alloc("A", (24 if F8 else 12 * KS) * (LOOK + 1), 4)
+    V.alloc("B", (8 if F8 else 4) * (PD + 1), 4)
     V.alloc("addr", 4 * NB if S2 else NB)      # (stride 2: per pixel block one swizzled address per (row, column) offset of the taps)
     V.alloc("prow", NG)
-    if S2:
+    if F8:
+        V.alloc("tapoff", 5)      # per MFMA step: 64 x the region-row offset of the tap THIS lane's operand half belongs to (lanes 0-31: tap 2 p, 32-63: 2 p + 1)
+        V.alloc("SC", 12, 4)      # epilogue: act_scale x weight_scale of this lane's 3 x 4 output channels
+    if S2 or F8:
         V.alloc("voff", NDMA)     # per LDS-DMA instruction of a chunk: this lane's byte offset into the parity plane, or beyond the descriptor
         V.alloc("bpa", 4)         # ds_bpermute addresses: lane (16 m + lane / 4) * 4, m = 0 .. 3
         V.alloc("qoff")           # 16 x the channel group this lane fetches: (lane & 3) ^ 2 ((lane >> 4) & 1)
-    if RES_EARLY and not S2:
+    if RES_EARLY and not S2 and not F8:
         V.alloc("R", 6 * NB, 2)
     V.alloc("oo", NB)
     V.alloc("t", 24, 4)           # temporaries
@@ -231,6 +261,8 @@ def vr(name, i, cnt):
 
 def rreg(b):
     """First register of residual pair b (0 .. 3 NB - 1): its own block, or (two-workgroup families) weight set 2 and then the B ring."""
+    if F8:
+        return 12 * NB + 2 * b                             # (accumulator-file register number)
     if RES_EARLY:
         return V.names["R"][0] + 2 * b
     assert 3 * NB <= 12 + 2 * (PD + 1) and LOOK == 2 and not A_IN_ACC
@@ -239,6 +271,9 @@ def rreg(b):
 
 def areg(set_idx, k):
     """The four registers of fragment k (0 .. 5) of weight set set_idx."""
+    if F8:                                                 # fragment k (0 .. 2) of a step: 8 registers (loads 2 k and 2 k + 1)
+        assert 0 <= set_idx <= LOOK and 0 <= k < 3
+        return vr("A", 24 * set_idx + 8 * k, 8)
     assert 0 <= set_idx <= LOOK and 0 <= k < 3 * KS
     if A_IN_ACC:
         b = 12 * NB + 24 * set_idx + 4 * k
@@ -273,7 +308,7 @@ def emit_convert(tap, ks, i, step):
 
 
 def n_acc():
-    return 12 * NB + (24 * (LOOK + 1) if A_IN_ACC else 0)
+    return 12 * NB + (24 * (LOOK + 1) if A_IN_ACC else 0) + (6 * NB if F8 else 0)
 
 
 def acc(i, j):
@@ -396,12 +431,15 @@ def emit_region_rows(tile_s):
     """prow[k] = unpad(rs(tile) + GROUPS[k] + lane) for k = 0 .. NG - 1."""
     emit_rs_of_tile(tile_s, s("rs_dma"))
     T = [v("t", i) for i in range(6)]
+    if F8:
+        E(f"s_mul_i32 {s('tmp0')}, {s('wave')}, {16 * NDMA}", "this wave loads region rows 96 wave .. + 95")
+        E(f"s_add_u32 {s('rs_dma')}, {s('rs_dma')}, {s('tmp0')}")
     for k in range(NG):
         E(f"v_add_u32 {T[5]}, {s('rs_dma')}, {v('lane')}")
         if k:
             E(f"v_add_u32 {T[5]}, {GROUPS[k]}, {T[5]}")
         emit_unpad(v("prow", k), T[5], T[0], T[1], T[2], T[3], T[4])
-    if S2:
+    if S2 or F8:
         # deal the 64-row groups to the 16-row instructions: lane L of instruction g fetches for region row 16 g + L / 4, whose source pixel
         # sits in lane 16 (g & 3) + L / 4 of prow[g >> 2]; then offset = pixel * in_sp + 16 * (channel group), or out of the descriptor's range
         for g_ in range(NDMA):
@@ -415,7 +453,7 @@ def emit_region_rows(tile_s):
 
 
 def emit_no_rows():
-    if S2:
+    if S2 or F8:
         for g_ in range(NDMA):
             E(f"v_bfrev_b32 {v('voff', g_)}, 1")
         return
@@ -427,11 +465,11 @@ def emit_dma_base(cd_s, bd_s):
     """Per chunk: dbase = inp + (8 cd + 2 wave) * in_ss (plane 2 wave of chunk cd) and dlds = bd * CHUNK + 2 wave * PS, the operands every
     LDS-DMA instruction of that chunk starts from.  (Computing them inside each of the 12 instructions' sequences cost 13 scalar
     instructions apiece, in a stream that is bound by instruction issue.)"""
-    if S2:
-        # chunk cd = bytes 64 cd .. + 63 of every pixel (the descriptor's soffset); this wave's parity plane of ring buffer bd
+    if S2 or F8:
+        # chunk cd = bytes 64 cd .. + 63 of every pixel (the descriptor's soffset); this wave's parity plane (fp8: its rows) of ring buffer bd
         E(f"s_lshl_b32 {s('coff')}, {cd_s}, 6")
         E(f"s_mul_i32 {s('tmp2')}, {bd_s}, {CHUNK}")
-        E(f"s_mul_i32 {s('tmp1')}, {s('wave')}, {PSTR}")
+        E(f"s_mul_i32 {s('tmp1')}, {s('wave')}, {1024 * NDMA if F8 else PSTR}")
         E(f"s_add_u32 {s('dlds')}, {s('tmp2')}, {s('tmp1')}", "the ring starts at LDS address 0")
         return
     E(f"s_lshl_b32 {s('tmp0')}, {cd_s}, 3")
@@ -450,7 +488,7 @@ def emit_dma_base(cd_s, bd_s):
 
 def emit_dma(k, s2i, cd_s=None, bd_s=None):
     """One LDS-DMA instruction: plane 2 wave + s2i of the chunk emit_dma_base was called for, region rows 64 k .. 64 k + 63."""
-    if S2:
+    if S2 or F8:
         # (k = the instruction's number 0 .. NDMA - 1; in the stream the two halves sit around an element's MFMAs)
         emit_dma_m0(k, 0)
         E("s_nop 0", "hz: m0 write -> LDS-DMA")
@@ -483,16 +521,17 @@ def emit_load_a(set_idx, k, base_s2, extra_off):
     assert -4096 <= off <= 4095
     import os as _os
     pol = _os.environ.get("AQ_GEN_A_POLICY", "")          # experiment: cache policy of the weight loads ("nt", "sc0", "sc1", ...)
-    E(f"global_load_dwordx4 {rawreg(set_idx, k) if W8 else areg(set_idx, k)}, {v('aoff')}, {base_s2} offset:{off}" + (f" {pol}" if pol else ""))
+    dst = vr("A", 24 * set_idx + 4 * k, 4) if F8 else (rawreg(set_idx, k) if W8 else areg(set_idx, k))
+    E(f"global_load_dwordx4 {dst}, {v('aoff')}, {base_s2} offset:{off}" + (f" {pol}" if pol else ""))
 
 
 def emit_set_a_base(dst, tap):
     """dst (SGPR pair) = stream address (+3072) of tap-step `tap` of this chunk (0..8) or of the next chunk / tile (9, 10)."""
-    if tap < 9:
+    if tap < NT:
         E(f"s_add_u32 {s(dst)}, {s('a_cur')}, {tap * STEP_B}")
         E(f"s_addc_u32 {s(dst, 1)}, {s('a_cur', 1)}, 0")
     else:
-        E(f"s_add_u32 {s(dst)}, {s('a_nxt')}, {(tap - 9) * STEP_B}")
+        E(f"s_add_u32 {s(dst)}, {s('a_nxt')}, {(tap - NT) * STEP_B}")
         E(f"s_addc_u32 {s(dst, 1)}, {s('a_nxt', 1)}, 0")
 
 
@@ -505,8 +544,8 @@ def emit_a_stream_base(dst, tile_s, c_s):
     E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {s('wave')}")
     E(f"s_mul_i32 {s('tmp0')}, {s('tmp0')}, {s('CC')}")
     E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {c_s}")
-    E(f"s_mul_i32 {s('tmp1')}, {s('tmp0')}, {9 * STEP_B}")
-    E(f"s_mul_hi_u32 {s('tmp2')}, {s('tmp0')}, {9 * STEP_B}")
+    E(f"s_mul_i32 {s('tmp1')}, {s('tmp0')}, {NT * STEP_B}")
+    E(f"s_mul_hi_u32 {s('tmp2')}, {s('tmp0')}, {NT * STEP_B}")
     E(f"s_add_u32 {s('tmp1')}, {s('tmp1')}, 3072", "keeps every fragment offset inside the 13-bit immediate")
     E(f"s_addc_u32 {s('tmp2')}, {s('tmp2')}, 0")
     E(f"s_add_u32 {s(dst)}, {s('w')}, {s('tmp1')}")
@@ -541,7 +580,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     global out, W8, STEP_B
     out = []
     STAMPED[0] = stamped
-    NLOAD = 3 if (w8 or KS == 1) else 6       # weight load instructions per tap: 1 KB fragments (or e4m3 fragment pairs)
+    NLOAD = 6 if F8 else 3 if (w8 or KS == 1) else 6       # weight load instructions per tap: 1 KB fragments (or e4m3 fragment pairs)
     W8, STEP_B = w8, NLOAD * 1024
     assert not w8 or (RES_EARLY and LOOK == 2 and not A_IN_ACC and NB >= 12 and KS == 2)
     assert not (S2 and RES), "the stride-2 layers have no shortcut"
@@ -568,7 +607,10 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"v_and_b32 {v('l15')}, 15, {v('lane')}")
     E(f"v_lshrrev_b32 {v('q')}, 4, {v('lane')}")
     E(f"v_lshlrev_b32 {v('aoff')}, 4, {v('lane')}")
-    if S2:
+    if F8:
+        E(f"v_and_b32 {v('qps')}, 1, {v('q')}")
+        E(f"v_lshlrev_b32 {v('qps')}, 5, {v('qps')}", "fp8 family: operand lanes 16 q .. hold the 32 channels 32 (q & 1) .. of their tap")
+    elif S2:
         E(f"v_lshlrev_b32 {v('qps')}, 4, {v('q')}", "stride-2 family: channel group q is 16 q bytes into a (pixel-major) region row")
     else:
         E(f"v_mul_u32_u24 {v('qps')}, {PS}, {v('q')}")
@@ -576,12 +618,14 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"v_mov_b32 {v('insp')}, {s('in_sp')}")
     E(f"v_mov_b32 {v('zero_lo')}, {s('zero')}")
     E(f"v_mov_b32 {v('zero_hi')}, {s('zero', 1)}")
-    if S2:
+    if S2 or F8:
         # descriptor of this wave's parity plane (py, px) = (wave >> 1, wave & 1): base = inp + py in_row + px in_sp, raw buffer (stride 0),
         # num_records 2^31 (every valid offset is below it -- the host checks the tensor's size --, the padding rows' 0x80000000 is not)
+        # (fp8 family: one plane, base = inp)
         lp, lq = uid("py"), uid("px")
         E(f"s_mov_b32 {s('srd', 0)}, {s('inp')}")
         E(f"s_mov_b32 {s('srd', 1)}, {s('inp', 1)}")
+    if S2:
         E(f"s_bitcmp0_b32 {s('wave')}, 1")
         E(f"s_cbranch_scc1 {lp}")
         E(f"s_add_u32 {s('srd', 0)}, {s('srd', 0)}, {s('in_row')}")
@@ -592,6 +636,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         E(f"s_add_u32 {s('srd', 0)}, {s('srd', 0)}, {s('in_sp')}")
         E(f"s_addc_u32 {s('srd', 1)}, {s('srd', 1)}, {s('in_sp', 1)}")
         label(lq)
+    if S2 or F8:
         E(f"s_and_b32 {s('srd', 1)}, {s('srd', 1)}, 0xffff")
         E(f"s_mov_b32 {s('srd', 2)}, 0x80000000")
         E(f"s_mov_b32 {s('srd', 3)}, 0x00020000")
@@ -612,6 +657,21 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_add_u32 {s('Hpad')}, {s('tmp0')}, {s('W')}", "H + W + 1")
     E(f"s_lshl_b32 {s('tmp0')}, {s('Wp')}, {6 if S2 else 4}")
     E(f"s_mov_b32 {s('dRow')}, {s('tmp0')}", "kernel row r -> r + 1: Wp * 16 bytes (stride-2 family: Wp * 64)")
+    if F8:
+        # tapoff[p]: lanes 0-31 carry tap 2 p, lanes 32-63 tap 2 p + 1 (step 4: tap 8 again -- its weights are zeros there);
+        # tap t = (dy, dx) sits dy Wp + dx region rows (of 64 bytes) below / right of the upper left neighbour
+        E(f"v_lshrrev_b32 {v('t', 0)}, 5, {v('lane')}", "0 / 1: which tap of the pair")
+        for p_ in range(5):
+            ta, tb = 2 * p_, min(2 * p_ + 1, 8)
+            offs = []
+            for t_ in (ta, tb):
+                E(f"s_mul_i32 {s('tmp0')}, {s('Wp')}, {t_ // 3}")
+                E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {t_ % 3}")
+                E(f"s_lshl_b32 {s('tmp1' if t_ == ta else 'tmp2')}, {s('tmp0')}, 6")
+            E(f"v_mov_b32 {v('tapoff', p_)}, {s('tmp1')}")
+            E(f"v_mov_b32 {v('t', 1)}, {s('tmp2')}")
+            E(f"v_cmp_eq_u32 vcc, 1, {v('t', 0)}")
+            E(f"v_cndmask_b32 {v('tapoff', p_)}, {v('tapoff', p_)}, {v('t', 1)}, vcc")
     E(f"s_mov_b32 {s('klog2e2')}, 0xbfb8aa3b", "-log2(e)")
     E(f"s_mov_b32 {s('klog2e2', 1)}, 0xbfb8aa3b")
     E(f"s_mov_b32 {s('kone2')}, 1.0")
@@ -651,10 +711,10 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_mov_b32 {s('cd')}, 0")
     E(f"s_mov_b32 {s('bd')}, 0")
     emit_dma_base(s("cd"), s("bd"))
-    if S2:
+    if S2 or F8:
         for g_ in range(NDMA):
             emit_dma(g_, 0)
-    for k in range(NG if not S2 else 0):
+    for k in range(NG if not (S2 or F8) else 0):
         for s2i in range(PPW):
             emit_dma(k, s2i, s("cd"), s("bd"))
     # bias: 256 floats per wave by LDS-DMA (lane: floats wave * 256 + 4 lane .. + 3, or zeros beyond cout)
@@ -675,8 +735,9 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_mov_b32 m0, {s('tmp0')}")
     E("s_nop 0", "hz: s_mov m0 -> LDS-DMA")
     E(f"global_load_lds_dwordx4 v[{V.names['t'][0] + 4}:{V.names['t'][0] + 5}], off")
-    if w8:
+    if w8 or F8:
         # fp8 weights: `bias` holds bias x 2^-e (1024 floats) and then the per-channel scales 2^e (1024 floats)
+        # (fp8 family: bias / (act_scale x weight_scale), then act_scale x weight_scale)
         E(f"v_add_co_u32 {T[4]}, vcc, 4096, {T[4]}")
         E(f"v_addc_co_u32 {T[5]}, vcc, 0, {T[5]}, vcc")
         E(f"v_cmp_lt_u32 vcc, {s('cout')}, {T[3]}")
@@ -698,7 +759,10 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         E(f"s_mov_b32 {s('cd')}, 1")
         E(f"s_mov_b32 {s('bd')}, 1")
         emit_dma_base(s("cd"), s("bd"))
-        for k in range(NG):
+        if F8:
+            for g_ in range(NDMA):
+                emit_dma(g_, 0)
+        for k in range(NG if not F8 else 0):
             for s2i in range(PPW):
                 emit_dma(k, s2i, s("cd"), s("bd"))
     stamp(PH_PROLOGUE)
@@ -736,6 +800,12 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         E(f"v_add_u32 {v('oo', j)}, {v('oo', j)}, {T[7]}")
         emit_pp_of(T[5], T[4], T[0], T[1], T[2], T[3])
         E(f"v_subrev_u32 {T[5]}, {s('tmp2')}, {T[5]}")
+        if F8:
+            # linear byte address of (upper left neighbour's row, this lane's 32-byte channel half), in the tile's first ring buffer;
+            # the tap offset and the swizzle are applied where the fragment is read
+            E(f"v_lshl_add_u32 {T[5]}, {T[5]}, 6, {v('qps')}", "qps = 32 (q & 1) here")
+            E(f"v_add_u32 {v('addr', j)}, {s('tmp3')}, {T[5]}")
+            continue
         if S2:
             # four swizzled addresses per pixel block: region row (upper left neighbour) + (ry Wp + rx), 64 B per row, channel group q at
             # position q ^ 2 bit2(row): byte bit 5 ^= byte bit 8; + the ring buffer
@@ -862,8 +932,20 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         L = lines.append
         for e in range(4):
             L(f"v_accvgpr_read_b32 v{X + e}, a{a0 + e}")
+        if F8:                                            # accumulators are sums of code products: x act_scale x weight_scale[channel]
+            sc = V.names["SC"][0] + 4 * i
+            L(f"v_pk_mul_f32 v[{X}:{X + 1}], v[{X}:{X + 1}], v[{sc}:{sc + 1}]")
+            L(f"v_pk_mul_f32 v[{X + 2}:{X + 3}], v[{X + 2}:{X + 3}], v[{sc + 2}:{sc + 3}]")
 
         def unpack():
+            if F8:                                        # the residual waits in the accumulator file
+                L(f"v_accvgpr_read_b32 v{Rr + 1}, a{r0}")
+                L(f"v_accvgpr_read_b32 v{Rr + 3}, a{r0 + 1}")
+                L(f"v_lshlrev_b32 v{Rr}, 16, v{Rr + 1}")
+                L(f"v_and_b32 v{Rr + 1}, 0xffff0000, v{Rr + 1}")
+                L(f"v_lshlrev_b32 v{Rr + 2}, 16, v{Rr + 3}")
+                L(f"v_and_b32 v{Rr + 3}, 0xffff0000, v{Rr + 3}")
+                return
             L(f"v_lshlrev_b32 v{Rr}, 16, v{r0}")
             L(f"v_and_b32 v{Rr + 1}, 0xffff0000, v{r0}")
             L(f"v_lshlrev_b32 v{Rr + 2}, 16, v{r0 + 1}")
@@ -1084,6 +1166,19 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             h, j = divmod(n, NB)
             t, ks = divmod(h, KS)
             # the pixel block's address moves once per kernel ROW (taps 0, 3, 6); the column and the k-step are immediate offsets
+            if F8:
+                # step t = tap pair: this lane's tap offset, then the swizzle (byte bit 5 ^= bit 8), two reads of 16 bytes
+                bq = V.names["B"][0] + 8 * (n % (PD + 1))
+                if t == 0:
+                    E(f"v_add_u32 {v('addr', j)}, {s('delta0')}, {v('addr', j)}")
+                E(f"v_add_u32 {T[2]}, {v('tapoff', t)}, {v('addr', j)}")
+                E(f"v_lshrrev_b32 {T[3]}, 3, {T[2]}")
+                E(f"v_and_b32 {T[3]}, 32, {T[3]}")
+                E(f"v_xor_b32 {T[2]}, {T[2]}, {T[3]}")
+                if not abl & 4:
+                    E(f"ds_read_b128 v[{bq}:{bq + 3}], {T[2]}")
+                    E(f"ds_read_b128 v[{bq + 4}:{bq + 7}], {T[2]} offset:16")
+                return
             if S2:
                 # tap (dy, dx) = divmod(t, 3): parity plane (dy != 1, dx != 1) -- plane index as the waves load them, 2 py + px -- as the
                 # immediate offset; the (row, column) offset (dy >= 1, dx >= 1) picks one of the block's four swizzled addresses, each of
@@ -1111,7 +1206,14 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         kD0, kD1 = DPOS[0], DPOS[-1]
         in_stream_res = RES and RES_EARLY
         res_groups = []                       # res_groups[t] = pixel blocks whose residual is loaded in tap t
-        if in_stream_res:
+        if in_stream_res and F8:
+            nxt = 0
+            for t in range(NT):
+                cnt = min(NB - nxt, -(-(NB - nxt) // (4 - t)), len(RPOS)) if t < 4 else 0
+                res_groups.append(list(range(nxt, nxt + cnt)))
+                nxt += cnt
+            assert nxt == NB
+        elif in_stream_res:
             nxt = 0
             for t in range(9):
                 cnt = min(NB - nxt, -(-(NB - nxt) // (7 - t))) if t < 7 else 0
@@ -1120,24 +1222,24 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             assert nxt == NB and kD1 + 2 < 2 * NB
 
         def tap_ops(t, last=True):
-            ops = [(2 * k + 1, "A", (t + LOOK) % 9, k) for k in range(NLOAD) if not abl & 1]
+            ops = [(2 * k + 1, "A", (t + LOOK) % NT, k) for k in range(NLOAD) if not abl & 1]
             if DMA_FRONT and t == 0 and not abl & 2:
                 assert 12 + 2 * NG <= 2 * NB
                 ops += [(12 + 2 * k + h, "D", k, h) for k in range(NG) for h in range(2)]
-            elif S2 and not abl & 2:
+            elif (S2 or F8) and not abl & 2:
                 ops += [(DPOS[i_], "D", g_, 0) for i_, g_ in enumerate(DMA_TAPS[t])]
-            elif not S2 and not DMA_FRONT and t < NG and not abl & 2:
+            elif not S2 and not F8 and not DMA_FRONT and t < NG and not abl & 2:
                 ops += [(DPOS[h], "D", t, h) for h in range(PPW)]
             if in_stream_res and last:
                 for g, j in enumerate(res_groups[t]):
-                    ops += [((kD0, kD1)[g] + 2, "R", j, i) for i in range(3)]
+                    ops += [((RPOS[g] if F8 else (kD0, kD1)[g] + 2), "R", j, i) for i in range(3)]
             return sorted(ops, key=lambda o: o[0])
 
         def younger_than(tap, k_last, t_wait, e_wait, last):
             """Vector-memory operations issued after weight load k_last of tap `tap` and before element e_wait of tap t_wait, in a tile's
             last chunk (with the residual loads) or another one; the chunk before is never a last chunk that matters: its residual loads
             are older than the weights of taps 0 and 1."""
-            seq = [o for tt in range(9) for o in tap_ops(tt, False)] + [o for tt in range(t_wait) for o in tap_ops(tt, last)]
+            seq = [o for tt in range(NT) for o in tap_ops(tt, False)] + [o for tt in range(t_wait) for o in tap_ops(tt, last)]
             seq += [o for o in tap_ops(t_wait, last) if o[0] < e_wait]
             idx = max(i for i, o in enumerate(seq) if o[1] == "A" and o[2] == tap and o[3] == k_last)
             return len(seq) - 1 - idx
@@ -1171,7 +1273,9 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             post = []                                         # KS = 1 families: the LDS-DMA itself, behind this element's MFMAs
             if n + PD < NE:
                 b_read(n + PD)
-            if j == 0 and not w8:
+            if j == 0 and F8:
+                wait_weights(t, 5, t, e)                      # the step's three 8-register fragments: six loads
+            elif j == 0 and not w8:
                 wait_weights(t, 2 + 3 * ks, t, e)             # bf16 fragments: three per k-step
             elif j == 0 and ks == 0:
                 wait_weights(t, 2, t, e)                      # raw pair 2 of this tap: converted (k-step 1) under this k-step's MFMAs
@@ -1200,13 +1304,18 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
                     if jr:
                         body.append(f"v_add_u32 {T[4]}, {16 * jr}, {T[4]}")
                     body += [f"v_min_i32 {T[4]}, {s('rlim')}, {T[4]}", f"v_mul_lo_u32 {T[4]}, {T[4]}, {s('res_ld')}", f"v_add_u32 {T[4]}, {T[4]}, {T[7]}"]
-                    body += [f"global_load_dwordx2 v[{rreg(3 * jr + i)}:{rreg(3 * jr + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}" for i in range(3)]
+                    body += [f"global_load_dwordx2 {'a' if F8 else 'v'}[{rreg(3 * jr + i)}:{rreg(3 * jr + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}" for i in range(3)]
                     cold.append((lx, body, ld))
             # one wait per PAIR of elements (fragments n and n + 1 have landed): the stream is bound by instruction issue
             allowed = min(PD, NE - 1 - n)
-            if n % 2 == 0:
+            if F8:
+                E(f"s_waitcnt lgkmcnt({2 * allowed})", "two reads per fragment")
+            elif n % 2 == 0:
                 E(f"s_waitcnt lgkmcnt({max(allowed - 1, 0) if n + 1 < NE else allowed})")
             for i in range(3 if not abl & 8 else 0):
+                if F8:
+                    E(f"v_mfma_f32_16x16x128_f8f6f4 {acc(i, j)}, {areg(t % (LOOK + 1), i)}, {vr('B', 8 * (n % (PD + 1)), 8)}, {acc(i, j)}")
+                    continue
                 srca = bfreg(ks, i) if w8 else areg(t % (LOOK + 1), 3 * ks + i)
                 E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {srca}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
             for k_, h_ in post:
@@ -1227,8 +1336,8 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_cselect_b32 {s('tmp0')}, 0, {s('tmp0')}", "next buffer")
     E(f"s_sub_i32 {s('tmp1')}, {s('tmp0')}, {s('buf')}")
     E(f"s_mul_i32 {s('tmp1')}, {s('tmp1')}, {CHUNK}")
-    if S2:
-        E(f"s_mov_b32 {s('delta0')}, {s('tmp1')}", "stride-2 family: the row offsets live in separate address registers")
+    if S2 or F8:
+        E(f"s_mov_b32 {s('delta0')}, {s('tmp1')}", "stride-2 / fp8 families: the row offsets are not accumulated in the address registers")
     else:
         E(f"s_lshl_b32 {s('tmp2')}, {s('Wp')}, 5", "2 Wp * 16: back from kernel row 2 to row 0")
         E(f"s_sub_i32 {s('delta0')}, {s('tmp1')}, {s('tmp2')}")
@@ -1263,11 +1372,11 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         k_res = len(tail) - 1 - max(i for i, o in enumerate(tail) if o[2] == "R")
         E(f"s_waitcnt vmcnt({min(63, k_res)})", "the residual (loads return in order: at most 63 younger operations can be outstanding)")
     elif RES and RES_EARLY:
-        tail = [o for tt in range(9) for o in tap_ops(tt, True)]
+        tail = [o for tt in range(NT) for o in tap_ops(tt, True)]
         k_res = len(tail) - 1 - max(i for i, o in enumerate(tail) if o[1] == "R")
         E(f"s_waitcnt vmcnt({k_res})", "the residual (only weight loads of the next tile's first taps are younger)")
-    SC = V.names["A"][0] + 60    # fp8 weights: per-channel scales 2^e of this lane's 3 x 4 output channels
-    if w8:
+    SC = V.names["SC"][0] if F8 else V.names["A"][0] + 60    # fp8 weights: per-channel scales 2^e of this lane's 3 x 4 output channels
+    if w8 or F8:
         for i in range(3):
             E(f"v_lshl_add_u32 {T[6]}, {v('q')}, 2, {s('cbase')}")
             E(f"v_lshlrev_b32 {T[6]}, 2, {T[6]}")
@@ -1405,7 +1514,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
 
 
 def lds_bytes():
-    return LDS_BYTES + (4096 if W8 else 0)
+    return LDS_BYTES + (4096 if W8 else 0)     # (the fp8 family's LDS_BYTES already holds both vectors)
 
 
 def register_budget():
@@ -1487,6 +1596,8 @@ def main():
         variants = [(False, False, 0, False), (True, False, 0, False), (True, True, 0, False)]
         if S2:
             variants = [(False, False, 0, False), (False, True, 0, False)] + ([(False, True, a, False) for a in (1, 2, 3, 4, 7, 8)] if DIAG else [])
+        if F8 and DIAG:
+            variants += [(True, True, a, False) for a in (1, 2, 4, 7, 8)]
         if nb == 13:
             variants += [(False, False, 0, True), (True, False, 0, True), (True, True, 0, True)]     # fp8-weight stream
         if DIAG and nb in (7, 13):

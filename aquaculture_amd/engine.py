@@ -69,7 +69,7 @@ EXPORTS = (
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
     "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_pack_conv_weights_x3", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_stemdown_supported", "aq_stemdown", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
     "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct",
-    "aq_conv3x3_pl_supported", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_s2_supported", "aq_pack_conv3x3_pl_s2", "aq_conv3x3_pl_s2", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
+    "aq_conv3x3_pl_supported", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_s2_supported", "aq_pack_conv3x3_pl_s2", "aq_conv3x3_pl_s2", "aq_f32_to_e4m3", "aq_conv3x3_pl_f8_supported", "aq_pack_conv3x3_pl_f8", "aq_conv3x3_pl_f8", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_letterbox_tiles_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
 
@@ -126,6 +126,11 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_conv3x3_pl_w8.argtypes = lib.aq_conv3x3_pl.argtypes
     lib.aq_pack_conv3x3_pl_w8.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), i32, i32, vp, C.POINTER(C.c_size_t), vp, vp]
     lib.aq_conv3x3_pl_w8_supported.argtypes = [i32] * 5
+    lib.aq_f32_to_e4m3.argtypes = [f32]
+    lib.aq_f32_to_e4m3.restype = C.c_ubyte
+    lib.aq_conv3x3_pl_f8_supported.argtypes = [i32] * 5
+    lib.aq_pack_conv3x3_pl_f8.argtypes = [C.POINTER(f32), C.POINTER(f32), i32, i32, f32, vp, C.POINTER(sz), vp, vp]
+    lib.aq_conv3x3_pl_f8.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp]
     lib.aq_conv3x3_pl_s2_supported.argtypes = [i32] * 5
     lib.aq_pack_conv3x3_pl_s2.argtypes = [C.POINTER(f32), i32, i32, vp, C.POINTER(sz), vp]
     lib.aq_conv3x3_pl_s2.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp]
@@ -706,6 +711,36 @@ def conv3x3_pl_s2_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor
     # channel offsets are expressed through the base pointers (slices): in_choff = out_choff = 0
     _check(lib.aq_conv3x3_pl_s2(x.data_ptr(), ld, 0, cin, out.data_ptr(), out.stride(2), 0, cout, wbuf.data_ptr(), bbuf.data_ptr(), B, H, W, int(act),
                                 _stream_ptr()))
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
+def conv3x3_pl_f8_nhwc(xq: torch.Tensor, act_scale: float, w_oihw: torch.Tensor, bias: torch.Tensor, act: bool = True,
+                       residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """e4m3 codes NHWC [B,H,W,cin] (uint8 or float8_e4m3fn view; may be a channel slice; value = code x act_scale) ->
+    (residual +) SiLU(conv3x3/s1/p1 + b) as bf16 [B,H,W,cout] through aq_conv3x3_pl_f8 (fp8 MFMA on both operands; tests, tools)."""
+    _require_gpu()
+    lib = load_library()
+    xq = xq.view(torch.uint8)
+    assert xq.stride(3) == 1
+    B, H, W, cin = xq.shape
+    cout = w_oihw.shape[0]
+    ld = xq.stride(2)
+    assert xq.stride(1) == W * ld and xq.stride(0) == H * W * ld, "x must be a channel slice of a dense NHWC tensor"
+    w = np.ascontiguousarray(w_oihw.permute(0, 2, 3, 1).float().cpu().numpy())
+    bh = np.ascontiguousarray(bias.float().cpu().numpy())
+    n = C.c_size_t()
+    wp, bp = w.ctypes.data_as(C.POINTER(C.c_float)), bh.ctypes.data_as(C.POINTER(C.c_float))
+    _check(lib.aq_pack_conv3x3_pl_f8(wp, bp, cin, cout, float(act_scale), None, C.byref(n), None, None))
+    wbuf = torch.empty(n.value, dtype=torch.uint8, device=xq.device)
+    sb = torch.empty(2048, dtype=torch.float32, device=xq.device)
+    _check(lib.aq_pack_conv3x3_pl_f8(wp, bp, cin, cout, float(act_scale), wbuf.data_ptr(), C.byref(n), sb.data_ptr(), _stream_ptr()))
+    if out is None:
+        out = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=xq.device)
+    assert out.dtype == torch.bfloat16 and out.stride(3) == 1 and (residual is None or (residual.dtype == torch.bfloat16 and residual.stride(3) == 1))
+    _check(lib.aq_conv3x3_pl_f8(xq.data_ptr(), ld, 0, cin, out.data_ptr(), out.stride(2), 0, cout,
+                                residual.data_ptr() if residual is not None else None, residual.stride(2) if residual is not None else 0, 0,
+                                wbuf.data_ptr(), sb.data_ptr(), B, H, W, int(act), _stream_ptr()))
     torch.cuda.current_stream().synchronize()
     return out
 

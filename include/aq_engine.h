@@ -238,6 +238,17 @@ int aq_conv3x3_pl_s2_supported(int cin, int cout, int B, int H, int W);
 int aq_pack_conv3x3_pl_s2(const float* w_krsc_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream);
 int aq_conv3x3_pl_s2(const void* in_dev, int in_ld, int in_choff, int cin, void* out_dev, int out_ld, int out_choff, int cout,
                      const void* packed_w_dev, const float* bias_dev, int B, int H, int W, int act, void* stream);
+/* fp8 on BOTH MFMA operands (round 3; BASELINE.json configs[3]): the stride-1 planar kernel on v_mfma_f32_16x16x128_f8f6f4 -- input tensor =
+ * OCP e4m3fn codes (NHWC, one byte per channel, value = code x act_scale, written by the producing kernel), weights quantised by the
+ * packer with one scale per output channel (max |w| / 448), fp32 accumulate, epilogue x act_scale x w_scale[co] + bias, SiLU, shortcut,
+ * bf16 out.  cin a multiple of 64, cout of 192 (cout / 192 a power of two).  in_ld / in_choff in BYTES (= channels). */
+unsigned char aq_f32_to_e4m3(float v);      /* round to nearest even, saturating at +-448 */
+int aq_conv3x3_pl_f8_supported(int cin, int cout, int B, int H, int W);
+int aq_pack_conv3x3_pl_f8(const float* w_krsc_host, const float* bias_host, int cin, int cout, float act_scale, void* packed_dev,
+                          size_t* bytes, float* scale_bias_dev, void* stream);
+int aq_conv3x3_pl_f8(const void* in_dev, int in_ld, int in_choff, int cin, void* out_dev, int out_ld, int out_choff, int cout,
+                     const void* res_dev, int res_ld, int res_choff, const void* packed_w_dev, const float* scale_bias_dev,
+                     int B, int H, int W, int act, void* stream);
 /* The same kernel streaming e4m3fn weight codes (AQ_BF16_W8): bit-identical outputs to aq_conv3x3_pl on the dequantised weights.
  * `w` must lie on a per-output-channel grid code x 2^e (AQ_ERR_INVALID otherwise); scale_bias_dev: float[2048] written by the packer
  * (bias x 2^-e, then 2^e).  _supported: NB = 13 tiles fit the image and cout / 192 is a power of two. */

@@ -1,0 +1,81 @@
+"""fp8 on both MFMA operands (BASELINE.json configs[3] "fp8 weights (CDNA4 fp8 MFMA)"): the planar 3x3 kernel's fp8 family
+(gen_conv3x3_pl_asm.py f8nb13, v_mfma_f32_16x16x128_f8f6f4) against F.conv2d on the SAME quantised operands -- the products of two e4m3
+values are exact in fp32, so the only differences are fp32 summation order and the bf16 rounding of the output."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def test_host_e4m3_rounding_is_torchs(lib):
+    """aq_f32_to_e4m3 (the packer's weight quantiser) == torch.float8_e4m3fn's round-to-nearest-even on a dense sweep of the range,
+    every code's exact value, every midpoint between neighbouring codes, subnormals and the saturation edge."""
+    codes = torch.arange(0, 127, dtype=torch.uint8)                        # 0 .. 0x7e: the finite non-negative codes
+    vals = codes.view(torch.float8_e4m3fn).float()
+    mids = (vals[:-1] + vals[1:]) / 2
+    g = torch.Generator().manual_seed(7)
+    sweep = torch.cat([vals, mids, torch.nextafter(mids, torch.tensor(0.0)), torch.nextafter(mids, torch.tensor(1e9)),
+                       torch.rand(20000, generator=g) * 460.0, torch.rand(20000, generator=g) * 0.05, torch.tensor([447.9, 448.0])])
+    sweep = torch.cat([sweep, -sweep])
+    sweep = sweep[sweep.abs() <= 448.0]
+    want = sweep.to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    got = np.array([lib.aq_f32_to_e4m3(float(v)) for v in sweep.tolist()], dtype=np.uint8)
+    bad = np.nonzero((got != want) & ~((want & 0x7f) == 0) | ((got & 0x7f) != (want & 0x7f)))[0]     # (the sign of a zero may differ)
+    assert bad.size == 0, [(float(sweep[i]), hex(got[i]), hex(want[i])) for i in bad[:8]]
+
+
+F8_CASES = [
+    # B, H, W, Cin, Cout, residual mode (None / "sep" / "inplace"), act
+    (3, 40, 40, 192, 192, "inplace", True),    # yolov5m model.6 Bottleneck.cv2: three 64-channel chunks, in-place shortcut
+    (2, 20, 20, 384, 384, "sep", True),        # model.8: two M tiles, six chunks
+    (1, 9, 7, 192, 192, "sep", True),          # sub-tile ragged image: every border case inside one tile
+    (2, 13, 24, 128, 192, None, True),         # two chunks only (the ring wraps into the next tile at once)
+    (5, 20, 20, 192, 192, None, False),        # no activation, no shortcut
+    (40, 40, 40, 192, 192, "inplace", True),   # more tiles than CUs: persistent workgroups walk several tiles
+    (70, 20, 20, 384, 384, "sep", True),       # the same with two M tiles
+    (3, 10, 10, 768, 768, "sep", True),        # four M tiles, twelve chunks
+    (2, 6, 6, 64, 192, None, True),            # ONE chunk: every tile starts and ends the ring
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", F8_CASES)
+def test_planar_conv3x3_f8_matches_reference(lib, case):
+    from aquaculture_amd import engine
+    B, H, W, cin, c, resmode, act = case
+    assert lib.aq_conv3x3_pl_f8_supported(cin, c, B, H, W)
+    g = torch.Generator().manual_seed(c * 3 + H * 5 + cin)
+    x = torch.randn(B, H, W, cin + 32, generator=g).abs() * 0.9 - 0.25          # SiLU-like range: mostly positive, a negative tail
+    act_scale = float(x.abs().max()) / 448.0
+    xq = (x / act_scale).to(torch.float8_e4m3fn)                                 # the codes a producing kernel would have written
+    xw = xq.cuda()
+    xs = xw[..., 16:16 + cin]
+    w = torch.randn(c, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    w = w * (10.0 ** torch.linspace(-1, 1, c)).view(-1, 1, 1, 1)                 # per-channel scales two orders of magnitude apart
+    b = torch.randn(c, generator=g) * 0.2
+    ws = w.abs().amax(dim=(1, 2, 3), keepdim=True) / 448.0
+    wq = (w / ws).to(torch.float8_e4m3fn)
+    outw = torch.full((B, H, W, c + 24), 7.0, dtype=torch.bfloat16, device="cuda")
+    out = outw[..., 16:16 + c]
+    res = None
+    if resmode == "sep":
+        resw = (torch.randn(B, H, W, c + 8, generator=g)).bfloat16().cuda()
+        res = resw[..., 8:]
+    elif resmode == "inplace":
+        out.copy_((torch.randn(B, H, W, c, generator=g)).bfloat16())
+        res = out
+    res_host = res.float().cpu().clone() if res is not None else None
+    engine.conv3x3_pl_f8_nhwc(xs, act_scale, w, b, act, residual=res, out=out)
+    ref = F.conv2d(xq[..., 16:16 + cin].float().double().permute(0, 3, 1, 2), wq.float().double(), None, padding=1)
+    ref = ref * (act_scale * ws.view(1, -1, 1, 1).double()) + b.double().view(1, -1, 1, 1)
+    ref = (F.silu(ref) if act else ref).permute(0, 2, 3, 1)
+    if res_host is not None:
+        ref = ref + res_host.double()
+    got = out.float().cpu()
+    assert (outw[..., :16] == 7.0).all() and (outw[..., 16 + c:] == 7.0).all(), "wrote outside its channel slice"
+    scale = ref.abs().amax(dim=(0, 1, 2)).clamp_min(1e-6).float()
+    err = ((got - ref.float()).abs() / scale).max().item()
+    assert err <= 2 ** -7, err                                                   # bf16 output rounding (+ fp32 summation order)
+    torch.testing.assert_close(got, ref.float().bfloat16().float(), rtol=2 ** -6, atol=2e-2 * float(scale.max()))
