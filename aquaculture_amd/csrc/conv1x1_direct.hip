@@ -27,6 +27,7 @@ struct C1Params {
     const char* zero;
     int in_ld_b, out_ld_b;
     int npix, n_tiles, act;
+    float out_inv_scale;       // F8OUT: the output leaves as OCP e4m3fn codes of y * out_inv_scale (one byte per channel)
 };
 
 constexpr int kNW = 12;
@@ -53,7 +54,10 @@ __device__ __forceinline__ f32x4 c1_silu4(f32x4 v) {        // same sequence as 
     return v * r;
 }
 
-template <int KS, int MBT, int MBW, int NBW>
+// F8OUT (round 3, the fp8 path of BASELINE.json configs[3]): the consumer is the fp8 planar 3x3 kernel (conv3x3_pl.hip, family f8nb13), so
+// the activation is quantised HERE, in the producer's epilogue: y / scale, clamped to e4m3's range, v_cvt_pk_fp8_f32 (round to nearest
+// even), 8 codes = one 8-byte store per lane and pixel; out_ld_b is the pixel pitch in bytes, the codes of channel c sit at byte c.
+template <int KS, int MBT, int MBW, int NBW, bool F8OUT = false>
 __global__ __launch_bounds__(kNW * 64) void conv1x1_direct_kernel(const C1Params p) {
     using G = C1Geom<KS, MBT, MBW, NBW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,7 +124,19 @@ __global__ __launch_bounds__(kNW * 64) void conv1x1_direct_kernel(const C1Params
                 for (int m = 0; m < MBW; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[s][m], f[s], acc[m], 0, 0, 0);
             f32x4 v0 = acc[0] + bv[0], v1 = acc[1] + bv[1];
             if (p.act) { v0 = c1_silu4(v0); v1 = c1_silu4(v1); }
-            if (n0 + px < p.npix)
+            if constexpr (F8OUT) {
+                f32x4 q0 = v0 * p.out_inv_scale, q1 = v1 * p.out_inv_scale;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                // saturate: a tile brighter than the calibration set must not become a NaN code
+                    q0[e] = __builtin_amdgcn_fmed3f(q0[e], -448.0f, 448.0f);
+                    q1[e] = __builtin_amdgcn_fmed3f(q1[e], -448.0f, 448.0f);
+                }
+                int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q0[0], q0[1], 0, false);
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q0[2], q0[3], w0, true);
+                int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q1[0], q1[1], 0, false);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q1[2], q1[3], w1, true);
+                if (n0 + px < p.npix) *(uint2*)(p.out + (n0 + px) * p.out_ld_b + cbase) = make_uint2((unsigned)w0, (unsigned)w1);
+            } else if (n0 + px < p.npix)
                 *(uint4*)(p.out + (n0 + px) * p.out_ld_b + cbase * 2) =
                     make_uint4(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3]));
         }
@@ -129,11 +145,11 @@ __global__ __launch_bounds__(kNW * 64) void conv1x1_direct_kernel(const C1Params
 
 int g_c1_cus = 0;
 
-template <int KS, int MBT, int MBW, int NBW>
+template <int KS, int MBT, int MBW, int NBW, bool F8OUT = false>
 int launch_c1(C1Params p, hipStream_t stream) {
     using G = C1Geom<KS, MBT, MBW, NBW>;
     static bool attr = false;
-    auto fn = conv1x1_direct_kernel<KS, MBT, MBW, NBW>;
+    auto fn = conv1x1_direct_kernel<KS, MBT, MBW, NBW, F8OUT>;
     if (!attr) {
         AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         attr = true;
@@ -204,4 +220,33 @@ extern "C" int aq_conv1x1_direct(const void* in_dev, int in_ld, int in_choff, vo
     if (cin == 192) return launch_c1<6, 12, 2, 4>(p, st);    // 6 x 2, 128-pixel tiles
     if (cout == 192) return launch_c1<12, 12, 2, 2>(p, st);  // 6 x 2, 64-pixel tiles
     return launch_c1<12, 24, 2, 4>(p, st);                   // 12 x 1, 64-pixel tiles
+}
+
+
+// The same convolution writing OCP e4m3fn codes of y / out_scale (192 -> 192 and 384 -> 384: the Bottleneck cv1 layers whose consumer is the
+// fp8 planar 3x3 kernel).  out_pitch_bytes: bytes per output pixel row; the codes of channel c go to byte out_byte_off + c.
+extern "C" int aq_conv1x1_direct_f8out(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_pitch_bytes, int out_byte_off, int cin,
+                                       int cout, const void* packed_w_dev, const float* bias_dev, long long npix, int act, float out_scale,
+                                       void* stream) {
+    AQ_REQUIRE(in_dev && out_dev && packed_w_dev && bias_dev, "conv1x1_direct_f8out: null pointer");
+    AQ_REQUIRE((cin == 192 && cout == 192) || (cin == 384 && cout == 384), "conv1x1_direct_f8out: unsupported %d -> %d", cin, cout);
+    AQ_REQUIRE(npix > 0 && npix < (1LL << 31) && out_scale > 0.0f, "conv1x1_direct_f8out: bad pixel count or scale");
+    AQ_REQUIRE(in_ld % 8 == 0 && in_choff % 8 == 0 && in_choff + cin <= in_ld && out_pitch_bytes % 8 == 0 && out_byte_off % 8 == 0 &&
+                   out_byte_off + cout <= out_pitch_bytes, "conv1x1_direct_f8out: slices must be 8-byte aligned and inside their rows");
+    C1Params p{};
+    p.in = (const char*)in_dev + (size_t)in_choff * 2; p.in_ld_b = in_ld * 2;
+    p.out = (char*)out_dev + out_byte_off; p.out_ld_b = out_pitch_bytes;
+    p.w = (const char*)packed_w_dev; p.bias = bias_dev;
+    p.npix = (int)npix; p.act = act; p.out_inv_scale = 1.0f / out_scale;
+    p.zero = aq_zero_page();
+    AQ_REQUIRE(p.zero, "conv1x1_direct_f8out: zero page allocation failed");
+    if (g_c1_cus == 0) {
+        int dev = 0, cus = 256;
+        AQ_CHECK_HIP(hipGetDevice(&dev));
+        AQ_CHECK_HIP(aq_query_cus(&cus, dev));
+        g_c1_cus = cus;
+    }
+    const hipStream_t st = (hipStream_t)stream;
+    if (cin == 192) return launch_c1<6, 12, 2, 4, true>(p, st);
+    return launch_c1<12, 24, 2, 4, true>(p, st);
 }

@@ -67,6 +67,12 @@ struct PackedW {
     void* w_head = nullptr;     // bf16 engines, Detect head convs with a small head: aq_pack_head_weights image (csrc/head_decode.hip)
     void* w_pl8 = nullptr;      // AQ_BF16_W8 engines, planar 3x3 layers: the e4m3 code stream and its float[2048] bias x 2^-e | 2^e
     float* sb_pl8 = nullptr;
+    // fp8 path (aq_engine_set_fp8_scales): a 3x3 consumer on the fp8 planar kernel, fed with e4m3 codes by its 1x1 producer
+    void* w_f8 = nullptr;       // consumer: aq_pack_conv3x3_pl_f8 image ...
+    float* sb_f8 = nullptr;     // ... and its bias / scale vectors
+    float act_scale = 0.0f;     // consumer: the scale of its input tensor; producer: of its output tensor
+    int f8_consumer = -1;       // producer: the op that reads its codes (the pair runs in fp8 only when that op's geometry fits)
+    std::vector<float> w_host, b_host;   // layers with an fp8 form keep their fused fp32 weights: the fp8 packer needs the activation scale, known later
 };
 
 // Host-side packing: KRSC fp32 -> [cout_rows][kgroups_pad*16 B] of bf16 / fp32, zero padded.
@@ -165,6 +171,7 @@ struct aq_engine {
     int N = 0;
     void* last_ws = nullptr;
     const uint8_t* last_tiles = nullptr;
+    float* calib_amax = nullptr;        // device float[n_ops] while aq_engine_calibrate_amax runs: max |output| of every bf16 conv op
     // profiling
     bool prof = false;
     int ring = 0;
@@ -213,7 +220,36 @@ inline char* tptr(aq_engine* e, void* ws, const uint8_t* tiles, int t) {
     return (char*)ws + e->place[t].offset;
 }
 
+// Does the fp8 pair (1x1 producer -> 3x3 consumer `ci`) run in fp8 for this batch geometry?  Decided by the consumer's kernel alone, so
+// that both ops of the pair always agree.
+bool f8_pair_active(const aq_engine* e, int ci, int B) {
+    if (ci < 0 || !e->packed[ci].w_f8) return false;
+    const aq_op_desc& c = e->ops[ci];
+    const TensorPlace& ps = e->place[c.src.tensor];
+    return aq_conv3x3_pl_f8_supported(c.src.channels, c.dst.channels, B, ps.h, ps.w) != 0;
+}
+
 int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStream_t stream, int force_cfg = -1, bool no_table = false) {
+    if (force_cfg < 0 && !e->calib_amax) {              // (the tuner and the calibration pass run every op in bf16)
+        const aq_op_desc& op = e->ops[oi];
+        const PackedW& pw = e->packed[oi];
+        if (pw.f8_consumer >= 0 && f8_pair_active(e, pw.f8_consumer, B)) {
+            // producer: e4m3 codes of y / scale into the first bytes of each pixel's bf16 slot of the temporary (pitch = the bf16 row)
+            const TensorPlace& pd = e->place[op.dst.tensor];
+            return aq_conv1x1_direct_f8out(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
+                                           tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels * 2, op.dst.ch_off * 2,
+                                           op.src.channels, op.dst.channels, pw.w_direct, pw.bias, (long long)B * pd.h * pd.w, op.act,
+                                           pw.act_scale, stream);
+        }
+        if (pw.w_f8 && f8_pair_active(e, oi, B)) {
+            const TensorPlace& ps = e->place[op.src.tensor];
+            return aq_conv3x3_pl_f8(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels * 2, op.src.ch_off * 2, op.src.channels,
+                                    tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off, op.dst.channels,
+                                    op.res.tensor >= 0 ? tptr(e, ws, tiles, op.res.tensor) : nullptr,
+                                    op.res.tensor >= 0 ? e->tensors[op.res.tensor].channels : 0, op.res.ch_off,
+                                    pw.w_f8, pw.sb_f8, B, ps.h, ps.w, op.act, stream);
+        }
+    }
     if (force_cfg < 0 && !no_table && e->conv_cfg[oi] < 0 && e->tuned_B > 0 && B != e->tuned_B && e->tuned_H == e->lay_H && e->tuned_W == e->lay_W &&
         e->tuned_cfg[oi] >= 0) {
         // A table entry was validated (and timed) at tuned_B only.  Should it reject another batch size -- the ragged last batch of a
@@ -365,6 +401,11 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
                 break;
             }
             rc = run_conv(e, oi, ws, tiles, B, stream);
+            if (!rc && e->calib_amax && e->tensors[op.dst.tensor].dtype == AQ_T_ACT && prec == AQ_BF16 && op.dst.channels % 8 == 0) {
+                const TensorPlace& pdc = e->place[op.dst.tensor];
+                rc = aq_absmax_bf16(tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off, op.dst.channels,
+                                    (long long)B * pdc.h * pdc.w, e->calib_amax + oi, stream);
+            }
             break;
         case AQ_OP_STEM:
             if (stemdown) break;                         // computed inside the down-block launch below
@@ -717,6 +758,11 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
                 return fail(AQ_ERR_HIP);
             }
         }
+        if (d->precision == AQ_BF16 && op.kind == AQ_OP_CONV && op.k == 3 && op.stride == 1 && op.pad == 1 && e->packed[oi].direct_cfg == AQ_CONV_CFG_PL3X3 &&
+            aq_conv3x3_pl_f8_supported(op.src.channels, op.dst.channels, 1, 8, 8)) {
+            e->packed[oi].w_host.assign(op.weight, op.weight + (size_t)op.dst.channels * 9 * op.src.channels);
+            e->packed[oi].b_host.assign(op.bias, op.bias + op.dst.channels);
+        }
         op.weight = nullptr; op.bias = nullptr;   // host pointers are not kept
     }
     *out = e;
@@ -730,6 +776,8 @@ extern "C" void aq_engine_destroy(aq_engine* e) {
         if (pw.w_direct) (void)hipFree(pw.w_direct);
         if (pw.w_head) (void)hipFree(pw.w_head);
         if (pw.w_pl8) (void)hipFree(pw.w_pl8);
+        if (pw.w_f8) (void)hipFree(pw.w_f8);
+        if (pw.sb_f8) (void)hipFree(pw.sb_f8);
         if (pw.sb_pl8) (void)hipFree(pw.sb_pl8);
         if (pw.bias) (void)hipFree(pw.bias);
     }
@@ -758,6 +806,81 @@ extern "C" int aq_engine_forward_raw(aq_engine* e, const uint8_t* tiles_dev, int
                                      float* pred_dev, void* stream) {
     AQ_REQUIRE(pred_dev, "forward_raw: null output pointer");
     return run_plan(e, tiles_dev, B, H, W, ws, ws_bytes, pred_dev, nullptr, nullptr, 0.f, 0.f, 1, (hipStream_t)stream);
+}
+
+// fp8 path, step 1: one bf16 forward pass over `tiles_dev` recording max |y| of every conv op's output (0 for the others) -- the caller turns
+// the Bottleneck cv1 outputs' maxima into per-tensor e4m3 scales (max / 448, with whatever margin it wants) for aq_engine_set_fp8_scales.
+extern "C" int aq_engine_calibrate_amax(aq_engine* e, const uint8_t* tiles_dev, int B, int H, int W, void* ws, size_t ws_bytes,
+                                        float* amax_host, int n_ops, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ_REQUIRE(e && tiles_dev && ws && amax_host && n_ops == (int)e->ops.size(), "calibrate_amax: expected %d entries", e ? (int)e->ops.size() : 0);
+    AQ_REQUIRE(e->desc.precision == AQ_BF16, "calibrate_amax: bf16 engines only");
+    int rc = layout(e, B, H, W);
+    if (rc) return rc;
+    if (ws_bytes < e->total_bytes) { aq_set_error("calibrate_amax: workspace too small"); return AQ_ERR_WORKSPACE; }
+    float* dev = nullptr;
+    AQ_CHECK_HIP(hipMalloc((void**)&dev, sizeof(float) * n_ops));
+    hipError_t he = hipMemsetAsync(dev, 0, sizeof(float) * n_ops, stream);
+    e->calib_amax = dev;
+    if (he == hipSuccess) rc = run_plan(e, tiles_dev, B, H, W, ws, ws_bytes, (float*)((char*)ws + e->off_pred), nullptr, nullptr, 0.f, 0.f, 1, stream);
+    e->calib_amax = nullptr;
+    if (he == hipSuccess && !rc) he = hipMemcpyAsync(amax_host, dev, sizeof(float) * n_ops, hipMemcpyDeviceToHost, stream);
+    if (he == hipSuccess && !rc) he = hipStreamSynchronize(stream);
+    (void)hipFree(dev);
+    if (rc) return rc;
+    AQ_CHECK_HIP(he);
+    return AQ_OK;
+}
+
+// fp8 path, step 2: act_scale[i] > 0 marks conv op i -- a 3x3 / stride-1 layer with a planar form -- as an fp8 consumer whose INPUT tensor
+// carries e4m3 codes of x / act_scale[i]; its producer (the 1x1 conv whose output slice is exactly that input, read by nothing else) is
+// switched to the code-writing epilogue.  Ops that do not qualify are refused (AQ_ERR_INVALID); act_scale <= 0 returns an op to bf16.
+extern "C" int aq_engine_set_fp8_scales(aq_engine* e, const float* act_scale, int n_ops) {
+    AQ_REQUIRE(e && act_scale && n_ops == (int)e->ops.size(), "set_fp8_scales: expected %d entries", e ? (int)e->ops.size() : 0);
+    AQ_REQUIRE(e->desc.precision == AQ_BF16, "set_fp8_scales: bf16 engines only");
+    for (int i = 0; i < n_ops; ++i) {                     // back to bf16 first (a second call replaces the first)
+        PackedW& pw = e->packed[i];
+        if (pw.w_f8) { (void)hipFree(pw.w_f8); pw.w_f8 = nullptr; }
+        if (pw.sb_f8) { (void)hipFree(pw.sb_f8); pw.sb_f8 = nullptr; }
+        pw.f8_consumer = -1;
+        pw.act_scale = 0.0f;
+    }
+    for (int i = 0; i < n_ops; ++i) {
+        if (!(act_scale[i] > 0.0f)) continue;
+        const aq_op_desc& op = e->ops[i];
+        PackedW& pw = e->packed[i];
+        AQ_REQUIRE(op.kind == AQ_OP_CONV && op.k == 3 && op.stride == 1 && op.pad == 1 && pw.direct_cfg == AQ_CONV_CFG_PL3X3 && !pw.w_host.empty() &&
+                       aq_conv3x3_pl_f8_supported(op.src.channels, op.dst.channels, 1, 8, 8), "set_fp8_scales: op %d has no fp8 form", i);
+        int prod = -1, readers = 0;
+        for (int j = 0; j < n_ops; ++j) {
+            const aq_op_desc& o = e->ops[j];
+            if (o.src.tensor == op.src.tensor && o.src.ch_off < op.src.ch_off + op.src.channels && op.src.ch_off < o.src.ch_off + o.src.channels) ++readers;
+            if (o.res.tensor == op.src.tensor && o.res.tensor >= 0) ++readers;
+            if (j < i && o.dst.tensor == op.src.tensor && o.dst.ch_off == op.src.ch_off && o.dst.channels == op.src.channels) prod = j;
+        }
+        AQ_REQUIRE(prod >= 0 && e->ops[prod].kind == AQ_OP_CONV && e->ops[prod].k == 1 && e->packed[prod].direct_cfg == AQ_CONV_CFG_DIRECT1X1 &&
+                       e->ops[prod].res.tensor < 0 && e->ops[prod].src.channels == e->ops[prod].dst.channels &&
+                       (e->ops[prod].dst.channels == 192 || e->ops[prod].dst.channels == 384),
+                   "set_fp8_scales: the input of op %d is not written by a 1x1 layer with a code-writing form", i);
+        // the temporary is shared by the Bottlenecks of a C3 stage: every reader of that slice must be an fp8 consumer as well
+        for (int j = 0; j < n_ops; ++j) {
+            const aq_op_desc& o = e->ops[j];
+            const bool reads = o.src.tensor == op.src.tensor && o.src.ch_off == op.src.ch_off && o.src.channels == op.src.channels;
+            AQ_REQUIRE(!reads || act_scale[j] > 0.0f, "set_fp8_scales: op %d reads the same tensor as op %d but stays bf16", j, i);
+        }
+        (void)readers;
+        size_t nb = 0;
+        AQ_REQUIRE(aq_pack_conv3x3_pl_f8(pw.w_host.data(), pw.b_host.data(), op.src.channels, op.dst.channels, act_scale[i], nullptr, &nb, nullptr, nullptr) == AQ_OK,
+                   "set_fp8_scales: op %d cannot be packed", i);
+        AQ_CHECK_HIP(hipMalloc(&pw.w_f8, nb));
+        AQ_CHECK_HIP(hipMalloc((void**)&pw.sb_f8, 2048 * sizeof(float)));
+        const int rc = aq_pack_conv3x3_pl_f8(pw.w_host.data(), pw.b_host.data(), op.src.channels, op.dst.channels, act_scale[i], pw.w_f8, &nb, pw.sb_f8, nullptr);
+        if (rc) return rc;
+        pw.act_scale = act_scale[i];
+        e->packed[prod].f8_consumer = i;
+        e->packed[prod].act_scale = act_scale[i];
+    }
+    return AQ_OK;
 }
 
 extern "C" int aq_engine_tensor_ptr(aq_engine* e, int tensor, void** ptr, int* channels, int* h, int* w, int* elem_bytes) {

@@ -354,6 +354,42 @@ __global__ __launch_bounds__(256) void mfma_peak16_kernel(float* out, int iters,
     if (s == 123.456f) out[0] = s;
 }
 
+// max |x| over a channel slice of an NHWC bf16 tensor -> *out_dev (float, the caller zeroes it first): calibration of the fp8 path's
+// per-tensor activation scales (aq_engine_calibrate_amax).  |x| as an unsigned integer orders like the float, so atomicMax on the bits.
+namespace {
+__global__ void absmax_bf16_kernel(const unsigned short* x, int ld, int c8, long long ngroups, unsigned* out) {
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < ngroups; i += (long long)gridDim.x * blockDim.x) {
+        const long long px = i / c8;
+        const int g = (int)(i - px * c8);
+        const uint4 v = *(const uint4*)(x + px * ld + g * 8);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned lo = (w[e] << 16) & 0x7fffffffu, hi = w[e] & 0x7fff0000u;
+            m = lo > m ? lo : m;
+            m = hi > m ? hi : m;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)m, o);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+}  // namespace
+
+extern "C" int aq_absmax_bf16(const void* t_dev, int ld, int choff, int c, long long npix, float* out_dev, void* stream) {
+    AQ_REQUIRE(t_dev && out_dev && c > 0 && c % 8 == 0 && ld % 8 == 0 && choff % 8 == 0 && choff + c <= ld && npix > 0, "absmax_bf16: bad slice");
+    const long long ngroups = npix * (c / 8);
+    long long grid = (ngroups + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(absmax_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)t_dev + choff, ld, c / 8, ngroups, (unsigned*)out_dev);
+    AQ_CHECK_HIP(hipGetLastError());
+    return AQ_OK;
+}
+
 extern "C" int aq_debug_mfma_peak(int blocks, int iters, void* out_dev, void* stream) {
     AQ_REQUIRE(blocks > 0 && iters != 0 && out_dev, "mfma_peak: bad argument");
     if (iters < 0) {       // negative count: the 16x16x32 form, 16 MFMAs (the same FLOPs as 8 of the 32x32x16 form) per iteration

@@ -79,7 +79,7 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
     p.add_argument("--dnn", action="store_true")
     p.add_argument("--vid-stride", type=int, default=1)
     p.add_argument("--batch-size", type=int, default=64, help="tiles per engine call")
-    p.add_argument("--precision", choices=("fp32", "bf16", "fp8w", "f16x3"), default=None,
+    p.add_argument("--precision", choices=("fp32", "bf16", "fp8w", "f16x3", "fp8"), default=None,
                    help="default fp32 (detect.py without --half); fp8w = OCP e4m3 weights with per-channel power-of-two scales, bf16 activations")
     p.add_argument("--workers", type=int, default=8, help="jpeg decoders (worker processes for uniform tile directories, threads otherwise)")
     p.add_argument("--decode-threads", action="store_true", help="decode in threads of this process instead of worker processes")

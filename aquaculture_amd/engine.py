@@ -26,7 +26,7 @@ AQ_BF16, AQ_FP32, AQ_BF16_W8, AQ_F16X3 = 0, 1, 2, 3
 PRECISIONS = {"bf16": AQ_BF16, "fp32": AQ_FP32, "fp8w": AQ_BF16, "f16x3": AQ_F16X3}
 """Compute precision of the single-op helpers.  fp8w = fp8 (OCP e4m3fn) weights with per-output-channel power-of-two scales, bf16
 activations (quant.py): values bf16 holds exactly, so every bf16 kernel runs them as they are."""
-ENGINE_PRECISIONS = {"bf16": AQ_BF16, "fp32": AQ_FP32, "fp8w": AQ_BF16_W8, "f16x3": AQ_F16X3}
+ENGINE_PRECISIONS = {"bf16": AQ_BF16, "fp32": AQ_FP32, "fp8w": AQ_BF16_W8, "f16x3": AQ_F16X3, "fp8": AQ_BF16}
 """aq_model_desc.precision.  AQ_BF16_W8 computes as AQ_BF16; kernels with an fp8-weight stream (the planar 3x3) load the e4m3 codes."""
 _DTYPE_CODE = {"act": 0, "f32": 1, "u8": 2}
 
@@ -69,7 +69,7 @@ EXPORTS = (
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
     "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_pack_conv_weights_x3", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_stemdown_supported", "aq_stemdown", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
     "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct",
-    "aq_conv3x3_pl_supported", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_s2_supported", "aq_pack_conv3x3_pl_s2", "aq_conv3x3_pl_s2", "aq_f32_to_e4m3", "aq_conv3x3_pl_f8_supported", "aq_pack_conv3x3_pl_f8", "aq_conv3x3_pl_f8", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
+    "aq_conv3x3_pl_supported", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_s2_supported", "aq_pack_conv3x3_pl_s2", "aq_conv3x3_pl_s2", "aq_f32_to_e4m3", "aq_conv1x1_direct_f8out", "aq_absmax_bf16", "aq_engine_calibrate_amax", "aq_engine_set_fp8_scales", "aq_conv3x3_pl_f8_supported", "aq_pack_conv3x3_pl_f8", "aq_conv3x3_pl_f8", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_letterbox_tiles_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
 
@@ -101,6 +101,10 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_engine_autotune.argtypes = [vp, vp, i32, i32, i32, vp, sz, i32, vp]
     lib.aq_engine_get_conv_config.argtypes = [vp, i32]
     lib.aq_engine_set_tuned_table.argtypes = [vp, i32, i32, i32, C.POINTER(i32), i32]
+    lib.aq_engine_calibrate_amax.argtypes = [vp, vp, i32, i32, i32, vp, sz, C.POINTER(f32), i32, vp]
+    lib.aq_engine_set_fp8_scales.argtypes = [vp, C.POINTER(f32), i32]
+    lib.aq_conv1x1_direct_f8out.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, C.c_longlong, i32, f32, vp]
+    lib.aq_absmax_bf16.argtypes = [vp, i32, i32, i32, C.c_longlong, vp, vp]
     lib.aq_debug_conv_stamp.argtypes = [vp, sz]
     lib.aq_debug_mfma_peak.argtypes = [i32, i32, vp, vp]
     lib.aq_conv_config_tiles.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
@@ -172,8 +176,11 @@ class Engine:
     """YOLOv5 tile engine on one GPU.  Owns the C engine (packed weights) and a workspace tensor."""
 
     def __init__(self, ck: Checkpoint, precision: str = "bf16", device: int = 0, fused_stem: bool = True,
-                 fused_bottleneck: Optional[bool] = None):
-        """``fused_bottleneck``: None = on for bf16 engines (the fused kernel is bf16 only), off for fp32 parity engines."""
+                 fused_bottleneck: Optional[bool] = None, fp8_calibration=None):
+        """``fused_bottleneck``: None = on for bf16 engines (the fused kernel is bf16 only), off for fp32 parity engines.
+        ``precision="fp8"`` (BASELINE.json configs[3]): a bf16 engine whose wide Bottleneck 3x3 layers run on the fp8 MFMA with e4m3 on
+        both operands; the per-tensor activation scales are calibrated on ``fp8_calibration`` (uint8 tiles [B,H,W,3], numpy or CUDA tensor;
+        default: synthetic tiles 0-7 at 640 px) -- call ``calibrate_fp8`` again to re-calibrate on other tiles."""
         _require_gpu()
         self.lib = load_library()
         self.ck = ck
@@ -181,7 +188,7 @@ class Engine:
         self.precision_name = precision
         self.device = torch.device("cuda", device)
         if fused_bottleneck is None:
-            fused_bottleneck = precision in ("bf16", "fp8w")
+            fused_bottleneck = precision in ("bf16", "fp8w", "fp8")
         if fused_bottleneck and precision in ("fp32", "f16x3"):
             raise ValueError("the fused Bottleneck kernel is bf16 only")
         self.plan = _spec.build_plan(ck.variant, ck.nc, ck.na, fused_stem=fused_stem, fused_bottleneck=fused_bottleneck)
@@ -226,6 +233,48 @@ class Engine:
         self.handle = h
         self._ws: Optional[torch.Tensor] = None
         self._slots: Dict[int, torch.Tensor] = {}     # one workspace per in-flight batch (stream slot)
+        self.fp8_scales: Dict[str, float] = {}        # fp8 engines: consumer op name -> e4m3 scale of its input tensor
+        if precision == "fp8":
+            if fp8_calibration is None:
+                from . import tiles as _tiles
+                fp8_calibration = _tiles.synthetic_batch(list(range(8)), 640)
+            self.calibrate_fp8(fp8_calibration)
+
+    def fp8_pairs(self) -> List[Tuple[int, int]]:
+        """(producer op, consumer op) pairs the fp8 path covers: a Bottleneck's cv1 (1x1, direct kernel) feeding its cv2 (3x3 / stride 1,
+        planar kernel) with 192 or 384 channels -- yolov5m: the 14 wide Bottleneck layers."""
+        pairs = []
+        ops = self.plan.ops
+        for i, o in enumerate(ops):
+            if (i and o.kind == _spec.OP_CONV and o.k == 3 and o.stride == 1 and o.name.endswith(".cv2") and ops[i - 1].name == o.name[:-1] + "1"
+                    and ops[i - 1].kind == _spec.OP_CONV and ops[i - 1].k == 1 and o.src.channels == o.dst.channels and o.src.channels in (192, 384)
+                    and (ops[i - 1].dst.tensor, ops[i - 1].dst.ch_off) == (o.src.tensor, o.src.ch_off)
+                    and self.lib.aq_conv3x3_pl_f8_supported(o.src.channels, o.dst.channels, 1, 8, 8)):
+                pairs.append((i - 1, i))
+        return pairs
+
+    def calibrate_fp8(self, tiles, margin: float = 1.0) -> Dict[str, float]:
+        """One bf16 pass over ``tiles`` (uint8 [B,H,W,3]) records max |t| of every Bottleneck cv1 output; scale = margin x max / 448 (e4m3's
+        largest value; the producer saturates beyond it).  Installs the scales (aq_engine_set_fp8_scales) and returns them by consumer name."""
+        if not isinstance(tiles, torch.Tensor):
+            tiles = torch.from_numpy(np.ascontiguousarray(tiles))
+        tiles = tiles.to(self.device).contiguous()
+        B, H, W = self._check_tiles(tiles)
+        n = len(self.plan.ops)
+        zero = (C.c_float * n)()
+        _check(self.lib.aq_engine_set_fp8_scales(self.handle, zero, n))         # calibrate on the bf16 path
+        ws = self.workspace(B, H, W)
+        amax = (C.c_float * n)()
+        _check(self.lib.aq_engine_calibrate_amax(self.handle, tiles.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(), amax, n, _stream_ptr()))
+        scales = (C.c_float * n)()
+        self.fp8_scales = {}
+        for prod, cons in self.fp8_pairs():
+            a = float(amax[prod])
+            if a > 0.0 and np.isfinite(a):
+                scales[cons] = margin * a / 448.0
+                self.fp8_scales[self.plan.ops[cons].name] = float(scales[cons])
+        _check(self.lib.aq_engine_set_fp8_scales(self.handle, scales, n))
+        return dict(self.fp8_scales)
 
     def close(self) -> None:
         if getattr(self, "handle", None):

@@ -127,6 +127,15 @@ int aq_engine_set_conv_config(aq_engine* e, int op, int cfg);
  * fastest per op for that geometry (cudnn.benchmark-style).  Synchronises the stream; call once before timing. */
 int aq_engine_autotune(aq_engine* e, const uint8_t* tiles_dev, int B, int H, int W,
                        void* workspace_dev, size_t workspace_bytes, int reps, void* stream);
+/* fp8 path of BASELINE.json configs[3] (a bf16 engine whose wide Bottleneck 3x3 layers run on the fp8 MFMA, both operands e4m3):
+ * 1. aq_engine_calibrate_amax: one bf16 forward pass over calibration tiles; amax_host[i] = max |output| of conv op i (0 for other ops).
+ * 2. aq_engine_set_fp8_scales: act_scale[i] > 0 switches conv op i (a 3x3 / stride-1 layer with a planar form, cin % 64 == 0) to
+ *    aq_conv3x3_pl_f8 and the 1x1 layer that writes its input to the code-writing epilogue (aq_conv1x1_direct_f8out); act_scale[i] is the
+ *    e4m3 scale of that input tensor (value = code x scale; typically amax of the producer / 448).  The pair falls back to bf16 for batch
+ *    geometries the fp8 kernel cannot tile.  Weights are quantised per output channel (max |w| / 448) by the packer. */
+int aq_engine_calibrate_amax(aq_engine* e, const uint8_t* tiles_dev, int B, int H, int W, void* workspace_dev, size_t workspace_bytes,
+                             float* amax_host, int n_ops, void* stream);
+int aq_engine_set_fp8_scales(aq_engine* e, const float* act_scale, int n_ops);
 int aq_engine_get_conv_config(aq_engine* e, int op);
 /* Install a table that aq_engine_autotune produced earlier (or on another rank) for the SAME engine and (B,H,W): cfgs[n_ops], one id per
  * op as aq_engine_get_conv_config returns them (-1 for ops that are not tuned).  Used for every batch of that tile geometry (H, W),
@@ -242,6 +251,9 @@ int aq_conv3x3_pl_s2(const void* in_dev, int in_ld, int in_choff, int cin, void*
  * OCP e4m3fn codes (NHWC, one byte per channel, value = code x act_scale, written by the producing kernel), weights quantised by the
  * packer with one scale per output channel (max |w| / 448), fp32 accumulate, epilogue x act_scale x w_scale[co] + bias, SiLU, shortcut,
  * bf16 out.  cin a multiple of 64, cout of 192 (cout / 192 a power of two).  in_ld / in_choff in BYTES (= channels). */
+int aq_conv1x1_direct_f8out(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_pitch_bytes, int out_byte_off, int cin, int cout,
+                            const void* packed_w_dev, const float* bias_dev, long long npix, int act, float out_scale, void* stream);
+int aq_absmax_bf16(const void* t_dev, int ld, int choff, int c, long long npix, float* out_dev, void* stream);
 unsigned char aq_f32_to_e4m3(float v);      /* round to nearest even, saturating at +-448 */
 int aq_conv3x3_pl_f8_supported(int cin, int cout, int B, int H, int W);
 int aq_pack_conv3x3_pl_f8(const float* w_krsc_host, const float* bias_host, int cin, int cout, float act_scale, void* packed_dev,

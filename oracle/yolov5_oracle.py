@@ -56,6 +56,21 @@ def wq_fp8_e4m3(w: torch.Tensor) -> torch.Tensor:
     return ((w.double() / s).float().to(torch.float8_e4m3fn).float().double() * s).float()
 
 
+def q_fp8_act(t: torch.Tensor, scale: float) -> torch.Tensor:
+    """The fp8 mode's activation quantiser (engine: the Bottleneck cv1 epilogue, aquaculture_amd/csrc/conv1x1_direct.hip F8OUT):
+    e4m3fn CODES (as floats) of t / scale, saturating at +-448, round to nearest even.  The tensor's value is code x scale."""
+    return (t.float() / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+
+
+def wq_fp8_real(w: torch.Tensor):
+    """The fp8 mode's weight quantiser (engine: aq_pack_conv3x3_pl_f8): per output channel s = max|w| / 448 in fp32, codes =
+    float8_e4m3fn(w / s).  Returns (codes as floats, s [cout])."""
+    amax = w.float().abs().amax(dim=tuple(range(1, w.dim())))
+    s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    codes = (w.float() / s.view(-1, *([1] * (w.dim() - 1)))).to(torch.float8_e4m3fn).float()
+    return codes, s
+
+
 def q_bf16_f64(t: torch.Tensor) -> torch.Tensor:
     """The same storage rounding with the arithmetic between two roundings carried in fp64: against ``q_bf16`` (fp32 accumulation in
     PyTorch's summation order) it measures how far results move when ONLY the accumulation changes -- the floor any other
@@ -87,7 +102,8 @@ class OracleModel:
 
     def __init__(self, state: Dict[str, torch.Tensor], nc: int, anchors_grid: torch.Tensor,
                  stride: Sequence[float] = (8.0, 16.0, 32.0), bn_eps: float = 1e-3,
-                 quant: Callable[[torch.Tensor], torch.Tensor] = q_fp32, wquant: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+                 quant: Callable[[torch.Tensor], torch.Tensor] = q_fp32, wquant: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+                 f8_scales: Optional[Dict[str, float]] = None):
         self.state = state
         self.nc, self.no = nc, nc + 5
         self.anchors = anchors_grid.float()          # (nl, na, 2) grid units
@@ -95,6 +111,8 @@ class OracleModel:
         self.na = int(self.anchors.shape[1])
         self.eps = bn_eps
         self.q = quant
+        self.f8 = dict(f8_scales or {})   # fp8 mode (configs[3]): "<bottleneck key>.cv2" -> e4m3 scale of that layer's INPUT (the cv1 output);
+        #                                  those 3x3 layers multiply e4m3 codes on both sides (q_fp8_act x wq_fp8_real), everything else as ``quant``
         self.wq = wquant          # weight-only quantiser of the conv layers (fp8w mode), applied to the fused weights before ``quant``
         self._fused: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.taps: Optional[Dict[str, torch.Tensor]] = None   # per-module outputs when tracing
@@ -117,6 +135,15 @@ class OracleModel:
 
     def bottleneck(self, x, key, shortcut):
         """Bottleneck: x + cv2(cv1(x)) if shortcut else cv2(cv1(x)); cv1 1x1, cv2 3x3."""
+        sa = self.f8.get(f"{key}.cv2")
+        if sa:
+            # fp8 pair: cv1's fp32 epilogue output goes straight to e4m3 codes (no bf16 rounding in between); cv2 multiplies codes by
+            # codes (exact products, fp32 accumulate) and rescales by act_scale x w_scale[co] before bias and SiLU
+            tq = q_fp8_act(self.conv(x, f"{key}.cv1", 1, 1), sa)
+            w, b = fuse_conv_and_bn(self.state, f"{key}.cv2", self.eps)
+            wc, ws = wq_fp8_real(w)
+            y = F.silu(F.conv2d(tq, wc, None, padding=1) * (sa * ws).view(1, -1, 1, 1) + b.view(1, -1, 1, 1))
+            return self.q(x + y if shortcut else y)
         t = self.q(self.conv(x, f"{key}.cv1", 1, 1))
         y = self.conv(t, f"{key}.cv2", 3, 1)
         return self.q(x + y if shortcut else y)
@@ -327,7 +354,7 @@ def detect_tiles(model: OracleModel, tiles_u8_nhwc: np.ndarray, conf_thres=0.25,
     return dets
 
 
-def model_from_checkpoint(ck, quant=q_fp32, wquant=None) -> OracleModel:
+def model_from_checkpoint(ck, quant=q_fp32, wquant=None, f8_scales=None) -> OracleModel:
     """``ck``: any object with .state, .nc, .anchors (grid units), .stride, .bn_eps.  ``wquant=wq_fp8_e4m3`` with ``quant=q_bf16`` is
-    the engine's fp8w mode."""
-    return OracleModel(ck.state, ck.nc, ck.anchors, ck.stride, ck.bn_eps, quant, wquant)
+    the engine's fp8w mode; ``f8_scales`` (with ``quant=q_bf16``) its fp8 mode: {"model.6.m.0.cv2": act_scale, ...}."""
+    return OracleModel(ck.state, ck.nc, ck.anchors, ck.stride, ck.bn_eps, quant, wquant, f8_scales)

@@ -79,3 +79,66 @@ def test_planar_conv3x3_f8_matches_reference(lib, case):
     err = ((got - ref.float()).abs() / scale).max().item()
     assert err <= 2 ** -7, err                                                   # bf16 output rounding (+ fp32 summation order)
     torch.testing.assert_close(got, ref.float().bfloat16().float(), rtol=2 ** -6, atol=2e-2 * float(scale.max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,H,W", [(192, 40, 40), (384, 20, 20), (192, 7, 9)])
+def test_direct_conv1x1_writes_the_e4m3_codes_of_its_output(lib, c, H, W):
+    """The producer half of an fp8 pair: aq_conv1x1_direct_f8out == float8_e4m3fn(SiLU(conv1x1) / scale) -- code for code, but for
+    values whose fp32 sum lands on another side of a rounding boundary in another summation order (a fraction of a percent, one code apart)."""
+    from aquaculture_amd import engine
+    B = 3
+    g = torch.Generator().manual_seed(c + H)
+    xw = (torch.randn(B, H, W, c + 16, generator=g) * 0.8).bfloat16().cuda()
+    x = xw[..., 8:8 + c]
+    w = torch.randn(c, c, 1, 1, generator=g) * (2.0 / c) ** 0.5
+    b = torch.randn(c, generator=g) * 0.2
+    ref = F.silu(F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.bfloat16().float(), b)).permute(0, 2, 3, 1)
+    scale = float(ref.abs().max()) / 448.0 * 0.9                                # 10 % of the range saturates: the clamp is exercised
+    want = (ref / scale).clamp(-448, 448).to(torch.float8_e4m3fn)
+    wk = np.ascontiguousarray(w.permute(0, 2, 3, 1).float().numpy())
+    n = C.c_size_t()
+    wp = wk.ctypes.data_as(C.POINTER(C.c_float))
+    engine._check(lib.aq_pack_conv1x1_direct(wp, c, c, None, C.byref(n), None))
+    wbuf = torch.empty(n.value, dtype=torch.uint8, device="cuda")
+    engine._check(lib.aq_pack_conv1x1_direct(wp, c, c, wbuf.data_ptr(), C.byref(n), engine._stream_ptr()))
+    bbuf = b.float().cuda()
+    pitch = 2 * c + 32                                                            # codes live in the first bytes of a wider (bf16-sized) row
+    out = torch.full((B, H, W, pitch), 0xAA, dtype=torch.uint8, device="cuda")
+    engine._check(lib.aq_conv1x1_direct_f8out(x.data_ptr(), c + 16, 0, out.data_ptr(), pitch, 16, c, c, wbuf.data_ptr(), bbuf.data_ptr(),
+                                              B * H * W, 1, scale, engine._stream_ptr()))
+    torch.cuda.synchronize()
+    got = out[..., 16:16 + c].cpu()
+    assert (out[..., :16] == 0xAA).all() and (out[..., 16 + c:] == 0xAA).all()
+    gv, wv = got.view(torch.float8_e4m3fn).float(), want.float()
+    assert not torch.isnan(gv).any() and float(gv.max()) == 448.0               # saturated, never NaN
+    same = (got == want.view(torch.uint8)).float().mean().item()
+    assert same > 0.99, same
+    assert ((gv - wv).abs() <= 0.126 * wv.abs().clamp_min(2.0 ** -9)).all()    # the others: the neighbouring code
+
+
+@pytest.mark.gpu
+def test_fp8_engine_matches_the_fp8_oracle(lib, synth_ck):
+    """Engine precision "fp8" (14 Bottleneck pairs on the fp8 MFMA, everything else bf16) against the oracle emulating the same
+    quantisers with the engine's calibrated scales, and against the plain bf16 engine: the fp8 layers add quantisation error of their own
+    (3 mantissa bits), which must stay of the order the oracle's own fp8 emulation shows against its bf16 emulation."""
+    from aquaculture_amd import engine, tiles
+    from oracle import yolov5_oracle as O
+    x = tiles.synthetic_batch([0, 5, 19], 256)
+    eng = engine.Engine(synth_ck, "fp8", fp8_calibration=x)
+    assert len(eng.fp8_scales) == 14 and all(s > 0 for s in eng.fp8_scales.values())
+    pred = eng.forward_raw(torch.from_numpy(x).cuda()).float().cpu()
+    m8 = O.model_from_checkpoint(synth_ck, O.q_bf16, f8_scales=eng.fp8_scales)
+    m16 = O.model_from_checkpoint(synth_ck, O.q_bf16)
+    ref8, ref16 = m8.forward(O.preprocess(x)), m16.forward(O.preprocess(x))
+    bf = engine.Engine(synth_ck, "bf16")
+    p16 = bf.forward_raw(torch.from_numpy(x).cuda()).float().cpu()
+    d_eng = (pred[..., 4] - ref8[..., 4]).abs()               # engine fp8 vs oracle fp8: accumulation-order noise only
+    d_q = (ref8[..., 4] - ref16[..., 4]).abs()                # what the quantisation itself does (oracle vs oracle)
+    d_bf = (p16[..., 4] - ref16[..., 4]).abs()                # the bf16 engine's own distance from its oracle
+    print(f"objectness |d|: fp8 engine vs fp8 oracle mean {d_eng.mean():.2e} max {d_eng.max():.2e}; fp8 vs bf16 oracle mean {d_q.mean():.2e} "
+          f"max {d_q.max():.2e}; bf16 engine vs bf16 oracle mean {d_bf.mean():.2e} max {d_bf.max():.2e}")
+    assert float(d_eng.mean()) <= 3.0 * float(d_bf.mean()) + 1e-4 and float(d_eng.max()) <= 3.0 * float(d_bf.max()) + 1e-3
+    assert float((pred[..., 4] - p16[..., 4]).abs().mean()) > 0.0                  # the fp8 layers did run
+    dets, counts = eng.infer(torch.from_numpy(x).cuda())
+    assert int(counts.sum()) > 0

@@ -126,6 +126,47 @@ def main():
                   f"-> clock {(life / ticks).median() * 100:.0f} MHz | " + " ".join(f"{n}={t[:, k].mean():.0f}" for k, n in enumerate(names)), flush=True)
         us = timeit(run_w8)
         print(f"{c}ch {H}x{W} B{B}  planar NB=13 asm, e4m3 weight stream: {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
+        # fp8 on both MFMA operands (family f8nb13): the input as e4m3 codes
+        xq = [(x.float() / 0.01).clamp(-448, 448).to(torch.float8_e4m3fn) for x in xs]
+        E._check(lib.aq_pack_conv3x3_pl_f8(wp, bh.ctypes.data_as(C.POINTER(C.c_float)), c, c, 0.01, None, C.byref(n), None, None))
+        wf8 = torch.empty(n.value, dtype=torch.uint8, device=dev)
+        sbf8 = torch.empty(2048, dtype=torch.float32, device=dev)
+        E._check(lib.aq_pack_conv3x3_pl_f8(wp, bh.ctypes.data_as(C.POINTER(C.c_float)), c, c, 0.01, wf8.data_ptr(), C.byref(n), sbf8.data_ptr(), st))
+
+        def run_f8(i):
+            o = outs[i % nbuf]
+            E._check(lib.aq_conv3x3_pl_f8(xq[i % nbuf].data_ptr(), c, 0, c, o.data_ptr(), 2 * c, 0, c, o.data_ptr(), 2 * c, 0,
+                                          wf8.data_ptr(), sbf8.data_ptr(), B, H, W, 1, st))
+
+        r_f8, r_bf = [], []
+        for rnd in range(3):                                  # interleaved rounds in one process
+            r_f8.append(timeit(run_f8))
+            r_bf.append(timeit(run_pl))
+        print(f"{c}ch {H}x{W} B{B}  planar fp8 x fp8 (f8nb13): median {np.median(r_f8):8.1f} us (min {min(r_f8):.1f})  {flops / np.median(r_f8) / 1e6:7.1f} TFLOP/s   "
+              f"[bf16 planar beside it: {np.median(r_bf):.1f} us]", flush=True)
+        if a.stamp:
+            for abl_ in [""] + [v for v in a.abl.split(",") if v]:
+                buf = torch.zeros(1 << 16, dtype=torch.int64, device=dev)
+                E._check(lib.aq_debug_conv_stamp(buf.data_ptr(), buf.numel() * 8))
+                os.environ["AQ_PL_ASM"] = "2"
+                if abl_:
+                    os.environ["AQ_PL_ASM_ABL"] = abl_
+                for i in range(3):
+                    run_f8(i)
+                torch.cuda.synchronize()
+                buf.zero_()
+                run_f8(3)
+                torch.cuda.synchronize()
+                lib.aq_debug_conv_stamp(None, 0)
+                os.environ.pop("AQ_PL_ASM", None)
+                os.environ.pop("AQ_PL_ASM_ABL", None)
+                t = buf.cpu().view(-1, 8).double()
+                t = t[t[:, 6] > 0]
+                if t.shape[0]:
+                    names = ["prologue", "chunk-barrier", "stream", "tile-setup", "epilogue", "chunk-top"]
+                    life, ticks = t[:, 6], t[:, 7]
+                    print(f"{c}ch fp8 stamped ABL={abl_ or 0}: waves {t.shape[0]}  lifetime {life.mean():.0f} cycles = {ticks.mean() * 10:.0f} ns -> clock "
+                          f"{(life / ticks).median() * 100:.0f} MHz | " + " ".join(f"{n_}={t[:, k].mean():.0f}" for k, n_ in enumerate(names)), flush=True)
         us = timeit(run_pl)
         print(f"{c}ch {H}x{W} B{B}  planar auto : {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
         for cfg in [int(v) for v in a.old.split(",") if v]:
