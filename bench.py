@@ -57,6 +57,9 @@ def parse():
     p.add_argument("--parity-steps", type=int, default=3, help="steps of the fp32 parity-mode engine timed beside the bf16 metric (0 = skip)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle sample budget")
     p.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristic instead of timing configs")
+    p.add_argument("--retune", action="store_true", help="time the tile configurations in this run even when the in-tree table (aquaculture_amd/data/"
+                                                         "tuned_tables.json) has this geometry")
+    p.add_argument("--write-tuned", default="", help="merge this run's tuned table into the given JSON file (maintainers: refresh the shipped table)")
     p.add_argument("--no-profile", action="store_true", help="skip per-op HIP events (roofline becomes null)")
     p.add_argument("--launcher-selftest", action="store_true", help="run only the rank launch / rendezvous / reduction plumbing (no GPU work)")
     p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"),
@@ -251,8 +254,18 @@ def main() -> int:
         return t
 
     with torch.cuda.stream(streams[0]):                   # (a CU-masked stream times the candidates on the CUs they will run on)
-        cfgs = eng.autotune(tiles_dev[0], cache=os.environ.get("AQ_TUNE_CACHE")) if not a.no_autotune else None
+        cfgs = eng.autotune(tiles_dev[0], cache=os.environ.get("AQ_TUNE_CACHE"), shipped=not a.retune) if not a.no_autotune else None
     torch.cuda.synchronize()
+    if a.write_tuned and cfgs is not None and rank == 0:
+        key = eng.tune_key(B, a.size, a.size)
+        try:
+            with open(a.write_tuned) as f:
+                tab = json.load(f)
+        except (OSError, ValueError):
+            tab = {}
+        tab[key] = [int(c) for c in cfgs]
+        with open(a.write_tuned, "w") as f:
+            json.dump(tab, f, indent=0)
     for k in range(max(W, a.streams)):
         step(k, 0)
     join()
@@ -396,10 +409,20 @@ def main() -> int:
         "config": {"workload": f"{a.variant} {a.precision}, 1xMI355X per rank, batch={B}, synthetic {a.size}x{a.size} ocean tiles "
                                f"resident in HBM ({a.pool} distinct batches cycled), seeded random-init weights nc=5 "
                                f"(BASELINE.json configs[{3 if a.precision in ('fp8w', 'fp8') else 1}])",
+                   "tile_configs": getattr(eng, "tuned_from", "heuristic") if not a.no_autotune else "heuristic",
                    "batch_per_gpu": B, "tile_px": a.size, "parallelism": f"tile-sharded dp{world}", "batches_in_flight": a.streams, **({"cu_split": a.cu_split} if a.cu_split else {}),
                    "detections_gathered": n_dets_total},
         "roofline": roof,
     }
+    # SURVEY 8d's second leg: the same build end to end from an image directory (tools/bench_e2e.py, a separate run on the same pool of
+    # boxes): quoted only when it was measured on THIS library build; never part of `value`
+    try:
+        with open(os.path.join(ROOT, "profiles", "e2e_latest.json")) as f:
+            e2e = json.load(f)
+        with open(os.path.join(ROOT, "aquaculture_amd", "csrc", "libaqengine.so.sha256")) as f:
+            out["e2e"] = e2e if e2e.get("library_source_digest") == f.read().strip() else None
+    except (OSError, ValueError):
+        out["e2e"] = None
     if world == 1 and a.precision == "bf16" and a.parity_steps > 0:
         # what the 1e-4 parity gate costs: the same workload through the fp32 engine (exact-fp32 MFMA, 157 TFLOP/s peak), heuristic tile shapes
         eng.close()

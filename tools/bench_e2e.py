@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--decode-threads", action="store_true", help="in-process decode threads instead of worker processes (A/B)")
     ap.add_argument("--scenes", type=int, default=0, help="scene mode: write this many 6144x6144 scene rasters (36 tiles each) and sweep them "
                                                           "with --tile-scenes instead of a jpeg directory")
+    ap.add_argument("--json", default="", help="append this run's numbers to a JSON file (profiles/e2e_latest.json: bench.py quotes it as `e2e`)")
     a = ap.parse_args()
     from aquaculture_amd import checkpoint, tiles
     jp = os.path.join(a.dir, f"jpegs_{a.size}")
@@ -67,6 +68,31 @@ def main():
         print(r.stderr[-2000:])
     what = f"{a.scenes} scenes ({a.n} 1024px tiles)" if a.scenes else f"{a.n} {a.size}px jpegs"
     print(f"wall {dt:.1f} s for {what} -> {a.n / dt:.0f} images/s including process start, checkpoint load and autotune")
+    if a.json and r.returncode == 0:
+        import json
+        import re
+        steady = None
+        for l in r.stdout.splitlines():
+            m = re.search(r"([0-9.]+) images/s on (\d+) GPU", l)
+            if m:
+                steady = float(m.group(1))
+        try:
+            digest = open(os.path.join(ROOT, "aquaculture_amd", "csrc", "libaqengine.so.sha256")).read().strip()
+        except OSError:
+            digest = ""
+        try:
+            doc = json.load(open(a.json))
+        except (OSError, ValueError):
+            doc = {}
+        if doc.get("library_source_digest") != digest:
+            doc = {"library_source_digest": digest, "what": "yolov5/detect.py end to end on one MI355X: image directory -> label files "
+                   "(decode, H2D, device letterbox, engine, NMS, D2H, rescale, %g formatting, one file per tile with detections)", "runs": []}
+        doc["runs"].append({"input": ("6144x6144 scene rasters, tiles cut on the device (--tile-scenes)" if a.scenes else f"{a.size}x{a.size} jpegs (q75)"),
+                            "images": a.n, "decode_workers": a.workers, "decode": "threads" if a.decode_threads else "worker processes",
+                            "batch_size": a.batch_size, "precision": a.precision, "images_per_s_steady": steady,
+                            "images_per_s_wall_incl_start": round(a.n / dt, 1), "host_cpus": os.cpu_count()})
+        with open(a.json, "w") as f:
+            json.dump(doc, f, indent=1)
 
 
 if __name__ == "__main__":

@@ -3,7 +3,9 @@
 
 Runs `bench.py` under `rocprofv3 --pmc` once per counter group (counters in their own passes, with
 kernel-trace only -- never with sys/hip/hsa tracing), maps every kernel dispatch of the timed steps back to its
-plan op by position (each engine step launches a fixed kernel sequence starting with the stem kernel) and
+plan op by KERNEL NAME in plan order (a step starts with the stem kernel; every op kind has its kernel families, auxiliary
+dispatches -- the fused heads' counter memset and gather -- go to the op they serve; round 2 mapped by position and mislabelled the
+head rows once the heads were fused; the engine's roctx ranges cannot help here: counter passes must not enable marker tracing) and
 writes a per-op table.  FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for
 gfx950 wide coalesced reads; WRITE_SIZE is taken as is; both are in KiB in rocprofv3's output.
 
@@ -76,9 +78,58 @@ def parse(path):
 FIRST_KERNELS = ("stem_conv_kernel", "preprocess_s2d_kernel")   # the kernel a step starts with (fused stem / two-kernel stem)
 
 
-def steps_of(disp, kernels_per_step):
-    starts = [i for i, d in enumerate(disp) if any(k in d["name"] for k in FIRST_KERNELS)]
-    return [disp[s:s + kernels_per_step] for s in starts if s + kernels_per_step <= len(disp)]
+PLAN = [None]
+
+
+def op_patterns(o, spec):
+    """Kernel-name fragments an op of the plan may launch."""
+    if o.kind == spec.OP_STEM:
+        return ("stem_conv_kernel",)
+    if o.kind == spec.OP_PREPROCESS:
+        return ("preprocess_s2d_kernel",)
+    if o.kind == spec.OP_DOWNBLOCK:
+        return ("downblock_kernel",)
+    if o.kind == spec.OP_BOTTLENECK:
+        return ("bottleneck_kernel",)
+    if o.kind == spec.OP_SPPF_POOL:
+        return ("sppf_pool",)
+    if o.kind == spec.OP_UPSAMPLE2X:
+        return ("upsample2x_kernel",)
+    if o.kind == spec.OP_DECODE:
+        return ("decode_kernel",)
+    if o.kind == spec.OP_NMS:
+        return ("nms_kernel",)
+    if o.level >= 0:
+        return ("head_decode_kernel", "conv_igemm_kernel")
+    return ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv1x1_direct_kernel", "conv3x3_pl", "downblock_kernel")
+
+
+def steps_of(disp, kernels_per_step=None):
+    """-> list of steps; a step = list of (op index, dispatch), dispatches matched to plan ops by kernel name in plan order.  A dispatch no
+    later op claims (memset / counter gather of the fused heads) is booked on the op before it; an op without a dispatch (the decode op of
+    the fused-head path) simply gets none.  Steps whose kernel sequence does not walk the whole plan are dropped."""
+    from aquaculture_amd import spec
+    plan = PLAN[0]
+    pats = [op_patterns(o, spec) for o in plan.ops]
+    starts = [i for i, d in enumerate(disp) if any(k in d["name"] for k in FIRST_KERNELS)] + [len(disp)]
+    out = []
+    for a_, b_ in zip(starts[:-1], starts[1:]):
+        cur, step, ok = 0, [], True
+        for d in disp[a_:b_]:
+            nxt = next((j for j in range(cur, len(pats)) if any(p_ in d["name"] for p_ in pats[j])), None)
+            # an auxiliary kernel matches nothing ahead -- or only something implausibly far ahead (more than the few ops a fused path skips)
+            if nxt is None or nxt > cur + 3:
+                step.append((max(cur - 1, 0), d))
+                continue
+            step.append((nxt, d))
+            cur = nxt + 1
+        seen = {i for i, _ in step}
+        need = {i for i, o in enumerate(plan.ops) if o.kind != spec.OP_DECODE}
+        if need - seen:
+            ok = False
+        if ok:
+            out.append(step)
+    return out
 
 
 def main():
@@ -98,10 +149,7 @@ def main():
     from aquaculture_amd import spec
     plan = spec.build_plan("yolov5m", 5, fused_bottleneck=True)   # what a bf16 Engine (and bench.py) runs
     fl = plan.flops(640, 640)
-    # kernel sequence of one step: one per op, the SPPF pool op launches 3 kernels
-    seq = []
-    for i, o in enumerate(plan.ops):
-        seq += [i] * (2 if o.kind == spec.OP_DECODE else 1)   # decode = memset + kernel (SPPF pools are one fused launch at 640 px)
+    PLAN[0] = plan
     if "stats" in a.groups:
         a.groups = [g for g in a.groups if g != "stats"]
         sd = run_stats(a.out, a.batch)
@@ -112,12 +160,25 @@ def main():
                 for row in csv.DictReader(f):
                     disp.append({"name": row["Kernel_Name"], "dur": int(row["End_Timestamp"]) - int(row["Start_Timestamp"]), "start": int(row["Start_Timestamp"])})
             disp.sort(key=lambda d: d["start"])
-            st = steps_of(disp, len(seq))[-10:]          # the 10 single-stream steps of bench.py's roofline pass (the last ones)
+            st = steps_of(disp)[-10:]                    # the 10 single-stream steps of bench.py's roofline pass (the last ones)
             idx3 = [i for i, o in enumerate(plan.ops) if o.kind == spec.OP_CONV and o.meta.get("class") == "conv3x3"]
-            durs = [d["dur"] for step in st for pos, d in enumerate(step) if seq[pos] in idx3]
+            durs = [d["dur"] for step in st for op_, d in step if op_ in idx3]
+            idx_all3 = set(idx3) | {i for i, o in enumerate(plan.ops) if o.kind in (spec.OP_BOTTLENECK, spec.OP_DOWNBLOCK)}
+            d_all3 = sum(d["dur"] for step in st for op_, d in step if op_ in idx_all3) / max(len(st), 1)
+            f_all3 = sum(plan.ops[i].flops_per_tile for i in idx_all3) * a.batch
+            by_kernel = defaultdict(lambda: [0, 0])
+            for step in st:
+                for op_, d in step:
+                    if op_ in idx3:
+                        k_ = d["name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0][:48]
+                        by_kernel[k_][0] += 1
+                        by_kernel[k_][1] += d["dur"]
             summ = {"steps": len(st), "which": "last 10 steps of the run = bench.py's single-stream roofline pass", "conv3x3_launches": len(durs), "conv3x3_avg_launch_us": sum(durs) / max(len(durs), 1) / 1e3,
                     "conv3x3_ms_per_step": sum(durs) / max(len(st), 1) / 1e6,
-                    "all_kernels_ms_per_step": sum(d["dur"] for step in st for d in step) / max(len(st), 1) / 1e6}
+                    "conv3x3_tflops": sum(plan.ops[i].flops_per_tile for i in idx3) * a.batch / (sum(durs) / max(len(st), 1)) / 1e3,
+                    "conv3x3_by_kernel_avg_us": {k_: round(v_[1] / v_[0] / 1e3, 2) for k_, v_ in sorted(by_kernel.items())},
+                    "all_3x3_kernels_ms_per_step": d_all3 / 1e6, "all_3x3_tflops": f_all3 / max(d_all3, 1) / 1e3,
+                    "all_kernels_ms_per_step": sum(d["dur"] for step in st for _, d in step) / max(len(st), 1) / 1e6}
             with open(os.path.join(a.out, "stats_summary.json"), "w") as f:
                 json.dump(summ, f, indent=1)
             print("kernel-trace summary:", json.dumps(summ))
@@ -127,15 +188,15 @@ def main():
         path = run_pass(g, GROUPS[g], a.out, a.batch, a.steps)
         if not path:
             continue
-        st = steps_of(parse(path), len(seq))
+        st = steps_of(parse(path))
         st = st[1:] if len(st) > 1 else st          # drop the warm-up step when there is another
         for step in st:
-            for pos, d in enumerate(step):
-                op = seq[pos]
+            for op, d in step:
                 for k, v in d["c"].items():
                     merged[op][k] += v / len(st)
                 merged[op]["dur_ns_" + g] += d["dur"] / len(st)
-                meta[op] = (d["name"], d["vgpr"], d["lds"], d["grid"], d["wg"])
+                if op not in meta or any(p_ in d["name"] for p_ in op_patterns(plan.ops[op], spec)):
+                    meta[op] = (d["name"], d["vgpr"], d["lds"], d["grid"], d["wg"])
     rows = []
     for i, o in enumerate(plan.ops):
         c = merged.get(i, {})
@@ -161,7 +222,7 @@ def main():
                 cfgs = {k: [v[i] for i, o in enumerate(plan.ops) if o.kind == spec.OP_CONV and o.meta.get("class") == "conv3x3"] for k, v in tc.items()}
             except (OSError, ValueError):
                 pass
-            json.dump({"kernel": f"conv3x3_pl_asm_nb13 / conv3x3_halo_kernel / conv_igemm_kernel / downblock_kernel on the {len(r3)} 3x3 layers launched as plain convs", "batch": a.batch, "launches_averaged": len(r3),
+            json.dump({"kernel": f"conv3x3_pl_asm_nb13 / conv3x3_pl_asm_s2nb13 / downblock_kernel / conv_igemm_kernel on the {len(r3)} 3x3 layers launched as plain convs", "batch": a.batch, "launches_averaged": len(r3),
                        "library_source_digest": lib_digest, "conv3x3_configs": cfgs,
                        "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr,
                        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 counts 128-B "
