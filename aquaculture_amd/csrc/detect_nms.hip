@@ -130,13 +130,19 @@ struct NmsParams {
     unsigned long long* dbg;    // diagnostics (armed stamp buffer): 8 phase timestamps per tile, else null
 };
 
-constexpr int kFast = 2048;              // candidates handled by the bit-matrix path
-constexpr int kFastWords = kFast / 64;
+// Candidates handled by the bit-matrix (fast) path: 2048 for 640-px tiles (25,200 rows, a few hundred candidates), 4096 for larger tiles
+// (round 3: at 1280 px -- BASELINE.json configs[4] -- the synthetic head passes ~2,000 candidates per tile, and the tiles beyond 2,048 fell
+// to the bitonic-sort path: 1.9 ms of a 21.6 ms step).  nms_kernel<KF>; aq_nms picks KF from the tile's row count.
+constexpr int kFast = 2048;
+constexpr int kFastBig = 4096;
+constexpr int kFastRowsLimit = 40000;    // rows per tile up to which the 2048 kernel is launched
+__host__ __device__ constexpr int nms_fast(int N) { return N > kFastRowsLimit ? kFastBig : kFast; }
 constexpr int kIdxBits = 17;             // candidate index / row slot < 2^17 (1280x1280 tiles: 100,800)
-constexpr int kFastLds = kFast * 8 + kFast * 16 + kFast * 4 + kFast * 2;   // keys + boxes + slots + kept ranks = 60 KiB
-constexpr int kMaskLds = 64 * 1024;      // LDS kept for the suppression bit matrix (n <= ~700 candidates)
+constexpr int nms_fast_lds(int kf) { return kf * 8 + kf * 16 + kf * 4 + kf * 2; }   // keys + boxes + slots + kept ranks = 60 KiB at 2048
+constexpr int nms_mask_lds(int kf) { return kf == kFast ? 64 * 1024 : 32 * 1024; }  // LDS kept for the suppression bit matrix (n <= ~700 / ~500 candidates)
 constexpr int kSlowLds = kSortLds * 8 + kMaxNms + 16;
-constexpr int kNmsLds = kFastLds + kMaskLds > kSlowLds ? kFastLds + kMaskLds : kSlowLds;
+constexpr int nms_lds(int kf) { return nms_fast_lds(kf) + nms_mask_lds(kf) > kSlowLds ? nms_fast_lds(kf) + nms_mask_lds(kf) : kSlowLds; }
+static_assert(nms_lds(kFastBig) <= 160 * 1024, "LDS");
 
 // conf = obj * cls_conf, best class = first maximum; box = xywh2xyxy (x -/+ w/2)
 __device__ __forceinline__ bool candidate_row(const float* row, int nc, float thr, float4& box, float& conf, int& cls) {
@@ -212,7 +218,9 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
     return ((unsigned long long)hi << 32) | lo;
 }
 
+template <int KF>
 __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
+    constexpr int kFast = KF, kFastWords = KF / 64, kFastLds = nms_fast_lds(KF), kMaskLds = nms_mask_lds(KF);
     __shared__ int s_n;
     // one dynamic LDS block, two uses: fast path = unsorted keys [kFast] + sorted offset boxes [kFast] + slots + kept
     //                                  list + (when it fits) the suppression bit matrix;
@@ -445,7 +453,7 @@ extern "C" int aq_detect_decode(const float* const head_dev[3], int head_ld, int
 extern "C" size_t aq_nms_scratch_bytes(int B, int N) {
     if (B <= 0 || N <= 0) return 0;
     return align_up((size_t)B * next_pow2(N) * sizeof(unsigned long long), 256) + align_up((size_t)B * N * sizeof(float4), 256) +
-           align_up((size_t)B * kFast * kFastWords * sizeof(unsigned long long), 256);
+           align_up((size_t)B * nms_fast(N) * (nms_fast(N) / 64) * sizeof(unsigned long long), 256);
 }
 
 extern "C" int aq_nms(const float* rows_dev, int rows_per_tile, int B, int N, int nc, float conf_thres, float iou_thres,
@@ -474,12 +482,15 @@ extern "C" int aq_nms(const float* rows_dev, int rows_per_tile, int B, int N, in
         unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
         p.dbg = (sbuf && (size_t)B * 64 <= sbytes) ? sbuf : nullptr;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        AQ_CHECK_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kNmsLds));
-        attr_set = true;
+    static bool attr_set[2] = {false, false};
+    const bool big = nms_fast(N) == kFastBig;
+    auto fn = big ? nms_kernel<kFastBig> : nms_kernel<kFast>;
+    const int lds = nms_lds(big ? kFastBig : kFast);
+    if (!attr_set[big]) {
+        AQ_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set[big] = true;
     }
-    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(kNmsThreads), kNmsLds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(fn, dim3(B), dim3(kNmsThreads), lds, (hipStream_t)stream, p);
     AQ_CHECK_HIP(hipGetLastError());
     return AQ_OK;
 }

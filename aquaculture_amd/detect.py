@@ -136,7 +136,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     labels_dir = str(save_dir / "labels")
     # done-manifest: every rank records the tiles it has finished (fsync'd per batch); --resume skips what ANY rank of the
     # interrupted run recorded (reference idiom: skip-if-exists, src/load_data/tile_tifs.py:40-41 -- which label files cannot express)
-    from .manifest import DoneManifest, check_run_params, file_digest, fsync_dir
+    from .manifest import DoneManifest, check_run_params, file_digest, fsync_dir, sync_filesystem_of
     durable = not tile_scenes and os.environ.get("AQ_NO_FSYNC") != "1"     # (AQ_NO_FSYNC=1: only process kills are covered, as before round 3)
     if rank == 0 and not tile_scenes:
         # what the label bytes depend on; --resume refuses to continue a directory written with anything else
@@ -209,13 +209,19 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                         with gather_lock:
                             gather.add(torch.full((det.shape[0],), gidx[b], dtype=torch.int32), aqdist.pack_rows(torch.from_numpy(det.copy())))
                 slot_free[slot_id].release()
-                for f in written:                        # the manifest line below vouches for these bytes: on disk first, then their
-                    if durable:                          # directory entries, then the record (a node crash must not leave a recorded
-                        os.fsync(f.fileno())             # tile without its label file -- it would look like "no detections" for good)
+                # the manifest line below vouches for these bytes: on disk first (files and their directory entries), then the record -- a
+                # node crash must not leave a recorded tile without its label file (it would look like "no detections" for good).
+                # One syncfs per batch; per-file fsync + directory fsync where that is unavailable.
+                fds = [f.fileno() for f in written]
+                for f in written:
+                    f.flush()
+                if durable and written and not sync_filesystem_of(labels_dir):
+                    for fd in fds:
+                        os.fsync(fd)
+                    fsync_dir(labels_dir)
+                for f in written:
                     f.close()
                 if not tile_scenes:
-                    if durable and written:
-                        fsync_dir(labels_dir)
                     with manifest_lock:
                         manifest.add(Path(p).stem for p in paths)
                 with lock:

@@ -9,8 +9,9 @@ drops those tiles from the listing before sharding.  A record is one line = one 
 newline) is ignored, so a tile is either recorded after its label file is complete or processed again (label files are written with
 "wb": processing a tile twice leaves the same bytes).
 
-Durability: the manifest line vouches for the label file, so the file must reach the disk first -- detect.py fsyncs every label file of
-a batch and then the labels directory (the new directory entries) before `add`, which fsyncs the manifest; a node crash or power loss
+Durability: the manifest line vouches for the label file, so the file must reach the disk first -- detect.py makes every label file of
+a batch and the labels directory's new entries durable (one syncfs(2) of that filesystem per batch; per-file fsync + directory fsync where
+syncfs is unavailable) before `add`, which fsyncs the manifest; a node crash or power loss
 can therefore lose unrecorded work but never leave a recorded tile without its label bytes.  `run_params.json` beside the manifests
 holds what the labels depend on (weights digest, thresholds, image size, precision); `--resume` refuses a directory written with
 other settings instead of mixing two runs' labels.
@@ -31,6 +32,27 @@ def fsync_dir(path: str) -> None:
         os.fsync(fd)
     finally:
         os.close(fd)
+
+
+_libc = None
+
+
+def sync_filesystem_of(path: str) -> bool:
+    """syncfs(2) on the filesystem holding `path`: every dirty page and directory entry of that filesystem reaches the disk -- ONE call
+    makes a whole batch of freshly written label files durable (64 fsyncs, one journal commit each, cost a multiple of the sweep's own
+    time on a real disk).  False when the call is unavailable: the caller falls back to per-file fsync."""
+    global _libc
+    try:
+        if _libc is None:
+            import ctypes
+            _libc = ctypes.CDLL("libc.so.6", use_errno=True)
+        fd = os.open(path, os.O_RDONLY)
+        try:
+            return _libc.syncfs(fd) == 0
+        finally:
+            os.close(fd)
+    except (OSError, AttributeError):
+        return False
 
 
 def file_digest(path: str) -> str:

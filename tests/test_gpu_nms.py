@@ -119,3 +119,18 @@ def test_engine_decode_plus_nms_equals_nms_on_raw_pred(lib, synth_ck, monkeypatc
     assert torch.equal(c0, c1)
     for b in range(2):
         assert torch.equal(d0[b, :c0[b]], d1[b, :c1[b]])
+
+
+@pytest.mark.parametrize("n_cand", [1500, 2049, 3500, 4096, 4097, 6000])
+def test_large_tiles_take_the_4096_candidate_bit_matrix(lib, n_cand):
+    """1280-px tiles (100,800 rows; BASELINE.json configs[4]) are launched on nms_kernel<4096> (round 3): candidate counts on both sides
+    of the old 2,048 and the new 4,096 limit (beyond it: the bitonic path), all bit for bit the oracle's."""
+    rng = np.random.default_rng(n_cand)
+    N = 100800
+    p = _random_pred(rng, N, spread=1240.0)
+    p[..., 4] = 0.1                                           # nothing passes ...
+    idx = rng.choice(N, n_cand, replace=False)
+    p[0, idx, 4] = rng.uniform(0.5, 1.0, n_cand)              # ... but n_cand rows
+    p[0, idx, 5:] = rng.uniform(0.6, 1.0, (n_cand, NC))
+    r = _run(p, max_det=1000)[0]
+    assert r.shape[0] > 100
