@@ -15,6 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libaqengine.so")
+JPEG_LIB = os.path.join(CSRC, "libaqjpeg.so")    # host half of the split JPEG decode: plain C (gcc), no HIP -- the decode worker processes load it
 ARCH = "gfx950"
 
 SOURCES = [
@@ -29,6 +30,7 @@ SOURCES = [
     ("pointwise.hip", []),
     ("detect_nms.hip", ["-ffp-contract=off"]),   # bit-level parity with the oracle's fp32 op order
     ("head_decode.hip", ["-ffp-contract=off"]),  # the same decode arithmetic, fused behind the Detect head convs
+    ("jpeg_idct.hip", []),                       # device half of the split JPEG decode (IDCT, chroma upsampling, colour conversion)
     ("engine.cpp", ["-x", "hip"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
@@ -44,7 +46,7 @@ def hipcc() -> str:
 def _digest() -> str:
     h = hashlib.sha256()
     for name in sorted(os.listdir(CSRC)):
-        if name.endswith((".hip", ".cpp", ".h", "_asm.py")):
+        if name.endswith((".hip", ".cpp", ".c", ".h", "_asm.py")):
             h.update(name.encode())
             h.update(open(os.path.join(CSRC, name), "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "aq_engine.h"), "rb").read())
@@ -89,10 +91,22 @@ def _assemble_planar(verbose: bool, cc: str) -> None:
     os.replace(inc + ".tmp", inc)
 
 
+def build_jpeg_lib() -> str:
+    """libaqjpeg.so: csrc/jpeg_coef.c with the host C compiler (no GPU toolchain involved)."""
+    cc = shutil.which("gcc") or shutil.which("cc") or shutil.which("clang")
+    if not cc:
+        raise RuntimeError("no C compiler for libaqjpeg.so")
+    r = subprocess.run([cc, "-O2", "-shared", "-fPIC", "-Wall", "-o", JPEG_LIB + ".tmp", os.path.join(CSRC, "jpeg_coef.c")], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"{cc} failed on jpeg_coef.c:\n{r.stdout}\n{r.stderr}")
+    os.replace(JPEG_LIB + ".tmp", JPEG_LIB)
+    return JPEG_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     stamp = LIB + ".sha256"
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+    if not force and os.path.exists(LIB) and os.path.exists(JPEG_LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return LIB
     # ranks (or test workers) that find a stale library at the same time: one builds, the others wait for the lock and find it fresh
     import fcntl
@@ -128,6 +142,7 @@ def _build_locked(dig: str, stamp: str, verbose: bool) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     os.replace(LIB + ".tmp", LIB)              # a process that has the old library mapped keeps its inode
+    build_jpeg_lib()
     with open(stamp + ".tmp", "w") as f:
         f.write(dig)
     os.replace(stamp + ".tmp", stamp)

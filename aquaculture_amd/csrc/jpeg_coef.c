@@ -1,0 +1,304 @@
+/* Host half of the split JPEG decode: entropy decoding only.
+ *
+ * The tiles the detector sweeps are baseline JPEGs written by GDAL's JPEG driver (reference src/load_data/tile_tifs.py:66-74: 8-bit,
+ * 3 bands, YCbCr, 4:2:0, Huffman) and [UPSTREAM detect.py LoadImages -> cv2.imread] decodes them with libjpeg(-turbo) on one host
+ * thread.  A full libjpeg decode of a 640-px tile costs ~2-3 ms of a core, most of it in the inverse DCT, the chroma upsampling and the
+ * colour conversion -- dense integer arithmetic that belongs on the GPU (csrc/jpeg_idct.hip restates libjpeg's ISLOW IDCT, fancy
+ * h2v2 upsampling and YCbCr -> RGB bit for bit).  What cannot go there cheaply is the serial Huffman bit stream: this file decodes it into
+ * quantised DCT coefficient blocks and nothing else.
+ *
+ * Plain C, no libjpeg (its headers are not in the image), no HIP: built by aquaculture_amd/build.py into libaqjpeg.so with gcc and loaded
+ * by the decode worker PROCESSES through ctypes (they never touch the GPU).
+ *
+ * Supported: baseline sequential DCT (SOF0) or extended sequential with 8-bit samples (SOF1), Huffman coding, 3 components YCbCr with
+ * sampling 2x2 / 1x1 / 1x1 (4:2:0) or 1 component (greyscale), restart intervals, one interleaved scan.  Everything else (progressive,
+ * arithmetic, 4:2:2, 4:4:4, CMYK, 12-bit) returns AQJ_UNSUPPORTED and the caller falls back to the full software decode.
+ *
+ * Output layout (int16, quantised coefficients in NATURAL (row-major, de-zigzagged) order, 64 per block):
+ *   Y  blocks [by = 0 .. Hb-1][bx = 0 .. Wb-1], Hb = 2 * mcu_rows, Wb = 2 * mcu_cols (4:2:0) -- i.e. the padded image in 8x8 blocks
+ *   Cb blocks [mcu_rows][mcu_cols], then Cr blocks [mcu_rows][mcu_cols]
+ * plus the three quantisation tables (uint16 [3][64], natural order) -- the GPU multiplies.
+ */
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#define AQJ_OK 0
+#define AQJ_UNSUPPORTED (-1)
+#define AQJ_CORRUPT (-2)
+#define AQJ_SPACE (-3)
+
+typedef struct aq_jpeg_info {
+    int32_t width, height;        /* image size in pixels */
+    int32_t ncomp;                /* 1 or 3 */
+    int32_t mcu_cols, mcu_rows;   /* 16x16 MCUs (3 components) or 8x8 (greyscale) */
+    int32_t y_blocks_w, y_blocks_h;
+    int32_t total_blocks;         /* blocks written to coef_out */
+    uint16_t qt[3][64];           /* quantisation table of each component, natural order */
+} aq_jpeg_info;
+
+static const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+#define LOOK 9
+typedef struct {
+    uint16_t look[1 << LOOK];     /* (length << 8) | symbol for codes of <= LOOK bits, 0 = longer */
+    int32_t maxcode[18];          /* largest code of each length (-1: none), [17] = sentinel */
+    int32_t valoff[17];           /* huffval index of the first code of a length minus that code */
+    uint8_t vals[256];
+    int present;
+} HuffTab;
+
+typedef struct {
+    const uint8_t* p;
+    const uint8_t* end;
+    uint64_t acc;                 /* bit accumulator, MSB first in the low `nbits` bits */
+    int nbits;
+    int marker;                   /* a marker was met: only zero bits follow */
+} Bits;
+
+static void fill(Bits* b) {
+    while (b->nbits <= 56) {
+        unsigned c = 0;
+        if (!b->marker && b->p < b->end) {
+            c = *b->p;
+            if (c == 0xFF) {
+                if (b->p + 1 < b->end && b->p[1] == 0x00) {
+                    b->p += 2;                                  /* stuffed zero */
+                } else {
+                    b->marker = 1;                              /* a real marker (RSTn, EOI): leave it for the caller */
+                    c = 0;
+                }
+            } else {
+                b->p += 1;
+            }
+        } else if (!b->marker) {
+            b->marker = 1;
+        }
+        b->acc = (b->acc << 8) | c;
+        b->nbits += 8;
+    }
+}
+
+static inline unsigned peek(Bits* b, int n) { return (unsigned)((b->acc >> (b->nbits - n)) & ((1u << n) - 1u)); }
+static inline void skip(Bits* b, int n) { b->nbits -= n; }
+
+static int build(HuffTab* t, const uint8_t* counts, const uint8_t* vals, int nvals) {
+    int code = 0, k = 0;
+    memset(t->look, 0, sizeof t->look);
+    memcpy(t->vals, vals, (size_t)nvals);
+    for (int len = 1; len <= 16; ++len) {
+        t->valoff[len] = k - code;
+        for (int i = 0; i < counts[len - 1]; ++i, ++k, ++code) {
+            if (k >= nvals) return AQJ_CORRUPT;
+            if (len <= LOOK) {
+                const int first = code << (LOOK - len), n = 1 << (LOOK - len);
+                for (int j = 0; j < n; ++j) t->look[first + j] = (uint16_t)((len << 8) | vals[k]);
+            }
+        }
+        t->maxcode[len] = counts[len - 1] ? code - 1 : -1;
+        if (code > (1 << len)) return AQJ_CORRUPT;
+        code <<= 1;
+    }
+    t->maxcode[17] = 0x7fffffff;
+    t->present = 1;
+    return AQJ_OK;
+}
+
+static inline int decode_sym(Bits* b, const HuffTab* t) {
+    if (b->nbits < 16) fill(b);
+    const unsigned e = t->look[peek(b, LOOK)];
+    if (e) {
+        skip(b, (int)(e >> 8));
+        return (int)(e & 0xff);
+    }
+    int len = LOOK + 1;
+    int code = (int)peek(b, len);
+    while (len <= 16 && code > t->maxcode[len]) {
+        ++len;
+        code = (int)peek(b, len);
+    }
+    if (len > 16) return -1;
+    skip(b, len);
+    return t->vals[(code + t->valoff[len]) & 0xff];
+}
+
+static inline int receive_extend(Bits* b, int s) {
+    if (b->nbits < s) fill(b);
+    const int v = (int)peek(b, s);
+    skip(b, s);
+    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+}
+
+static int decode_block(Bits* b, const HuffTab* dc, const HuffTab* ac, int* pred, int16_t* out) {
+    memset(out, 0, 64 * sizeof(int16_t));
+    if (b->nbits < 32) fill(b);
+    int s = decode_sym(b, dc);
+    if (s < 0 || s > 11) return AQJ_CORRUPT;
+    if (s) *pred += receive_extend(b, s);
+    out[0] = (int16_t)*pred;
+    for (int k = 1; k < 64;) {
+        if (b->nbits < 32) fill(b);
+        const int rs = decode_sym(b, ac);
+        if (rs < 0) return AQJ_CORRUPT;
+        const int r = rs >> 4;
+        s = rs & 15;
+        if (s) {
+            k += r;
+            if (k > 63) return AQJ_CORRUPT;
+            out[kZigzag[k]] = (int16_t)receive_extend(b, s);
+            ++k;
+        } else {
+            if (r != 15) break;            /* EOB */
+            k += 16;                       /* ZRL */
+        }
+    }
+    return AQJ_OK;
+}
+
+static inline unsigned be16(const uint8_t* p) { return ((unsigned)p[0] << 8) | p[1]; }
+
+/* Decodes the entropy-coded data of one JPEG file into coef_out (capacity `cap` int16 values).  Returns AQJ_OK or a negative code;
+ * info is filled as far as the headers were read. */
+int aq_jpeg_decode_coeffs(const uint8_t* data, size_t n, int16_t* coef_out, size_t cap, aq_jpeg_info* info) {
+    if (!data || !info || n < 4 || data[0] != 0xFF || data[1] != 0xD8) return AQJ_CORRUPT;
+    memset(info, 0, sizeof *info);
+    uint16_t qt[4][64];
+    int qt_present[4] = {0, 0, 0, 0};
+    HuffTab hdc[4], hac[4];
+    for (int i = 0; i < 4; ++i) hdc[i].present = hac[i].present = 0;
+    int comp_id[3] = {0, 0, 0}, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0};
+    int restart = 0, have_sof = 0;
+    size_t pos = 2;
+    while (pos + 4 <= n) {
+        if (data[pos] != 0xFF) return AQJ_CORRUPT;
+        const unsigned m = data[pos + 1];
+        if (m == 0xFF) { ++pos; continue; }                     /* fill byte */
+        pos += 2;
+        if (m == 0xD9) return AQJ_CORRUPT;                      /* EOI before any scan */
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;    /* standalone markers */
+        if (pos + 2 > n) return AQJ_CORRUPT;
+        const unsigned len = be16(data + pos);
+        if (len < 2 || pos + len > n) return AQJ_CORRUPT;
+        const uint8_t* seg = data + pos + 2;
+        const unsigned sl = len - 2;
+        if (m == 0xDB) {                                        /* DQT */
+            unsigned o = 0;
+            while (o < sl) {
+                const int pq = seg[o] >> 4, tq = seg[o] & 15;
+                if (tq > 3 || pq > 1) return AQJ_CORRUPT;
+                ++o;
+                if (o + (pq ? 128u : 64u) > sl) return AQJ_CORRUPT;
+                for (int k = 0; k < 64; ++k) {
+                    qt[tq][kZigzag[k]] = (uint16_t)(pq ? be16(seg + o + 2 * k) : seg[o + k]);
+                }
+                o += pq ? 128 : 64;
+                qt_present[tq] = 1;
+            }
+        } else if (m == 0xC4) {                                 /* DHT */
+            unsigned o = 0;
+            while (o + 17 <= sl) {
+                const int tc = seg[o] >> 4, th = seg[o] & 15;
+                if (tc > 1 || th > 3) return AQJ_CORRUPT;
+                int cnt = 0;
+                for (int k = 0; k < 16; ++k) cnt += seg[o + 1 + k];
+                if (cnt > 256 || o + 17 + (unsigned)cnt > sl) return AQJ_CORRUPT;
+                const int rc = build(tc ? &hac[th] : &hdc[th], seg + o + 1, seg + o + 17, cnt);
+                if (rc) return rc;
+                o += 17 + (unsigned)cnt;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {                    /* SOF0 / SOF1: sequential, Huffman */
+            if (sl < 6 || seg[0] != 8) return AQJ_UNSUPPORTED;
+            info->height = (int32_t)be16(seg + 1);
+            info->width = (int32_t)be16(seg + 3);
+            info->ncomp = seg[5];
+            if ((info->ncomp != 1 && info->ncomp != 3) || sl < 6u + 3u * (unsigned)info->ncomp || info->width <= 0 || info->height <= 0)
+                return AQJ_UNSUPPORTED;
+            for (int c = 0; c < info->ncomp; ++c) {
+                comp_id[c] = seg[6 + 3 * c];
+                comp_h[c] = seg[7 + 3 * c] >> 4;
+                comp_v[c] = seg[7 + 3 * c] & 15;
+                comp_q[c] = seg[8 + 3 * c];
+                if (comp_q[c] > 3) return AQJ_CORRUPT;
+            }
+            if (info->ncomp == 3 && !(comp_h[0] == 2 && comp_v[0] == 2 && comp_h[1] == 1 && comp_v[1] == 1 && comp_h[2] == 1 && comp_v[2] == 1))
+                return AQJ_UNSUPPORTED;                          /* only 4:2:0 */
+            if (info->ncomp == 1) comp_h[0] = comp_v[0] = 1;     /* a single component is never interleaved */
+            have_sof = 1;
+        } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            return AQJ_UNSUPPORTED;                              /* progressive, lossless, arithmetic */
+        } else if (m == 0xDD) {                                  /* DRI */
+            if (sl < 2) return AQJ_CORRUPT;
+            restart = (int)be16(seg);
+        } else if (m == 0xDA) {                                  /* SOS: the one scan */
+            if (!have_sof || sl < 1 || seg[0] != info->ncomp || sl < 1u + 2u * (unsigned)info->ncomp + 3u) return AQJ_UNSUPPORTED;
+            int tdc[3], tac[3];
+            for (int c = 0; c < info->ncomp; ++c) {
+                if (seg[1 + 2 * c] != comp_id[c]) return AQJ_UNSUPPORTED;
+                tdc[c] = seg[2 + 2 * c] >> 4;
+                tac[c] = seg[2 + 2 * c] & 15;
+                if (tdc[c] > 3 || tac[c] > 3 || !hdc[tdc[c]].present || !hac[tac[c]].present || !qt_present[comp_q[c]]) return AQJ_CORRUPT;
+                memcpy(info->qt[c], qt[comp_q[c]], sizeof info->qt[c]);
+            }
+            const int mcu_px = info->ncomp == 3 ? 16 : 8;
+            info->mcu_cols = (info->width + mcu_px - 1) / mcu_px;
+            info->mcu_rows = (info->height + mcu_px - 1) / mcu_px;
+            const int yb = info->ncomp == 3 ? 2 : 1;
+            info->y_blocks_w = info->mcu_cols * yb;
+            info->y_blocks_h = info->mcu_rows * yb;
+            const size_t ny = (size_t)info->y_blocks_w * info->y_blocks_h, nc = (size_t)info->mcu_cols * info->mcu_rows;
+            const size_t total = ny + (info->ncomp == 3 ? 2 * nc : 0);
+            info->total_blocks = (int32_t)total;
+            if (!coef_out || total * 64 > cap) return AQJ_SPACE;
+            Bits b;
+            b.p = data + pos + len; b.end = data + n; b.acc = 0; b.nbits = 0; b.marker = 0;
+            int pred[3] = {0, 0, 0};
+            int left = restart, next_rst = 0;
+            int16_t* cb = coef_out + ny * 64;
+            int16_t* cr = cb + nc * 64;
+            for (int my = 0; my < info->mcu_rows; ++my)
+                for (int mx = 0; mx < info->mcu_cols; ++mx) {
+                    if (restart && left == 0) {                 /* expect RSTn: byte align, skip the marker, reset the predictors */
+                        b.nbits = 0; b.acc = 0;
+                        const uint8_t* q = b.p;
+                        while (q + 1 < b.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) {
+                            if (q[0] == 0xFF && q[1] != 0x00 && q[1] != 0xFF) return AQJ_CORRUPT;
+                            ++q;
+                        }
+                        if (q + 1 >= b.end || q[1] != (uint8_t)(0xD0 + next_rst)) return AQJ_CORRUPT;
+                        b.p = q + 2; b.marker = 0;
+                        next_rst = (next_rst + 1) & 7;
+                        pred[0] = pred[1] = pred[2] = 0;
+                        left = restart;
+                    }
+                    int rc;
+                    if (info->ncomp == 3) {
+                        for (int v = 0; v < 2; ++v)
+                            for (int h = 0; h < 2; ++h) {
+                                rc = decode_block(&b, &hdc[tdc[0]], &hac[tac[0]], &pred[0],
+                                                  coef_out + ((size_t)(2 * my + v) * info->y_blocks_w + (2 * mx + h)) * 64);
+                                if (rc) return rc;
+                            }
+                        rc = decode_block(&b, &hdc[tdc[1]], &hac[tac[1]], &pred[1], cb + ((size_t)my * info->mcu_cols + mx) * 64);
+                        if (rc) return rc;
+                        rc = decode_block(&b, &hdc[tdc[2]], &hac[tac[2]], &pred[2], cr + ((size_t)my * info->mcu_cols + mx) * 64);
+                        if (rc) return rc;
+                    } else {
+                        rc = decode_block(&b, &hdc[tdc[0]], &hac[tac[0]], &pred[0], coef_out + ((size_t)my * info->y_blocks_w + mx) * 64);
+                        if (rc) return rc;
+                    }
+                    if (restart) --left;
+                }
+            return AQJ_OK;
+        }
+        pos += len;
+    }
+    return AQJ_CORRUPT;
+}
+
+/* Size query / header scan without decoding: fills info (total_blocks included) and returns AQJ_SPACE-free status. */
+int aq_jpeg_scan(const uint8_t* data, size_t n, aq_jpeg_info* info) {
+    const int rc = aq_jpeg_decode_coeffs(data, n, NULL, 0, info);
+    return rc == AQJ_SPACE ? AQJ_OK : rc;
+}

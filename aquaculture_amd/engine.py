@@ -69,7 +69,7 @@ EXPORTS = (
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
     "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_pack_conv_weights_x3", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_stemdown_supported", "aq_stemdown", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
     "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct",
-    "aq_conv3x3_pl_supported", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_s2_supported", "aq_pack_conv3x3_pl_s2", "aq_conv3x3_pl_s2", "aq_f32_to_e4m3", "aq_conv1x1_direct_f8out", "aq_absmax_bf16", "aq_engine_calibrate_amax", "aq_engine_set_fp8_scales", "aq_conv3x3_pl_f8_supported", "aq_pack_conv3x3_pl_f8", "aq_conv3x3_pl_f8", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
+    "aq_conv3x3_pl_supported", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_s2_supported", "aq_pack_conv3x3_pl_s2", "aq_conv3x3_pl_s2", "aq_jpeg_scratch_bytes", "aq_jpeg_idct_rgb", "aq_f32_to_e4m3", "aq_conv1x1_direct_f8out", "aq_absmax_bf16", "aq_engine_calibrate_amax", "aq_engine_set_fp8_scales", "aq_conv3x3_pl_f8_supported", "aq_pack_conv3x3_pl_f8", "aq_conv3x3_pl_f8", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_letterbox_tiles_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
 
@@ -130,6 +130,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_conv3x3_pl_w8.argtypes = lib.aq_conv3x3_pl.argtypes
     lib.aq_pack_conv3x3_pl_w8.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), i32, i32, vp, C.POINTER(C.c_size_t), vp, vp]
     lib.aq_conv3x3_pl_w8_supported.argtypes = [i32] * 5
+    lib.aq_jpeg_scratch_bytes.argtypes = [i32, i32, i32]
+    lib.aq_jpeg_scratch_bytes.restype = sz
+    lib.aq_jpeg_idct_rgb.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
     lib.aq_f32_to_e4m3.argtypes = [f32]
     lib.aq_f32_to_e4m3.restype = C.c_ubyte
     lib.aq_conv3x3_pl_f8_supported.argtypes = [i32] * 5
@@ -809,6 +812,23 @@ def conv3x3_pl_f8_nhwc(xq: torch.Tensor, act_scale: float, w_oihw: torch.Tensor,
                                 residual.data_ptr() if residual is not None else None, residual.stride(2) if residual is not None else 0, 0,
                                 wbuf.data_ptr(), sb.data_ptr(), B, H, W, int(act), _stream_ptr()))
     torch.cuda.current_stream().synchronize()
+    return out
+
+
+def jpeg_idct_rgb(coef: torch.Tensor, coef_off: torch.Tensor, qt: torch.Tensor, H: int, W: int, out: Optional[torch.Tensor] = None,
+                  scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The device half of the split JPEG decode (aq_jpeg_idct_rgb): coef int16 CUDA (the images' coefficient blocks), coef_off int64 [B]
+    (first value of each image, multiples of 64), qt uint16 [B,3,64]  ->  uint8 RGB [B,H,W,3], the pixels libjpeg(-turbo) produces."""
+    _require_gpu()
+    lib = load_library()
+    B = int(coef_off.shape[0])
+    assert coef.is_cuda and coef.dtype == torch.int16 and coef_off.dtype == torch.int64 and qt.dtype in (torch.uint16, torch.int16) and qt.numel() == B * 192
+    if out is None:
+        out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=coef.device)
+    n = lib.aq_jpeg_scratch_bytes(B, H, W)
+    if scratch is None or scratch.numel() < n:
+        scratch = torch.empty(n, dtype=torch.uint8, device=coef.device)
+    _check(lib.aq_jpeg_idct_rgb(coef.data_ptr(), coef_off.data_ptr(), qt.data_ptr(), B, H, W, scratch.data_ptr(), out.data_ptr(), _stream_ptr()))
     return out
 
 

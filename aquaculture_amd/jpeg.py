@@ -1,0 +1,59 @@
+"""Split JPEG decode: entropy decoding on the host (libaqjpeg.so, csrc/jpeg_coef.c), everything after it on the GPU (aq_jpeg_idct_rgb).
+
+[UPSTREAM utils/dataloaders.py LoadImages.__next__ -> cv2.imread] spends most of a host core's 2-3 ms per 640-px tile in the inverse DCT,
+the chroma upsampling and the colour conversion; the tiles of reference src/load_data/tile_tifs.py:66-74 are baseline 4:2:0 JPEGs, for
+which those stages are restated bit for bit on the device (csrc/jpeg_idct.hip).  This module is the host side: it imports neither torch
+nor the HIP library, so the decode worker processes can use it (aquaculture_amd/_decode_worker.py, mode "coef").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+AQJ_OK, AQJ_UNSUPPORTED, AQJ_CORRUPT, AQJ_SPACE = 0, -1, -2, -3
+_LIB = None
+
+
+class JpegInfo(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("ncomp", C.c_int32), ("mcu_cols", C.c_int32), ("mcu_rows", C.c_int32),
+                ("y_blocks_w", C.c_int32), ("y_blocks_h", C.c_int32), ("total_blocks", C.c_int32), ("qt", (C.c_uint16 * 64) * 3)]
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaqjpeg.so")
+
+
+def load_lib():
+    global _LIB
+    if _LIB is None:
+        lib = C.CDLL(lib_path())
+        lib.aq_jpeg_decode_coeffs.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(JpegInfo)]
+        lib.aq_jpeg_scan.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(JpegInfo)]
+        _LIB = lib
+    return _LIB
+
+
+def coef_count(H: int, W: int) -> int:
+    """int16 values of one image's coefficient blocks (4:2:0): 1.5 x the padded pixel count."""
+    return ((H + 15) // 16 * 16) * ((W + 15) // 16 * 16) * 3 // 2
+
+
+def scan(data: bytes) -> Optional[JpegInfo]:
+    """Headers of a baseline 4:2:0 JPEG, or None when the split decoder does not cover the file (the caller decodes it in software)."""
+    info = JpegInfo()
+    return info if load_lib().aq_jpeg_scan(data, len(data), C.byref(info)) == AQJ_OK and info.ncomp == 3 else None
+
+
+def decode_coeffs(data: bytes, coef_out: np.ndarray, qt_out: np.ndarray) -> Tuple[int, JpegInfo]:
+    """Entropy-decode `data` into coef_out (int16, C-contiguous, >= coef_count values) and its three quantisation tables into qt_out
+    (uint16 [3][64]).  Returns (status, info)."""
+    info = JpegInfo()
+    rc = load_lib().aq_jpeg_decode_coeffs(data, len(data), coef_out.ctypes.data, coef_out.size, C.byref(info))
+    if rc == AQJ_OK:
+        if info.ncomp != 3:
+            return AQJ_UNSUPPORTED, info
+        qt_out[...] = np.ctypeslib.as_array(info.qt).reshape(3, 64)
+    return rc, info

@@ -285,6 +285,14 @@ int aq_letterbox_u8(const uint8_t* src_dev, int B, int H0, int W0, uint8_t* dst_
 int aq_letterbox_tiles_u8(const uint8_t* scene_dev, long long scene_bytes, long long row_bytes, const long long* tile_off_dev,
                           const long long* tile_off_host, int B, int H0, int W0, uint8_t* dst_dev, int H, int W, int new_w, int new_h,
                           int top, int left, const int32_t* xtab_dev, const int32_t* ytab_dev, void* stream);
+/* Split JPEG decode (round 3): the pixel half of what [UPSTREAM detect.py LoadImages -> cv2.imread] gets from
+ * libjpeg(-turbo) -- dequantisation, the islow IDCT, h2v2 fancy chroma upsampling, YCbCr -> RGB -- bit for bit, on the device.  Input: the
+ * quantised coefficient blocks of B baseline 4:2:0 JPEGs of one size as written by aq_jpeg_decode_coeffs (libaqjpeg.so, include/aq_jpeg.h:
+ * the entropy decoder, which stays on the host), image b from coef_off_dev[b] (int16 units, a multiple of 64), qt_dev uint16 [B][3][64].
+ * Output: uint8 RGB [B][H][W][3].  scratch_dev: aq_jpeg_scratch_bytes(B, H, W) bytes. */
+size_t aq_jpeg_scratch_bytes(int B, int H, int W);
+int aq_jpeg_idct_rgb(const int16_t* coef_dev, const long long* coef_off_dev, const uint16_t* qt_dev, int B, int H, int W,
+                     void* scratch_dev, uint8_t* out_dev, void* stream);
 /* SPPF pools: y1 = mp5(x), y2 = mp5(y1), y3 = mp5(y2) written to channel slices c, 2c, 3c of the same buffer. */
 int aq_sppf_pool(void* buf_dev, int ld, int ch_off, int c, int B, int H, int W, int precision, void* stream);
 /* nearest 2x upsample of a channel slice into a channel slice. */

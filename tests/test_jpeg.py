@@ -1,0 +1,118 @@
+"""Split JPEG decode: the host entropy decoder (libaqjpeg.so) + the oracle's pixel half against Pillow's
+libjpeg-turbo on the CPU -- which PINS the oracle to the library [UPSTREAM cv2.imread] uses -- and the HIP pixel half against both on the
+GPU.  Byte for byte everywhere."""
+import io
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _jpeg(img, **kw):
+    bio = io.BytesIO()
+    Image.fromarray(img).save(bio, format="JPEG", **kw)
+    return bio.getvalue()
+
+
+def _pil(data):
+    return np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+
+
+def _cases():
+    from aquaculture_amd import tiles
+    rng = np.random.default_rng(5)
+    noise = lambda h, w: rng.integers(0, 255, (h, w, 3), dtype=np.uint8)
+    smooth = lambda h, w: np.clip(np.add.outer(np.arange(h) * 0.7, np.arange(w) * 0.4)[..., None] + rng.normal(0, 6, (h, w, 3)) + [20, 70, 110], 0, 255).astype(np.uint8)
+    return [
+        ("ocean tile 640, q75 (the GDAL default of reference tile_tifs.py:74)", _jpeg(tiles.synthetic_tile(3, 640), quality=75)),
+        ("cage tile 640", _jpeg(tiles.synthetic_tile(19, 640), quality=75)),
+        ("noise 128x192 q90", _jpeg(noise(128, 192), quality=90)),
+        ("noise 100x150 q50 (ragged: partial MCUs on both edges)", _jpeg(noise(100, 150), quality=50)),
+        ("noise 33x17 q80", _jpeg(noise(33, 17), quality=80)),
+        ("smooth 641x1023", _jpeg(smooth(641, 1023), quality=75)),
+        ("restart markers every 3 MCUs", _jpeg(noise(64, 64), quality=75, restart_marker_blocks=3)),
+        ("restart markers every row", _jpeg(smooth(96, 160), quality=85, restart_marker_rows=1)),
+        ("optimised Huffman tables, q95", _jpeg(noise(48, 80), quality=95, optimize=True)),
+        ("one MCU, q10", _jpeg(noise(16, 16), quality=10)),
+        ("saturated colours (range limit in every stage)", _jpeg(np.tile(np.array([[[255, 0, 0], [0, 255, 0]], [[0, 0, 255], [255, 255, 255]]], np.uint8).repeat(8, 0).repeat(8, 1), (4, 4, 1)), quality=100)),
+    ]
+
+
+@pytest.fixture(scope="module")
+def jpeg_lib():
+    from aquaculture_amd import build, jpeg
+    build.build()
+    return jpeg
+
+
+def test_libaqjpeg_exports_what_its_header_declares(jpeg_lib):
+    import re
+    hdr = open(os.path.join(ROOT, "include", "aq_jpeg.h")).read()
+    names = set(re.findall(r"\b(aq_jpeg_\w+)\s*\(", hdr))
+    assert names == {"aq_jpeg_decode_coeffs", "aq_jpeg_scan"}
+    lib = jpeg_lib.load_lib()
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+@pytest.mark.parametrize("idx", range(11))
+def test_entropy_decoder_plus_oracle_equals_pillow(jpeg_lib, idx):
+    from oracle import jpeg_oracle as J
+    name, data = _cases()[idx]
+    ref = _pil(data)
+    H, W = ref.shape[:2]
+    coef = np.zeros(jpeg_lib.coef_count(H, W), np.int16)
+    qt = np.zeros((3, 64), np.uint16)
+    rc, info = jpeg_lib.decode_coeffs(data, coef, qt)
+    assert rc == 0 and (info.height, info.width) == (H, W), (name, rc)
+    got = J.decode_from_coeffs(coef, qt, W, H, info.mcu_cols, info.mcu_rows)
+    assert np.array_equal(got, ref), f"{name}: {int((got != ref).sum())} bytes differ"
+
+
+def test_files_outside_the_split_decoder_are_refused_not_misread(jpeg_lib):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 255, (32, 48, 3), dtype=np.uint8)
+    for kw in (dict(subsampling=0), dict(subsampling=1), dict(progressive=True)):
+        assert jpeg_lib.scan(_jpeg(img, **kw)) is None, kw
+    grey = _jpeg(img[..., 0])
+    assert jpeg_lib.scan(grey) is None                                   # one component: the caller's software path
+    good = _jpeg(img)
+    assert jpeg_lib.scan(good) is not None
+    coef = np.zeros(jpeg_lib.coef_count(32, 48), np.int16)
+    qt = np.zeros((3, 64), np.uint16)
+    for cut in (len(good) // 2, len(good) - 3, 30):                      # truncated files: an error or a decodable prefix, never a crash
+        rc, _ = jpeg_lib.decode_coeffs(good[:cut], coef, qt)
+        assert rc in (0, -2), rc
+    rc, _ = jpeg_lib.decode_coeffs(good, coef[:100], qt)
+    assert rc == -3                                                      # too small a buffer is reported, not overrun
+    assert jpeg_lib.decode_coeffs(b"not a jpeg at all", coef, qt)[0] == -2
+
+
+@pytest.mark.gpu
+def test_device_pixel_half_equals_pillow(jpeg_lib, lib):
+    """aq_jpeg_idct_rgb on batches of same-size images: byte-identical to Pillow (and so to the oracle)."""
+    import torch
+    from aquaculture_amd import engine, tiles
+    rng = np.random.default_rng(11)
+    groups = {
+        (640, 640): [_jpeg(tiles.synthetic_tile(i, 640), quality=75) for i in (0, 3, 19, 40)],
+        (1024, 1024): [_jpeg(tiles.synthetic_tile(i, 1024), quality=75) for i in (1, 19)],
+        (100, 150): [_jpeg(rng.integers(0, 255, (100, 150, 3), dtype=np.uint8), quality=q) for q in (30, 75, 98)],
+        (33, 17): [_jpeg(rng.integers(0, 255, (33, 17, 3), dtype=np.uint8), quality=80)],
+        (64, 64): [_jpeg(np.tile(np.array([[[255, 0, 0], [0, 255, 0]], [[0, 0, 255], [255, 255, 255]]], np.uint8).repeat(8, 0).repeat(8, 1), (4, 4, 1)), quality=100)],
+    }
+    for (H, W), files in groups.items():
+        n = jpeg_lib.coef_count(H, W)
+        coef = np.zeros((len(files), n), np.int16)
+        qt = np.zeros((len(files), 3, 64), np.uint16)
+        for i, data in enumerate(files):
+            rc, info = jpeg_lib.decode_coeffs(data, coef[i], qt[i])
+            assert rc == 0
+        off = torch.arange(len(files), dtype=torch.int64) * n
+        got = engine.jpeg_idct_rgb(torch.from_numpy(coef).cuda(), off.cuda(), torch.from_numpy(qt.view(np.int16)).cuda(), H, W).cpu().numpy()
+        for i, data in enumerate(files):
+            ref = _pil(data)
+            assert np.array_equal(got[i], ref), f"{H}x{W} image {i}: {int((got[i] != ref).sum())} bytes differ"
