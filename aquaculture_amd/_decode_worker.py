@@ -1,11 +1,16 @@
 """jpeg decode worker process (decode scaling).
 
-Started by dataloader.LoadImages.pinned_batches as `python -m aquaculture_amd._decode_worker <shm name> <n_slots> <H> <W>`:
+Started by dataloader.LoadImages.pinned_batches as `python -m aquaculture_amd._decode_worker <shm name> <n_slots> <H> <W> [coef]`:
 a plain child process (never a fork of the GPU process) that imports only the standard library, numpy and PIL -- no torch, no HIP.
 Protocol, one line each way: parent -> `<slot> <path>`; worker decodes the image as RGB uint8 straight into slot `slot` of the
 shared-memory ring [n_slots][H][W][3] and answers `ok <slot>` or `err <slot> <message>`.  EOF on stdin ends the worker.
 
 [UPSTREAM utils/dataloaders.py LoadImages.__next__ -> cv2.imread]: same decoded pixels as the threaded path (PIL / libjpeg-turbo).
+
+Mode `coef` (round 3, the split decode): the worker undoes only the Huffman coding (libaqjpeg.so through aquaculture_amd/jpeg.py) and
+writes the image's quantised DCT coefficient blocks and quantisation tables into its slot of a byte ring [n_slots][jpeg.slot_bytes(H, W)];
+the GPU does the rest (aq_jpeg_idct_rgb), byte-identical to this process's PIL decode.  The parent only selects this mode for file sets
+whose headers say baseline 4:2:0 throughout; a file that still fails here is an error, as a PIL failure is.
 """
 import sys
 from multiprocessing import shared_memory
@@ -23,7 +28,13 @@ def main() -> int:
         resource_tracker.unregister(shm._name, "shared_memory")
     except Exception:
         pass
-    ring = np.ndarray((n_slots, H, W, 3), dtype=np.uint8, buffer=shm.buf)
+    coef_mode = len(sys.argv) > 5 and sys.argv[5] == "coef"
+    if coef_mode:
+        from aquaculture_amd import jpeg
+        nco = jpeg.coef_count(H, W)
+        ring = np.ndarray((n_slots, jpeg.slot_bytes(H, W)), dtype=np.uint8, buffer=shm.buf)
+    else:
+        ring = np.ndarray((n_slots, H, W, 3), dtype=np.uint8, buffer=shm.buf)
     out = sys.stdout
     for line in sys.stdin:
         line = line.rstrip("\n")
@@ -32,6 +43,17 @@ def main() -> int:
         slot_s, path = line.split(" ", 1)
         slot = int(slot_s)
         try:
+            if coef_mode:
+                with open(path, "rb") as f:
+                    data = f.read()
+                rc, info = jpeg.decode_coeffs(data, ring[slot, :2 * nco].view(np.int16), ring[slot, 2 * nco:2 * nco + 384].view(np.uint16).reshape(3, 64))
+                if rc != 0:
+                    raise ValueError(f"split JPEG decoder status {rc} (-1 unsupported coding, -2 corrupt data)")
+                if (info.width, info.height) != (W, H):
+                    raise ValueError(f"{info.height}x{info.width} differs from the first image {H}x{W}; mixed sizes need batches()")
+                out.write(f"ok {slot}\n")
+                out.flush()
+                continue
             with Image.open(path) as im:
                 if im.mode != "RGB":
                     im = im.convert("RGB")

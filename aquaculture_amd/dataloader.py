@@ -148,6 +148,12 @@ class LoadImages:
         with ThreadPoolExecutor(self.workers) as ex:
             return list(ex.map(size, self.files))
 
+    def scan_split_decodable(self) -> List[Optional[Tuple[int, int]]]:
+        """Per file: (width, height) when the split JPEG decoder covers it (aquaculture_amd/jpeg.py: baseline 4:2:0), else None."""
+        from . import jpeg
+        with ThreadPoolExecutor(self.workers) as ex:
+            return list(ex.map(jpeg.scan_file, self.files))
+
     def subset(self, positions: Sequence[int]) -> "LoadImages":
         """The same dataset restricted to some of its files (positions into ``files``); global indices travel with them."""
         import copy
@@ -182,7 +188,7 @@ class LoadImages:
             yield paths, np.stack(ims, 0), shapes
 
 
-    def pinned_batches(self, batch_size: int, n_buffers: int = 3, processes: Optional[int] = None):
+    def pinned_batches(self, batch_size: int, n_buffers: int = 3, processes: Optional[int] = None, coef: bool = False):
         """Raw-mode fast path for tile sweeps (every image the same size, as the reference's tiler produces them): decoders write
         straight into pre-pinned uint8 batch buffers [batch, H0, W0, 3] (no stack / pin copies).
         Yields (paths, pinned torch uint8 tensor [b,H0,W0,3], [orig shapes], buffer index); the caller must be done with
@@ -193,20 +199,30 @@ class LoadImages:
         ``processes`` (default: ``self.workers``; 0 = decode threads in this process): decode worker PROCESSES
         (aquaculture_amd/_decode_worker.py) that write into a shared-memory ring registered as pinned host memory.  The threaded
         path stops scaling after ~2 threads -- the PIL -> numpy conversion and the copies run under the GIL (8 threads: 231
-        images/s for 1024-px jpegs on 8 cores, 8 processes: 620) -- SURVEY.md 8f rank 2."""
+        images/s for 1024-px jpegs on 8 cores, 8 processes: 620) -- SURVEY.md 8f rank 2.
+
+        ``coef`` (worker processes only; every file must be split-decodable, ``scan_split_decodable``): the workers undo only the
+        Huffman coding and the batch is yielded as a uint8 tensor [b, jpeg.slot_bytes(H0, W0)] of coefficient blocks + quantisation
+        tables; the caller turns it into pixels on the device (engine.jpeg_slots_to_rgb)."""
         import threading
 
         import torch
         assert self.raw, "pinned_batches is the raw (device letterbox) path"
         if not self.files:
             return
-        first = read_rgb(self.files[0])
-        H0, W0 = first.shape[:2]
+        if coef:
+            from . import jpeg
+            wh = jpeg.scan_file(self.files[0])
+            assert wh is not None, "coef mode needs split-decodable files"
+            W0, H0 = wh
+        else:
+            first = read_rgb(self.files[0])
+            H0, W0 = first.shape[:2]
         free = [threading.Semaphore(1) for _ in range(n_buffers)]
         self.release = lambda i: free[i].release()
         nproc = self.workers if processes is None else processes
-        if nproc and nproc > 1:
-            yield from self._pinned_batches_procs(batch_size, n_buffers, nproc, H0, W0, free)
+        if (nproc and nproc > 1) or coef:
+            yield from self._pinned_batches_procs(batch_size, n_buffers, max(nproc or 1, 1), H0, W0, free, coef)
             return
         bufs = [torch.empty((batch_size, H0, W0, 3), dtype=torch.uint8).pin_memory() for _ in range(n_buffers)]
         views = [b.numpy() for b in bufs]
@@ -228,7 +244,7 @@ class LoadImages:
                 yield paths, bufs[i][:len(paths)], [(H0, W0)] * len(paths), i
                 k += 1
 
-    def _pinned_batches_procs(self, batch_size, n_buffers, nproc, H0, W0, free):
+    def _pinned_batches_procs(self, batch_size, n_buffers, nproc, H0, W0, free, coef=False):
         """Decode worker processes + shared-memory ring (see pinned_batches)."""
         import subprocess
         import sys
@@ -236,9 +252,16 @@ class LoadImages:
 
         import torch
         n_slots = n_buffers * batch_size
-        nbytes = n_slots * H0 * W0 * 3
-        shm = shared_memory.SharedMemory(create=True, size=nbytes)
-        ring = np.ndarray((n_buffers, batch_size, H0, W0, 3), dtype=np.uint8, buffer=shm.buf)
+        if coef:
+            from . import jpeg
+            slot = jpeg.slot_bytes(H0, W0)
+            nbytes = n_slots * slot
+            shm = shared_memory.SharedMemory(create=True, size=nbytes)
+            ring = np.ndarray((n_buffers, batch_size, slot), dtype=np.uint8, buffer=shm.buf)
+        else:
+            nbytes = n_slots * H0 * W0 * 3
+            shm = shared_memory.SharedMemory(create=True, size=nbytes)
+            ring = np.ndarray((n_buffers, batch_size, H0, W0, 3), dtype=np.uint8, buffer=shm.buf)
         ring_t = torch.from_numpy(ring)
         # Page-lock the ring in place (cudaHostRegister = hipHostRegister on ROCm) so that H2D copies from it are asynchronous DMA.
         # Measured on the MI355X box: DMA reads from a registered shm mapping run at only ~4 GB/s (hipHostMalloc memory: ~55 GB/s),
@@ -252,14 +275,14 @@ class LoadImages:
                 registered = int(rc) == 0
             except Exception:
                 registered = False
-        stage = None if registered else [torch.empty((batch_size, H0, W0, 3), dtype=torch.uint8).pin_memory() for _ in range(n_buffers)]
+        stage = None if registered else [torch.empty(tuple(ring.shape[1:]), dtype=torch.uint8).pin_memory() for _ in range(n_buffers)]
         ncopy = max(1, min(8, nproc))
         copiers = None if registered else ThreadPoolExecutor(ncopy)
         nproc = max(1, min(nproc, batch_size))
         env = dict(os.environ)
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-        procs = [subprocess.Popen([sys.executable, "-m", "aquaculture_amd._decode_worker", shm.name, str(n_slots), str(H0), str(W0)],
+        procs = [subprocess.Popen([sys.executable, "-m", "aquaculture_amd._decode_worker", shm.name, str(n_slots), str(H0), str(W0)] + (["coef"] if coef else []),
                                   stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1, env=env) for _ in range(nproc)]
         try:
             k = 0

@@ -91,6 +91,10 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
     p.add_argument("--autotune", choices=("auto", "on", "off"), default="auto",
                    help="time the conv kernels' tile configurations on the first full batch and keep the fastest per layer "
                         "(cached in $AQ_TUNE_CACHE or ~/.cache/aquaculture_amd/); auto = only for sweeps of >= 8 batches per GPU")
+    p.add_argument("--jpeg-decode", choices=("auto", "host", "split"), default="auto",
+                   help="split: the decode workers undo only the Huffman coding, the GPU does the inverse DCT, chroma upsampling and colour "
+                        "conversion (byte-identical to libjpeg-turbo; baseline 4:2:0 JPEGs, which is what the reference's tiler writes); "
+                        "host: full software decode in the workers; auto: split when every image of the sweep qualifies")
     p.add_argument("--resume", action="store_true",
                    help="continue an interrupted sweep in project/name (implies --exist-ok): tiles recorded in the run directory's "
                         "done.rank*.txt manifests are skipped, also those that produced no label file")
@@ -106,8 +110,8 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         save_txt=False, save_conf=False, nosave=False, classes=None, agnostic_nms=False,
         project="runs/detect", name="exp", exist_ok=False, half=False, batch_size=64, precision=None,
         workers=8, decode_threads=False, quiet=False, geocode_bboxes=None, geocode_out=None, tile_scenes=0, autotune="auto", resume=False,
-        log=print, **unsupported):
-    from .engine import Engine, format_label_rows, letterbox_device, letterbox_scene_tiles   # raises if the HIP library or the GPU is missing: there is no fallback
+        jpeg_decode="auto", log=print, **unsupported):
+    from .engine import Engine, format_label_rows, jpeg_slots_to_rgb, letterbox_device, letterbox_scene_tiles   # raises if the HIP library or the GPU is missing: there is no fallback
 
     for k in UNSUPPORTED:
         if unsupported.get(k):
@@ -276,7 +280,16 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                 parts.append((dataset.subset(sorted(odd, key=lambda i: (sizes[i] if main else (0, 0), i))), False))
         for sub, fast in parts:
             if fast:
-                gen = sub.pinned_batches(batch_size, depth + 1, processes=0 if decode_threads else None)
+                # split JPEG decode (Huffman on the host, the rest on the GPU) when every file of this part is a baseline 4:2:0 JPEG
+                split = False
+                if jpeg_decode != "host" and not decode_threads:
+                    split = all(r is not None for r in sub.scan_split_decodable())
+                    if jpeg_decode == "split" and not split:
+                        raise ValueError("--jpeg-decode split: some images are not baseline 4:2:0 JPEGs (use auto or host)")
+                if split and not split_note[0]:
+                    split_note[0] = True
+                    log(f"jpeg decode: split (entropy decoding in {sub.workers} worker processes, IDCT / upsampling / colour conversion on the GPU)")
+                gen = sub.pinned_batches(batch_size, depth + 1, processes=0 if decode_threads else None, coef=split)
                 release_of[0] = lambda i, sub=sub: sub.release(i)
                 it = gen
             else:
@@ -287,6 +300,8 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                 n_ += len(p_)
 
     release_of = [None]
+    split_note = [False]
+    jpeg_scratch = [None] * depth
     source_iter = scene_source() if tile_scenes else image_source()
     scene_dev, scene_path, scene_ev = None, None, None
     # Autotune on the first full batch (rank 0 times, every rank installs the same table: identical kernels on all GPUs of a run).
@@ -322,6 +337,11 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                         h2d = torch.cuda.Event()
                         h2d.record(st)
                         copy_done.append((h2d, buf_i))
+                    if tiles.dim() == 2:                   # coefficient blocks from the split JPEG decode: the pixel half runs here
+                        h0_, w0_ = shapes0[0]
+                        if jpeg_scratch[slot] is None:
+                            jpeg_scratch[slot] = torch.empty(eng.lib.aq_jpeg_scratch_bytes(batch_size, h0_, w0_), dtype=torch.uint8, device=tiles.device)
+                        tiles = jpeg_slots_to_rgb(tiles, h0_, w0_, scratch=jpeg_scratch[slot])
                     tiles = letterbox_device(tiles, tuple(imgsz), int(max(ck.stride)), True)
                 if tune:                                   # once, before the pipeline fills
                     tune = False

@@ -832,6 +832,18 @@ def jpeg_idct_rgb(coef: torch.Tensor, coef_off: torch.Tensor, qt: torch.Tensor, 
     return out
 
 
+def jpeg_slots_to_rgb(slots: torch.Tensor, H: int, W: int, scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A batch as the decode workers' coefficient mode delivers it -- uint8 CUDA [b, jpeg.slot_bytes(H, W)]: per image the int16 coefficient
+    blocks, then three uint16 quantisation tables -- to RGB tiles uint8 [b, H, W, 3] on the device."""
+    from . import jpeg
+    assert slots.is_cuda and slots.dtype == torch.uint8 and slots.dim() == 2 and slots.is_contiguous() and slots.shape[1] == jpeg.slot_bytes(H, W)
+    b = slots.shape[0]
+    nco = jpeg.coef_count(H, W)
+    qt = slots[:, 2 * nco:2 * nco + 384].contiguous().view(torch.int16)
+    off = torch.arange(b, dtype=torch.int64, device=slots.device) * (slots.shape[1] // 2)
+    return jpeg_idct_rgb(slots.view(torch.int16).reshape(-1), off, qt, H, W, scratch=scratch)
+
+
 def head_decode_level(x: torch.Tensor, w_oi: torch.Tensor, bias: torch.Tensor, cand_off: int, stride: float, anchors_px, nc: int,
                       conf_thres: float, cap: int):
     """One Detect level through aq_head_decode (tests): x bf16 NHWC [B, ny, nx, cin] (may be a channel slice), w [na * (nc + 5), cin].

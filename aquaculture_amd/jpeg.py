@@ -41,6 +41,26 @@ def coef_count(H: int, W: int) -> int:
     return ((H + 15) // 16 * 16) * ((W + 15) // 16 * 16) * 3 // 2
 
 
+def slot_bytes(H: int, W: int) -> int:
+    """Bytes of one image's slot in the decode workers' ring: coefficient blocks (int16), then the three quantisation tables (384 B),
+    padded so that slots stay 128-byte aligned."""
+    return 2 * coef_count(H, W) + 512
+
+
+def scan_file(path: str) -> Optional[Tuple[int, int]]:
+    """(width, height) when the split decoder covers the file (baseline / extended sequential Huffman, 8-bit, YCbCr 4:2:0), else None."""
+    try:
+        with open(path, "rb") as f:
+            head = f.read(1 << 16)              # the tables and frame header sit in front of the scan
+        info = scan(head)
+        if info is None and len(head) == (1 << 16):
+            with open(path, "rb") as f:
+                info = scan(f.read())
+        return (info.width, info.height) if info is not None else None
+    except OSError:
+        return None
+
+
 def scan(data: bytes) -> Optional[JpegInfo]:
     """Headers of a baseline 4:2:0 JPEG, or None when the split decoder does not cover the file (the caller decodes it in software)."""
     info = JpegInfo()

@@ -315,3 +315,18 @@ def test_cli_mixed_tile_sizes_do_not_end_the_sweep(tmp_path, lib, workdir):
     processed = [l for l in r.stdout.splitlines() if l.startswith("image ")]
     assert len(processed) == 20 and any(victim in l and "256x192" in l for l in processed)      # 224 x 160 letterboxed for --imgsz 256
     assert sorted(open(tmp_path / "runs" / "mixed" / "done.rank0.txt").read().split()) == sorted(n[:-5] for n in names)
+
+
+def test_split_jpeg_decode_gives_identical_labels(workdir, lib):
+    """--jpeg-decode split (Huffman in the worker processes, IDCT / chroma upsampling / colour conversion on the GPU) against --jpeg-decode
+    host (Pillow's libjpeg-turbo in the workers): the decoded pixels are byte-identical (tests/test_jpeg.py), so the label files are too;
+    `auto` picks the split path for a directory of baseline 4:2:0 JPEGs and says so."""
+    out_h, lab_h = _run(workdir, "jpeg_host", extra=("--quiet", "--half", "--jpeg-decode", "host"))
+    out_s, lab_s = _run(workdir, "jpeg_split", extra=("--quiet", "--half", "--jpeg-decode", "split"))
+    out_a, lab_a = _run(workdir, "jpeg_auto", extra=("--quiet", "--half"))
+    assert "jpeg decode: split" in out_s and "jpeg decode: split" in out_a and "jpeg decode: split" not in out_h
+    names = sorted(os.listdir(lab_h))
+    assert names and names == sorted(os.listdir(lab_s)) == sorted(os.listdir(lab_a))
+    for n in names:
+        ref = open(lab_h / n, "rb").read()
+        assert open(lab_s / n, "rb").read() == ref and open(lab_a / n, "rb").read() == ref, n

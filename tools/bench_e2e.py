@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--decode-threads", action="store_true", help="in-process decode threads instead of worker processes (A/B)")
     ap.add_argument("--scenes", type=int, default=0, help="scene mode: write this many 6144x6144 scene rasters (36 tiles each) and sweep them "
                                                           "with --tile-scenes instead of a jpeg directory")
+    ap.add_argument("--jpeg-decode", default="auto", choices=("auto", "host", "split"))
     ap.add_argument("--json", default="", help="append this run's numbers to a JSON file (profiles/e2e_latest.json: bench.py quotes it as `e2e`)")
     a = ap.parse_args()
     from aquaculture_amd import checkpoint, tiles
@@ -58,7 +59,7 @@ def main():
         checkpoint.write_synthetic_checkpoint(w, "yolov5m", 5)
     cmd = [sys.executable, os.path.join(ROOT, "yolov5", "detect.py"), "--weights", w, "--source", jp, "--nosave", "--save-txt", "--save-conf",
            "--project", os.path.join(a.dir, "runs"), "--name", "e2e", "--batch-size", str(a.batch_size), "--workers", str(a.workers),
-           "--precision", a.precision, "--quiet"] + (["--decode-threads"] if a.decode_threads else []) + (["--tile-scenes"] if a.scenes else [])
+           "--precision", a.precision, "--quiet", "--jpeg-decode", a.jpeg_decode] + (["--decode-threads"] if a.decode_threads else []) + (["--tile-scenes"] if a.scenes else [])
     t0 = time.perf_counter()
     r = subprocess.run(cmd, capture_output=True, text=True)
     dt = time.perf_counter() - t0
@@ -88,7 +89,7 @@ def main():
             doc = {"library_source_digest": digest, "what": "yolov5/detect.py end to end on one MI355X: image directory -> label files "
                    "(decode, H2D, device letterbox, engine, NMS, D2H, rescale, %g formatting, one file per tile with detections)", "runs": []}
         doc["runs"].append({"input": ("6144x6144 scene rasters, tiles cut on the device (--tile-scenes)" if a.scenes else f"{a.size}x{a.size} jpegs (q75)"),
-                            "images": a.n, "decode_workers": a.workers, "decode": "threads" if a.decode_threads else "worker processes",
+                            "images": a.n, "decode_workers": a.workers, "decode": "threads" if a.decode_threads else "worker processes", "jpeg_decode": a.jpeg_decode,
                             "batch_size": a.batch_size, "precision": a.precision, "images_per_s_steady": steady,
                             "images_per_s_wall_incl_start": round(a.n / dt, 1), "host_cpus": os.cpu_count()})
         with open(a.json, "w") as f:
