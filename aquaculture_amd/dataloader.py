@@ -285,19 +285,31 @@ class LoadImages:
         procs = [subprocess.Popen([sys.executable, "-m", "aquaculture_amd._decode_worker", shm.name, str(n_slots), str(H0), str(W0)] + (["coef"] if coef else []),
                                   stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1, env=env) for _ in range(nproc)]
         try:
-            k = 0
-            for s in range(0, len(self.files), batch_size):
-                paths = self.files[s:s + batch_size]
-                i = k % n_buffers
-                free[i].acquire()
-                sent = [0] * nproc
-                for j, p in enumerate(paths):            # round-robin over the workers; they decode concurrently
+            # The workers run one batch AHEAD of the batch being collected: the requests of batch k + 1 go out (when its ring buffer is
+            # free) before the answers of batch k are awaited, so the decoders never idle while the parent collects, uploads and launches
+            # (round 3: with one batch in flight the decode stage sat idle for most of every batch interval).  A worker answers its
+            # requests in order, so batch k's answers precede batch k + 1's on every pipe.
+            starts = list(range(0, len(self.files), batch_size))
+
+            def dispatch(k_, blocking):
+                i_ = k_ % n_buffers
+                if not free[i_].acquire(blocking=blocking):
+                    return None
+                paths_ = self.files[starts[k_]:starts[k_] + batch_size]
+                sent_ = [0] * nproc
+                for j, p in enumerate(paths_):           # round-robin over the workers; they decode concurrently
                     w = j % nproc
-                    procs[w].stdin.write(f"{i * batch_size + j} {p}\n")
-                    sent[w] += 1
+                    procs[w].stdin.write(f"{i_ * batch_size + j} {p}\n")
+                    sent_[w] += 1
                 for w in range(nproc):
-                    if sent[w]:
+                    if sent_[w]:
                         procs[w].stdin.flush()
+                return paths_, i_, sent_
+
+            ahead = None
+            for k in range(len(starts)):
+                paths, i, sent = ahead if ahead is not None else dispatch(k, True)
+                ahead = dispatch(k + 1, False) if k + 1 < len(starts) else None
                 for w in range(nproc):
                     for _ in range(sent[w]):
                         ans = procs[w].stdout.readline()
@@ -313,7 +325,8 @@ class LoadImages:
                     list(copiers.map(lambda a: stage[i][a:min(a + step, n)].copy_(ring_t[i][a:min(a + step, n)]), range(0, n, step)))
                     batch = stage[i][:n]
                 yield paths, batch, [(H0, W0)] * len(paths), i
-                k += 1
+                if ahead is None and k + 1 < len(starts):
+                    ahead = dispatch(k + 1, True)            # its buffer was still in use a moment ago: wait for it now
         finally:
             for pr in procs:
                 try:

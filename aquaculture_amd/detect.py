@@ -266,7 +266,13 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         parts = []
         if len(dataset):
             try:
-                sizes = dataset.scan_sizes()
+                sizes = None
+                if jpeg_decode != "host" and not decode_threads:       # one header pass serves both questions when every file qualifies
+                    split_sizes = dataset.scan_split_decodable()
+                    if all(r is not None for r in split_sizes):
+                        sizes, all_split[0] = split_sizes, True
+                if sizes is None:
+                    sizes = dataset.scan_sizes()
                 common = max(set(sizes), key=sizes.count)
                 main = [i for i, sz in enumerate(sizes) if sz == common]
                 odd = [i for i, sz in enumerate(sizes) if sz != common]
@@ -283,13 +289,13 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                 # split JPEG decode (Huffman on the host, the rest on the GPU) when every file of this part is a baseline 4:2:0 JPEG
                 split = False
                 if jpeg_decode != "host" and not decode_threads:
-                    split = all(r is not None for r in sub.scan_split_decodable())
+                    split = all_split[0] or all(r is not None for r in sub.scan_split_decodable())
                     if jpeg_decode == "split" and not split:
                         raise ValueError("--jpeg-decode split: some images are not baseline 4:2:0 JPEGs (use auto or host)")
                 if split and not split_note[0]:
                     split_note[0] = True
                     log(f"jpeg decode: split (entropy decoding in {sub.workers} worker processes, IDCT / upsampling / colour conversion on the GPU)")
-                gen = sub.pinned_batches(batch_size, depth + 1, processes=0 if decode_threads else None, coef=split)
+                gen = sub.pinned_batches(batch_size, depth + 2, processes=0 if decode_threads else None, coef=split)     # one buffer more than the batches in flight: the workers decode one batch ahead
                 release_of[0] = lambda i, sub=sub: sub.release(i)
                 it = gen
             else:
@@ -301,6 +307,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
 
     release_of = [None]
     split_note = [False]
+    all_split = [False]
     jpeg_scratch = [None] * depth
     source_iter = scene_source() if tile_scenes else image_source()
     scene_dev, scene_path, scene_ev = None, None, None
