@@ -81,6 +81,23 @@ static void fill(Bits* b) {
     }
 }
 
+/* At least 32 valid bits afterwards.  Fast path: four data bytes at once when none of them is 0xFF (no stuffing, no marker). */
+static inline void fill32(Bits* b) {
+    if (b->nbits > 32) return;
+    if (!b->marker && b->p + 4 <= b->end) {
+        uint32_t w;
+        memcpy(&w, b->p, 4);
+        const uint32_t nw = ~w;
+        if (!((nw - 0x01010101u) & ~nw & 0x80808080u)) {        /* no byte of ~w is zero = no byte of w is 0xFF */
+            b->acc = (b->acc << 32) | __builtin_bswap32(w);
+            b->nbits += 32;
+            b->p += 4;
+            return;
+        }
+    }
+    fill(b);
+}
+
 static inline unsigned peek(Bits* b, int n) { return (unsigned)((b->acc >> (b->nbits - n)) & ((1u << n) - 1u)); }
 static inline void skip(Bits* b, int n) { b->nbits -= n; }
 
@@ -106,8 +123,7 @@ static int build(HuffTab* t, const uint8_t* counts, const uint8_t* vals, int nva
     return AQJ_OK;
 }
 
-static inline int decode_sym(Bits* b, const HuffTab* t) {
-    if (b->nbits < 16) fill(b);
+static inline int decode_sym(Bits* b, const HuffTab* t) {       /* the caller guarantees >= 16 valid bits */
     const unsigned e = t->look[peek(b, LOOK)];
     if (e) {
         skip(b, (int)(e >> 8));
@@ -124,8 +140,7 @@ static inline int decode_sym(Bits* b, const HuffTab* t) {
     return t->vals[(code + t->valoff[len]) & 0xff];
 }
 
-static inline int receive_extend(Bits* b, int s) {
-    if (b->nbits < s) fill(b);
+static inline int receive_extend(Bits* b, int s) {              /* the caller guarantees >= s valid bits */
     const int v = (int)peek(b, s);
     skip(b, s);
     return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
@@ -133,13 +148,13 @@ static inline int receive_extend(Bits* b, int s) {
 
 static int decode_block(Bits* b, const HuffTab* dc, const HuffTab* ac, int* pred, int16_t* out) {
     memset(out, 0, 64 * sizeof(int16_t));
-    if (b->nbits < 32) fill(b);
+    fill32(b);                             /* a symbol (<= 16 bits) and its magnitude bits (<= 15) fit the 32 guaranteed bits */
     int s = decode_sym(b, dc);
     if (s < 0 || s > 11) return AQJ_CORRUPT;
     if (s) *pred += receive_extend(b, s);
     out[0] = (int16_t)*pred;
     for (int k = 1; k < 64;) {
-        if (b->nbits < 32) fill(b);
+        fill32(b);
         const int rs = decode_sym(b, ac);
         if (rs < 0) return AQJ_CORRUPT;
         const int r = rs >> 4;

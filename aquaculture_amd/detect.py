@@ -307,6 +307,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
 
     release_of = [None]
     split_note = [False]
+    t_steady, n_steady, n_fed = [None], [0], [0]
     all_split = [False]
     jpeg_scratch = [None] * depth
     source_iter = scene_source() if tile_scenes else image_source()
@@ -377,6 +378,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
             shape_str = f"(1, 3, {H}, {W})"
             t2 = time.perf_counter()
             q.put((ev, counts_h, dets_h, paths, shapes0, (H, W), list(gidx), t2 - t1, slot))
+            n_fed[0] += len(paths)
             while copy_done and (copy_done[0][0].query() or len(copy_done) > depth):
                 ev_, bi_ = copy_done.pop(0)
                 ev_.synchronize()
@@ -384,6 +386,8 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
             t_pre += t1 - t0
             t_inf += t2 - t1
             k += 1
+            if k == 2:                                     # steady state: from the hand-over of the second batch (header scan, worker start-up,
+                t_steady[0], n_steady[0] = time.perf_counter(), sum(1 for _ in gidx)        # autotune and the pipeline fill are behind us)
             if world > 1 and k % flush_every == 0:         # bounded gather: rows leave the host lists every few batches (collective)
                 with gather_lock:
                     gather.flush(more=True, failed=bool(err))
@@ -416,6 +420,11 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         log(f"Speed: {per(t_pre):.1f}ms pre-process, {per(t_inf):.1f}ms inference, {per(t_post):.1f}ms NMS-out/post-process "
             f"per image at shape {shape_str} (host time per stage; stages overlap)")
         log(f"{seen_all} images, {dets_all} detections, {seen_all / max(elapsed, 1e-9):.1f} images/s on {world} GPU(s) [{precision}]")
+        if t_steady[0] is not None and seen > 4 * batch_size:
+            # this rank's rate once the sweep is under way (everything up to the second batch -- header scan, decode worker start-up,
+            # tile-configuration timing, pipeline fill -- excluded): what a long sweep converges to
+            t_end = t_start + (time.perf_counter() - t_start if world > 1 else elapsed)
+            log(f"steady state: {(seen - 2 * batch_size) / max(t_end - t_steady[0], 1e-9):.1f} images/s on this GPU after the first two batches")
         if save_txt:
             log(f"Results saved to {save_dir}\n{labels_all} labels saved to {save_dir / 'labels'}")
         if geocode_bboxes:

@@ -63,7 +63,7 @@ def main():
     t0 = time.perf_counter()
     r = subprocess.run(cmd, capture_output=True, text=True)
     dt = time.perf_counter() - t0
-    tail = [l for l in r.stdout.splitlines() if l.startswith(("Speed", "Results")) or "images/s" in l or "labels saved" in l]
+    tail = [l for l in r.stdout.splitlines() if l.startswith(("Speed", "Results", "steady", "jpeg decode")) or "images/s" in l or "labels saved" in l]
     print("\n".join(tail[-5:]))
     if r.returncode != 0:
         print(r.stderr[-2000:])
@@ -72,9 +72,12 @@ def main():
     if a.json and r.returncode == 0:
         import json
         import re
-        steady = None
+        steady = whole = None
         for l in r.stdout.splitlines():
             m = re.search(r"([0-9.]+) images/s on (\d+) GPU", l)
+            if m:
+                whole = float(m.group(1))
+            m = re.search(r"steady state: ([0-9.]+) images/s", l)
             if m:
                 steady = float(m.group(1))
         try:
@@ -90,7 +93,7 @@ def main():
                    "(decode, H2D, device letterbox, engine, NMS, D2H, rescale, %g formatting, one file per tile with detections)", "runs": []}
         doc["runs"].append({"input": ("6144x6144 scene rasters, tiles cut on the device (--tile-scenes)" if a.scenes else f"{a.size}x{a.size} jpegs (q75)"),
                             "images": a.n, "decode_workers": a.workers, "decode": "threads" if a.decode_threads else "worker processes", "jpeg_decode": a.jpeg_decode,
-                            "batch_size": a.batch_size, "precision": a.precision, "images_per_s_steady": steady,
+                            "batch_size": a.batch_size, "precision": a.precision, "images_per_s_steady": steady, "images_per_s_whole_sweep": whole,
                             "images_per_s_wall_incl_start": round(a.n / dt, 1), "host_cpus": os.cpu_count()})
         with open(a.json, "w") as f:
             json.dump(doc, f, indent=1)
