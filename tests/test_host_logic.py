@@ -150,3 +150,19 @@ def test_bf16_byte_normalisation_by_reciprocal_is_exact():
         u = x.view(np.uint32).astype(np.uint64)
         return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
     assert np.array_equal(bf16(a), bf16(b)) and int((a != b).sum()) > 0
+
+
+def test_shipped_tuned_tables_match_the_plans():
+    """aquaculture_amd/data/tuned_tables.json (round 3: the tile configurations of BASELINE.json's geometries, timed on MI355X and shipped so
+    that two runs of one build launch the same kernels): every entry has one config per plan op of its model / precision, conv ops only."""
+    import json
+    from aquaculture_amd import spec
+    tab = json.load(open(os.path.join(ROOT, "aquaculture_amd", "data", "tuned_tables.json")))
+    assert any(k.startswith("yolov5m:nc5:pbf16:64x640x640:") for k in tab), "the headline geometry must ship"
+    for key, cfgs in tab.items():
+        variant, nc, prec = key.split(":")[0], int(key.split(":")[1][2:]), key.split(":")[2][1:]
+        plan = spec.build_plan(variant, nc, fused_bottleneck=prec in ("bf16", "fp8", "fp8w"))
+        assert len(cfgs) == len(plan.ops) == int(key.rsplit("ops", 1)[1]), key
+        for c, o in zip(cfgs, plan.ops):
+            assert (c == -1) == (o.kind != spec.OP_CONV) or c >= -1, (key, o.name, c)
+            assert o.kind == spec.OP_CONV or c == -1, (key, o.name, c)
