@@ -124,6 +124,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     precision = precision or ("bf16" if half else "fp32")
 
     rank, world, local = aqdist.init()
+    multi = world > 1 or aqdist.forced()                  # the collectives run (AQ_DIST_FORCE=1: also in a world of one -- RCCL on a one-GPU box)
     dev = int(device) if str(device).strip().isdigit() else local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev)
 
@@ -133,7 +134,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     if rank == 0:
         save_dir = increment_path(Path(project) / name, exist_ok=exist_ok or resume)
         (save_dir / "labels" if save_txt else save_dir).mkdir(parents=True, exist_ok=True)
-    if world > 1:
+    if multi:
         box = [str(save_dir) if rank == 0 else None]
         torch.distributed.broadcast_object_list(box, src=0)
         save_dir = Path(box[0])
@@ -147,7 +148,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         check_run_params(str(save_dir), {"weights_sha256": file_digest(weights) if os.path.isfile(str(weights)) else str(weights),
                                          "conf_thres": float(conf_thres), "iou_thres": float(iou_thres), "max_det": int(max_det),
                                          "imgsz": [int(v) for v in imgsz], "precision": precision, "save_conf": bool(save_conf)}, resume)
-    if world > 1:
+    if multi:
         aqdist.barrier()                                   # nobody processes a tile before rank 0 has accepted the directory
     done_before = DoneManifest.load(str(save_dir)) if resume else set()
     manifest = DoneManifest(str(save_dir), rank)
@@ -209,7 +210,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                         s = f"image {gidx[b] + 1}/{dataset.total} {p}: {H}x{W} "
                         s += postprocess.class_summary(det[:, 5], ck.names) if det.shape[0] else "(no detections), "
                         log(f"{s}{t_inf * 1e3 / len(paths):.1f}ms")
-                    if world > 1 and det.shape[0]:
+                    if multi and det.shape[0]:
                         with gather_lock:
                             gather.add(torch.full((det.shape[0],), gidx[b], dtype=torch.int32), aqdist.pack_rows(torch.from_numpy(det.copy())))
                 slot_free[slot_id].release()
@@ -356,7 +357,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                     geom = [int(tiles.shape[0]), int(tiles.shape[1]), int(tiles.shape[2])]
                     t_tune = time.perf_counter()
                     box = [geom, eng.autotune(tiles, cache=tune_cache) if rank == 0 else None]
-                    if world > 1:
+                    if multi:
                         torch.distributed.broadcast_object_list(box, src=0)
                         if rank != 0 and box[0] == geom:
                             eng.set_tuned_table(*geom, box[1])
@@ -388,7 +389,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
             k += 1
             if k == 2:                                     # steady state: from the hand-over of the second batch (header scan, worker start-up,
                 t_steady[0], n_steady[0] = time.perf_counter(), sum(1 for _ in gidx)        # autotune and the pipeline fill are behind us)
-            if world > 1 and k % flush_every == 0:         # bounded gather: rows leave the host lists every few batches (collective)
+            if multi and k % flush_every == 0:         # bounded gather: rows leave the host lists every few batches (collective)
                 with gather_lock:
                     gather.flush(more=True, failed=bool(err))
     except BaseException as e:   # anything the main loop raises (engine, autotune, a decode error, another rank's RankFailed) ends the sweep
@@ -397,7 +398,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         q.put(None)
     for w_ in wts:
         w_.join()
-    if world > 1:                                      # collective tail; a failed rank takes the others down with it at once
+    if multi:                                          # collective tail; a failed rank takes the others down with it at once
         try:
             with gather_lock:
                 gather.finish(failed=bool(err))
@@ -410,7 +411,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     elapsed = time.perf_counter() - t_start
     seen, n_labels, n_dets, t_post = stats["seen"], stats["labels"], stats["dets"], stats["t_post"]
 
-    if world > 1:   # the one collective of the path (detection gather over RCCL/xGMI) has run in bounded pieces; now the counters
+    if multi:       # the one collective of the path (detection gather over RCCL/xGMI) has run in bounded pieces; now the counters
         seen_all, labels_all, dets_all, elapsed = aqdist.reduce_counters(seen, n_labels, n_dets, elapsed, dev)
         assert rank != 0 or gather.total == dets_all, "gathered detection rows do not add up"
     else:

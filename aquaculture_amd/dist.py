@@ -25,9 +25,19 @@ def env_rank_world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
+def forced() -> bool:
+    """AQ_DIST_FORCE=1: run the collectives even in a world of one rank -- how a one-GPU box exercises the RCCL ("nccl") code path
+    (communicator set-up, device tensors through all_gather / gather / all_reduce / barrier) that otherwise needs a second GPU."""
+    return os.environ.get("AQ_DIST_FORCE") == "1"
+
+
+def active() -> bool:
+    return dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+
 def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, world, local = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("AQ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -61,7 +71,7 @@ class DetectionGather:
     On rank 0 ``tile_index`` / ``rows`` hold what was gathered (kept only when ``keep`` is true) and ``total`` the row count."""
 
     def __init__(self, device=None, keep: bool = True):
-        self.on = dist.is_initialized() and dist.get_world_size() > 1
+        self.on = active()
         self.world = dist.get_world_size() if self.on else 1
         self.rank = dist.get_rank() if self.on else 0
         gloo = self.on and dist.get_backend() == "gloo"
@@ -142,7 +152,7 @@ class DetectionGather:
 
 def reduce_counters(tiles: int, labels: int, dets: int, elapsed_s: float, device) -> Tuple[int, int, int, float]:
     """C3: sums of (tiles, label files, detections) and the max of elapsed seconds over ranks."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return tiles, labels, dets, elapsed_s
     if dist.get_backend() == "gloo":
         device = torch.device("cpu")
@@ -154,5 +164,5 @@ def reduce_counters(tiles: int, labels: int, dets: int, elapsed_s: float, device
 
 
 def barrier() -> None:
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         dist.barrier()

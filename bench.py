@@ -188,7 +188,7 @@ def main() -> int:
     from aquaculture_amd.engine import Engine
 
     # one rank per GPU over RCCL ("nccl"); AQ_DIST_BACKEND=gloo is the single-GPU rehearsal of the N > 1 code path
-    rank, world, local = aqdist.init((os.environ.get("AQ_DIST_BACKEND") or "nccl") if int(os.environ.get("WORLD_SIZE", 1)) > 1 else None)
+    rank, world, local = aqdist.init((os.environ.get("AQ_DIST_BACKEND") or "nccl") if int(os.environ.get("WORLD_SIZE", 1)) > 1 or aqdist.forced() else None)
     local = local % max(torch.cuda.device_count(), 1)
     if world != a.gpus:
         print(f"bench: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
@@ -283,7 +283,7 @@ def main() -> int:
     aqdist.barrier()
     elapsed = time.perf_counter() - t0
     n_dets_total = int(gathered[0])
-    if world > 1:
+    if aqdist.active():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t[0])
@@ -410,7 +410,7 @@ def main() -> int:
                                f"resident in HBM ({a.pool} distinct batches cycled), seeded random-init weights nc=5 "
                                f"(BASELINE.json configs[{3 if a.precision in ('fp8w', 'fp8') else 1}])",
                    "tile_configs": getattr(eng, "tuned_from", "heuristic") if not a.no_autotune else "heuristic",
-                   "batch_per_gpu": B, "tile_px": a.size, "parallelism": f"tile-sharded dp{world}", "batches_in_flight": a.streams, **({"cu_split": a.cu_split} if a.cu_split else {}),
+                   "batch_per_gpu": B, "tile_px": a.size, "parallelism": f"tile-sharded dp{world}", **({"collectives": torch.distributed.get_backend()} if aqdist.active() else {}), "batches_in_flight": a.streams, **({"cu_split": a.cu_split} if a.cu_split else {}),
                    "detections_gathered": n_dets_total},
         "roofline": roof,
     }

@@ -330,3 +330,17 @@ def test_split_jpeg_decode_gives_identical_labels(workdir, lib):
     for n in names:
         ref = open(lab_h / n, "rb").read()
         assert open(lab_s / n, "rb").read() == ref and open(lab_a / n, "rb").read() == ref, n
+
+
+def test_cli_with_the_collectives_on_rccl_writes_the_same_labels(workdir, lib):
+    """AQ_DIST_FORCE=1: save-directory broadcast, barrier, bounded detection gather and the counter reductions run through RCCL ("nccl") in
+    a world of one rank -- what a one-GPU box can execute of SURVEY.md 8e on the real backend; label bytes as the plain run."""
+    _, ref = _run(workdir, "exp_plain_bf16", extra=("--half",))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out, lab = _run(workdir, "exp_rccl1", extra=("--half",), env={"AQ_DIST_FORCE": "1", "AQ_DIST_BACKEND": "nccl", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                                                                 "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    a = {f: open(ref / f, "rb").read() for f in sorted(os.listdir(ref))}
+    b = {f: open(lab / f, "rb").read() for f in sorted(os.listdir(lab))}
+    assert a and a == b

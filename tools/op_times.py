@@ -14,11 +14,13 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--grep", default="")
 ap.add_argument("--lib", default=None)
+ap.add_argument("--variant", default="yolov5m")
+ap.add_argument("--size", type=int, default=640)
 a = ap.parse_args()
 if a.lib:
     engine.load_library(a.lib)
-eng = engine.Engine(checkpoint.synthetic_checkpoint("yolov5m", 5), "bf16")
-x = torch.from_numpy(tiles.synthetic_batch(range(a.batch), 640)).cuda()
+eng = engine.Engine(checkpoint.synthetic_checkpoint(a.variant, 5), "bf16")
+x = torch.from_numpy(tiles.synthetic_batch(range(a.batch), a.size)).cuda()
 eng.autotune(x)
 eng.infer(x)
 eng.profile(True, a.reps)
@@ -28,5 +30,6 @@ torch.cuda.synchronize()
 ms, calls = eng.op_times_ms()
 for i, o in enumerate(eng.plan.ops):
     if a.grep in o.name:
-        print(f"{i:3d} {o.name:28s} {ms[i] * 1e3:8.1f} us")
+        tf = o.flops_per_tile * a.batch / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else 0.0
+        print(f"{i:3d} {o.name:28s} k{o.k} s{o.stride} {o.src.channels if o.src else 0:5d}->{o.dst.channels if o.dst else 0:5d} {ms[i] * 1e3:8.1f} us {tf:8.1f} TF/s")
 print(f"total {ms.sum():.3f} ms over {calls} calls")
