@@ -1,7 +1,7 @@
 """RCCL on the hardware a one-GPU box has: the path's collectives (detection gather to rank 0, counters, barriers) run
 through the "nccl" backend in a world of ONE rank (AQ_DIST_FORCE=1) -- communicator set-up, device tensors through all_gather / gather /
 all_reduce / barrier, the CLI and bench.py end to end.  What it cannot show is a second rank; the gloo tests (tests/test_dist_gloo.py,
-world 2-8) cover the protocol, tests/test_bench_launcher.py::test_nccl_two_ranks the real thing where two GPUs exist."""
+world 2-8) cover the protocol, tests/test_bench_launcher.py::test_bench_gpus_2_as_typed_nccl the real thing where two GPUs exist."""
 import json
 import os
 import subprocess
