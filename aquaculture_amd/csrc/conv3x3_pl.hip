@@ -457,7 +457,13 @@ int pl_load_module(int dev) {
             char name[64];
             snprintf(name, sizeof name, "conv3x3_pl_asm_nb%d_res%d%s", kPlAsm[i].nb, v == 0 || v == 3 ? 0 : 1,
                      v == 2 ? "_stamped" : v >= 3 ? "_w8" : "");
-            AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_asm_fn[dev][i][v], mod, name));
+            const hipError_t e = hipModuleGetFunction(&g_pl_asm_fn[dev][i][v], mod, name);
+            if (e != hipSuccess && kPlAsm[i].nb != 13) {    // the two-workgroup families are built only with AQ_GEN_EXPERIMENTAL=1
+                (void)hipGetLastError();
+                g_pl_asm_fn[dev][i][v] = nullptr;
+                continue;
+            }
+            AQ_CHECK_HIP(e);
         }
     AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_s2_fn[dev][0], mod, "conv3x3_pl_asm_s2nb13_res0"));
     AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_s2_fn[dev][1], mod, "conv3x3_pl_asm_s2nb13_res0_stamped"));
@@ -469,6 +475,18 @@ int pl_load_module(int dev) {
 }
 
 }  // namespace
+
+// 1 when the assembly family with `nb` pixel blocks per tile is in this build (13 always; 7 and 8 -- two workgroups per CU, measured no
+// faster anywhere on the BASELINE geometries -- only when the library was built with AQ_GEN_EXPERIMENTAL=1), 0 when not, < 0 on error.
+extern "C" int aq_conv3x3_pl_asm_family(int nb) {
+    int dev = 0;
+    AQ_CHECK_HIP(hipGetDevice(&dev));
+    AQ_REQUIRE(dev >= 0 && dev < 64, "conv3x3_pl_asm_family: device ordinal %d", dev);
+    { const int rc = pl_load_module(dev); if (rc) return rc; }
+    for (int i = 0; i < kNumPlAsm; ++i)
+        if (kPlAsm[i].nb == nb) return g_pl_asm_fn[dev][i][0] ? 1 : 0;
+    return 0;
+}
 
 extern "C" int aq_conv3x3_pl_supported(int cin, int cout) {
     return cin >= 128 && cin % 64 == 0 && cout % PL_BM == 0 && cout <= 960;
@@ -566,11 +584,12 @@ static int pl_conv(const void* in_dev, long long in_sp, long long in_ss, int cin
         for (int i = 0; i < kNumPl; ++i)
             if (kPl[i].nb == nb && pl_region_rows(B, H, W, nb * 16) <= PL_ROWS) k = i;
     }
+    { const int rc = pl_load_module(dev); if (rc) return rc; }
     int fam = -1;
     if (w8) nb = 13;                                        // the fp8-weight stream exists in the NB = 13 assembly family only
     if ((w8 || (!(use_asm && *use_asm == '0') && !(abl && *abl))) && (p.n_mt & (p.n_mt - 1)) == 0 && in_sp < (1LL << 32) && in_ss < (1LL << 31))
         for (int i = 0; i < kNumPlAsm; ++i)
-            if (kPlAsm[i].nb == nb && pl_region_rows(B, H, W, nb * 16) <= kPlAsm[i].rows) fam = i;
+            if (kPlAsm[i].nb == nb && g_pl_asm_fn[dev][i][0] && pl_region_rows(B, H, W, nb * 16) <= kPlAsm[i].rows) fam = i;
     AQ_REQUIRE(!w8 || fam >= 0, "conv3x3_pl_w8: shape outside the fp8-weight kernel (aq_conv3x3_pl_w8_supported)");
     AQ_REQUIRE(k >= 0 || fam >= 0, "conv3x3_pl: no tile of this kernel fits a %d-wide image in its region rows", W);
     const int bn = nb * 16;
@@ -578,7 +597,6 @@ static int pl_conv(const void* in_dev, long long in_sp, long long in_ss, int cin
     AQ_REQUIRE(ntiles > 0 && ntiles < (1LL << 30), "conv3x3_pl: bad tile count");
     p.ntiles = (int)ntiles;
     if (fam >= 0) {
-        { const int rc = pl_load_module(dev); if (rc) return rc; }
         long long grid = (long long)g_pl_cus[dev] * kPlAsm[fam].occ;
         if (grid > ntiles) grid = ntiles;
         PlAsmArgs a{};

@@ -231,6 +231,9 @@ int aq_conv3x3s2_direct(const void* in_dev, int in_ld, int in_choff, void* out_d
  * g * in_group_stride_b (NHWC: row bytes and 16).  out / res: NHWC bf16 slices as in aq_conv2d (res may alias out: in-place shortcut). */
 #define AQ_CONV_CFG_PL3X3 1002
 int aq_conv3x3_pl_supported(int cin, int cout);
+/* 1 when the assembly family with `nb` 16-pixel blocks per tile is part of this build (13: always; 7, 8: two workgroups per CU, an
+ * experiment that wins on no BASELINE geometry, built only with AQ_GEN_EXPERIMENTAL=1), else 0; negative aq_status on a HIP error. */
+int aq_conv3x3_pl_asm_family(int nb);
 int aq_pack_conv3x3_pl(const float* w_krsc_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream);
 int aq_conv3x3_pl(const void* in_dev, long long in_pixel_stride_b, long long in_group_stride_b, int cin,
                   void* out_dev, int out_ld, int out_choff, int cout, const void* res_dev, int res_ld, int res_choff,

@@ -130,7 +130,7 @@ def test_generated_planar_assembly_fits_its_occupancy(tmp_path):
         pytest.skip("ROCm clang not available")
     src = tmp_path / "pl.s"
     gen = os.path.join(ROOT, "aquaculture_amd", "csrc", "gen_conv3x3_pl_asm.py")
-    subprocess.run([sys.executable, gen, str(src)], check=True, capture_output=True)
+    subprocess.run([sys.executable, gen, str(src)], check=True, capture_output=True, env=dict(os.environ, AQ_GEN_EXPERIMENTAL="1"))   # every family, shipped or not
     subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src), "-o", str(tmp_path / "pl.o")],
                    check=True, capture_output=True)
     text = src.read_text()
