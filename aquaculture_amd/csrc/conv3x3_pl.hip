@@ -405,6 +405,7 @@ hipModule_t g_pl_asm_mod[64];
 hipFunction_t g_pl_asm_fn[64][kNumPlAsm][5];     // res0, res1, res1 stamped, and (NB = 13 only) the fp8-weight res0, res1
 hipFunction_t g_pl_s2_fn[64][2];                 // stride-2 family (s2nb13): plain, stamped
 hipFunction_t g_pl_f8_fn[64][3];                 // fp8 family (f8nb13): res0, res1, res1 stamped
+hipFunction_t g_pl_pm_fn[64][3][3];              // pixel-major builds of the stride-1 bf16 kernel (pm13: any width, pm13w20, pm13w40) x (res0, res1, res1 stamped)
 constexpr int PL_S2_NB = 13, PL_S2_ROWS = 304;   // gen_conv3x3_pl_asm.py CONFIGS["s2nb13"]
 
 struct PlKernel { int nb; void (*plain)(const PlParams); void (*res)(const PlParams); };
@@ -470,6 +471,12 @@ int pl_load_module(int dev) {
     AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_f8_fn[dev][0], mod, "conv3x3_pl_asm_f8nb13_res0"));
     AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_f8_fn[dev][1], mod, "conv3x3_pl_asm_f8nb13_res1"));
     AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_f8_fn[dev][2], mod, "conv3x3_pl_asm_f8nb13_res1_stamped"));
+    for (int f = 0; f < 3; ++f)
+        for (int v = 0; v < 3; ++v) {
+            char name[64];
+            snprintf(name, sizeof name, "conv3x3_pl_asm_pm13%s_res%d%s", f == 0 ? "" : f == 1 ? "w20" : "w40", v ? 1 : 0, v == 2 ? "_stamped" : "");
+            AQ_CHECK_HIP(hipModuleGetFunction(&g_pl_pm_fn[dev][f][v], mod, name));
+        }
     g_pl_asm_mod[dev] = mod;
     return AQ_OK;
 }
@@ -613,10 +620,23 @@ static int pl_conv(const void* in_dev, long long in_sp, long long in_ss, int cin
             if (sbuf && sbytes >= (size_t)grid * 4 * 64) { a.debug = sbuf; which = 2; }
         }
         hipFunction_t fn_asm = g_pl_asm_fn[dev][fam][which];
+        // The pixel-major build of the same kernel (family pm13: same tiles, weights, arguments and results; 64-byte pixel-major region rows
+        // loaded through a buffer descriptor -- a quarter of the cache-line look-ups per LDS-DMA instruction) wherever its addressing holds:
+        // contiguous channel groups, 24-bit pixel stride and pixel count, the tensor inside 2 GiB.  It pays where the image width is known at
+        // build time (the kernel-row offset is then an immediate: builds for yolov5m's 20 and 40); the any-width build moves its addresses
+        // with VALU adds in the stream and is slower than the slot-major kernel, so it runs only on request.
+        // AQ_PL_PM=0: slot-major everywhere (A/B); AQ_PL_PM=2: pixel-major, any-width build, everywhere (tests).
+        const char* pm_env = getenv("AQ_PL_PM");
+        const int pm_mode = pm_env && *pm_env ? atoi(pm_env) : 1;
+        const int pmf = pm_mode == 2 ? 0 : W == 20 ? 1 : W == 40 ? 2 : 0;
+        const bool pm = nb == 13 && !w8 && pm_mode != 0 && (pmf != 0 || pm_mode == 2) && in_ss == 16 && in_sp < (1 << 24) && in_sp % 16 == 0 &&
+                        p.npix < (1 << 24) && (long long)p.npix * in_sp < (1LL << 31);
+        if (pm) fn_asm = g_pl_pm_fn[dev][pmf][which];
         const char* asm_abl = getenv("AQ_PL_ASM_ABL");      // timing-only ablations of the stamped build (wrong results)
         if (which == 2 && asm_abl && *asm_abl) {
             char name[80];
-            snprintf(name, sizeof name, "conv3x3_pl_asm_nb%d_res1_stamped_abl%d", nb, atoi(asm_abl));
+            if (pm) snprintf(name, sizeof name, "conv3x3_pl_asm_pm13w40_res1_stamped_abl%d", atoi(asm_abl));
+            else snprintf(name, sizeof name, "conv3x3_pl_asm_nb%d_res1_stamped_abl%d", nb, atoi(asm_abl));
             AQ_CHECK_HIP(hipModuleGetFunction(&fn_asm, g_pl_asm_mod[dev], name));
         }
         size_t asz = sizeof(a);

@@ -83,6 +83,22 @@ CONFIGS = {
     # LOOK = 4: five weight sets, one per step, each reloaded for the next chunk as soon as its step is done.  The residual waits in
     # the accumulator half of the register file (78 of the 100 registers free there).
     "f8nb13": dict(NB=13, PD=4, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=4, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=1, S2=False, F8=True),
+    # PM = the PIXEL-MAJOR build of the stride-1 bf16 kernel (round 3).  Family nb13's slot-major planes make every lane of an LDS-DMA
+    # instruction touch a different 128-byte line (64 tag look-ups for 1 KB); the stamped ablations that round the source rows to
+    # multiples of eight / to one row (abl 16 / 32: same instructions, 8 / 1 lines each) run the stream in 83.0 k / 81.6 k cycles
+    # against 90.3 k (no LDS-DMA at all: 81.3 k) and the prologue in 4.3 k against 9.9 k: the look-ups, not the bytes, are the cost.
+    # Here a chunk is two half-planes (32 channels each) of 64-byte pixel-major region rows -- the stride-2 / fp8 families' row format:
+    # one buffer-descriptor LDS-DMA instruction moves 16 rows x 64 B (16 look-ups), out-of-range lanes write the zero padding, channel
+    # group q of a row sits at position q ^ 2 b (byte address bit 5 ^= b).  b is bit 2 of the pixel's COLUMN x (not of the region row,
+    # as in those families): consecutive pixels of an image row still spread every ds_read_b128 lane group over all 64 banks, and a
+    # kernel-row offset (dy Wp rows) no longer changes b -- so a pixel block needs three swizzled addresses (dx = 0, 1, 2), moved
+    # down a kernel row by one add each, and the k-step is an immediate offset (the other half-plane).
+    # WFIX = W: builds for one image width (yolov5m at 640 px: 40 and 20).  The first pixel-major build moved each address down a kernel row
+    # with a v_add in front of the read that uses it -- 117 of them per chunk, each stalling its read: the stream WITHOUT any LDS-DMA took
+    # 85.3 k cycles against the slot-major build's 81.8 k.  With the width known, dy Wp rows is an immediate offset like the k-step.
+    "pm13": dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False, PM=True),
+    "pm13w20": dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False, PM=True, WFIX=20),
+    "pm13w40": dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False, PM=True, WFIX=40),
 }
 STEP_B = 6 * 1024          # weight bytes per (wave, tap-step): six 1 KB bf16 fragments (KS = 1: three) ...
 W8 = False                 # ... or, in the fp8-weight kernels (set per kernel by gen_kernel), three 1 KB pairs of e4m3 fragments
@@ -92,6 +108,8 @@ def configure(nb):
     """Sets the module-level tile constants and (re)allocates the registers of one family."""
     g = globals()
     g["F8"] = False
+    g["PM"] = False
+    g["WFIX"] = 0
     g.update(CONFIGS[nb])
     g["NT"] = 5 if F8 else 9                   # MFMA steps per chunk that take their own weight fragments: taps, or (fp8) tap pairs
     g["FAMILY"] = f"nb{nb}" if isinstance(nb, int) else nb
@@ -132,6 +150,15 @@ def configure(nb):
         g["DPOS"] = [6, 12]
         g["RPOS"] = [0, 2, 4, 8, 10]                       # elements of a step whose residual loads may go (steps 0 .. 3 of a tile's last chunk)
         assert ROWS % 64 == 0 and NDMA == 6 and NB == 13 and 2 * PD <= 15
+    if PM:
+        g["GROUPS"] = [0, 64]                              # per wave: the 96 region rows it loads (both half-planes), as two groups of computed source pixels
+        g["NG"] = 2
+        g["PSTR"] = ROWS * 64                              # one half-plane (32 channels): ROWS pixel-major rows of 64 B
+        g["CHUNK"] = 2 * PSTR
+        g["BIAS_OFF"] = RING * CHUNK
+        g["LDS_BYTES"] = BIAS_OFF + 4096
+        g["NDMA"] = ROWS // 16 // 4                        # LDS-DMA instructions per wave, chunk AND half-plane (the waves split the rows)
+        assert ROWS % 64 == 0 and NDMA == 6 and PSTR + 16 < 65536
     assert (KS == 1) == bool(S2 or F8)
     assert PS % 256 == 0 and NB >= 6 and NG + 2 <= 8
     assert KS == 2 or (not SPLIT and not DMA_FRONT and not A_IN_ACC and RES_EARLY)
@@ -179,25 +206,25 @@ def allocate_registers():
     if S2:
         S.alloc("in_row", 2, 2)   # stride-2 family: bytes per INPUT image row (H, W, npix describe the OUTPUT there)
     for nm in ("HW", "Wp", "HpWp", "lead", "Hpad", "tile", "next_tile", "has_next", "n0", "cbase", "c", "buf", "cd", "bd", "lastc", "extra",
-               "rs", "rs_dma", "delta0", "dRow", "wave", "first", "tmp0", "tmp1", "tmp2", "tmp3", "dlds", "lim") + (("coff",) if S2 else ("coff", "rlim") if F8 else ("par", "rlim")):
+               "rs", "rs_dma", "delta0", "dRow", "wave", "first", "tmp0", "tmp1", "tmp2", "tmp3", "dlds", "lim") + (("coff",) if S2 else ("coff", "rlim") if F8 else ("coff", "coff1", "rlim") if PM else ("par", "rlim")):
         S.alloc(nm)
     S.alloc("klog2e2", 2, 2)      # (-log2 e, -log2 e) for v_pk_mul_f32
     S.alloc("kone2", 2, 2)        # (1.0, 1.0)
     S.alloc("a_cur", 2, 2)
     S.alloc("a_nxt", 2, 2)
     S.alloc("a_ld", 2, 2)         # base of the weight loads being issued
-    if S2 or F8:
+    if S2 or F8 or PM:
         S.alloc("srd", 4, 4)      # buffer descriptor of (this wave's parity plane of) the input (constant for the kernel)
     else:
         S.alloc("dbase", 2, 2)    # LDS-DMA: input base of (chunk, this wave's first plane) ...
-    if KS == 2 and not F8:
+    if KS == 2 and not F8 and not PM:
         S.alloc("dbase1", 2, 2)   # ... and of its second plane (32-channel chunks: one base, the planes are immediate offsets)
     S.alloc("t64", 2, 2)
     S.alloc("actm", 2, 2)         # all ones when the layer has an activation (in-stream epilogue blocks select instead of branching)
     S.alloc("st_acc", 12, 2)      # stamped build only: cycle sums of six phases
     if S2:                        # (arguments the stride-2 kernels never read: no shortcut, channel groups 16 bytes apart)
         S.names["st_last"], S.names["st_rt0"] = S.names["res"], S.names["in_ss"]
-    elif F8:                      # (the zero page's address lives on in two VGPRs; channel groups are contiguous)
+    elif F8 or PM:                # (the zero page's address lives on in two VGPRs; channel groups are contiguous)
         S.names["st_last"], S.names["st_rt0"] = S.names["zero"], S.names["in_ss"]
     else:
         S.alloc("st_last", 2, 2)
@@ -215,16 +242,16 @@ def allocate_registers():
     if not A_IN_ACC:
         V.alloc("A", (24 if F8 else 12 * KS) * (LOOK + 1), 4)
     V.alloc("B", (8 if F8 else 4) * (PD + 1), 4)
-    V.alloc("addr", 4 * NB if S2 else NB)      # (stride 2: per pixel block one swizzled address per (row, column) offset of the taps)
+    V.alloc("addr", 4 * NB if S2 else 3 * NB if PM else NB)      # (stride 2: per pixel block one swizzled address per (row, column) offset of the taps; pixel-major: per column offset)
     V.alloc("prow", NG)
     if F8:
         V.alloc("tapoff", 5)      # per MFMA step: 64 x the region-row offset of the tap THIS lane's operand half belongs to (lanes 0-31: tap 2 p, 32-63: 2 p + 1)
         V.alloc("SC", 12, 4)      # epilogue: act_scale x weight_scale of this lane's 3 x 4 output channels
-    if S2 or F8:
+    if S2 or F8 or PM:
         V.alloc("voff", NDMA)     # per LDS-DMA instruction of a chunk: this lane's byte offset into the parity plane, or beyond the descriptor
         V.alloc("bpa", 4)         # ds_bpermute addresses: lane (16 m + lane / 4) * 4, m = 0 .. 3
-        V.alloc("qoff")           # 16 x the channel group this lane fetches: (lane & 3) ^ 2 ((lane >> 4) & 1)
-    if RES_EARLY and not S2 and not F8:
+        V.alloc("qoff")           # 16 x the channel group this lane fetches: (lane & 3) ^ 2 ((lane >> 4) & 1)  (pixel-major: 16 (lane & 3), the swizzle bit comes with the row)
+    if RES_EARLY and not S2 and not F8 and not PM:
         V.alloc("R", 6 * NB, 2)
     V.alloc("oo", NB)
     V.alloc("t", 24, 4)           # temporaries
@@ -261,7 +288,7 @@ def vr(name, i, cnt):
 
 def rreg(b):
     """First register of residual pair b (0 .. 3 NB - 1): its own block, or (two-workgroup families) weight set 2 and then the B ring."""
-    if F8:
+    if F8 or PM:
         return 12 * NB + 2 * b                             # (accumulator-file register number)
     if RES_EARLY:
         return V.names["R"][0] + 2 * b
@@ -308,7 +335,7 @@ def emit_convert(tap, ks, i, step):
 
 
 def n_acc():
-    return 12 * NB + (24 * (LOOK + 1) if A_IN_ACC else 0) + (6 * NB if F8 else 0)
+    return 12 * NB + (24 * (LOOK + 1) if A_IN_ACC else 0) + (6 * NB if F8 or PM else 0)
 
 
 def acc(i, j):
@@ -431,7 +458,7 @@ def emit_region_rows(tile_s):
     """prow[k] = unpad(rs(tile) + GROUPS[k] + lane) for k = 0 .. NG - 1."""
     emit_rs_of_tile(tile_s, s("rs_dma"))
     T = [v("t", i) for i in range(6)]
-    if F8:
+    if F8 or PM:
         E(f"s_mul_i32 {s('tmp0')}, {s('wave')}, {16 * NDMA}", "this wave loads region rows 96 wave .. + 95")
         E(f"s_add_u32 {s('rs_dma')}, {s('rs_dma')}, {s('tmp0')}")
     for k in range(NG):
@@ -439,6 +466,31 @@ def emit_region_rows(tile_s):
         if k:
             E(f"v_add_u32 {T[5]}, {GROUPS[k]}, {T[5]}")
         emit_unpad(v("prow", k), T[5], T[0], T[1], T[2], T[3], T[4])
+        # timing-only ablations of the slot-major LDS-DMA's cache-line look-ups (64 distinct 128-byte lines per instruction):
+        if ABL[0] & 16:                                    # 16: eight distinct lines per instruction (what a pixel-major layout would touch)
+            E(f"v_and_b32 {v('prow', k)}, -8, {v('prow', k)}")
+        if ABL[0] & 32:                                    # 32: one line per instruction
+            E("s_nop 1")
+            E(f"v_readfirstlane_b32 {s('tmp0')}, {v('prow', k)}")
+            E(f"v_mov_b32 {v('prow', k)}, {s('tmp0')}")
+        if PM:                                             # the row's swizzle bit b = bit 2 of its column x travels with the pixel: 2 pixel + b (-1 stays negative)
+            E(f"v_bfe_u32 {T[3]}, {T[3]}, 2, 1")
+            E(f"v_lshl_or_b32 {v('prow', k)}, {v('prow', k)}, 1, {T[3]}")
+    if PM:
+        # deal the 64-row groups to the 16-row instructions (lane L of instruction g: region row 16 g + L / 4), then
+        # offset = pixel * in_sp + 16 ((L & 3) ^ 2 b), or out of the descriptor's range for a padding row (the DMA writes zeros)
+        for g_ in range(NDMA):
+            E(f"ds_bpermute_b32 {v('voff', g_)}, {v('bpa', g_ & 3)}, {v('prow', g_ >> 2)}")
+        E("s_waitcnt lgkmcnt(0)")
+        E(f"v_bfrev_b32 {T[0]}, 1", "0x80000000: beyond num_records")
+        for g_ in range(NDMA):
+            E(f"v_cmp_gt_i32 vcc, 0, {v('voff', g_)}")
+            E(f"v_and_b32 {T[2]}, 1, {v('voff', g_)}", "b")
+            E(f"v_ashrrev_i32 {T[3]}, 1, {v('voff', g_)}", "pixel")
+            E(f"v_lshlrev_b32 {T[2]}, 5, {T[2]}")
+            E(f"v_xor_b32 {T[2]}, {T[2]}, {v('qoff')}", "16 ((L & 3) ^ 2 b)")
+            E(f"v_mad_u32_u24 {v('voff', g_)}, {T[3]}, {v('insp')}, {T[2]}")
+            E(f"v_cndmask_b32 {v('voff', g_)}, {v('voff', g_)}, {T[0]}, vcc")
     if S2 or F8:
         # deal the 64-row groups to the 16-row instructions: lane L of instruction g fetches for region row 16 g + L / 4, whose source pixel
         # sits in lane 16 (g & 3) + L / 4 of prow[g >> 2]; then offset = pixel * in_sp + 16 * (channel group), or out of the descriptor's range
@@ -453,7 +505,7 @@ def emit_region_rows(tile_s):
 
 
 def emit_no_rows():
-    if S2 or F8:
+    if S2 or F8 or PM:
         for g_ in range(NDMA):
             E(f"v_bfrev_b32 {v('voff', g_)}, 1")
         return
@@ -465,6 +517,14 @@ def emit_dma_base(cd_s, bd_s):
     """Per chunk: dbase = inp + (8 cd + 2 wave) * in_ss (plane 2 wave of chunk cd) and dlds = bd * CHUNK + 2 wave * PS, the operands every
     LDS-DMA instruction of that chunk starts from.  (Computing them inside each of the 12 instructions' sequences cost 13 scalar
     instructions apiece, in a stream that is bound by instruction issue.)"""
+    if PM:
+        # chunk cd = bytes 128 cd .. + 127 of every pixel, half-plane h the 64 bytes from 64 h (the descriptor's soffset); this wave's rows of ring buffer bd
+        E(f"s_lshl_b32 {s('coff')}, {cd_s}, 7")
+        E(f"s_add_u32 {s('coff1')}, {s('coff')}, 64")
+        E(f"s_mul_i32 {s('tmp2')}, {bd_s}, {CHUNK}")
+        E(f"s_mul_i32 {s('tmp1')}, {s('wave')}, {1024 * NDMA}")
+        E(f"s_add_u32 {s('dlds')}, {s('tmp2')}, {s('tmp1')}", "the ring starts at LDS address 0")
+        return
     if S2 or F8:
         # chunk cd = bytes 64 cd .. + 63 of every pixel (the descriptor's soffset); this wave's parity plane (fp8: its rows) of ring buffer bd
         E(f"s_lshl_b32 {s('coff')}, {cd_s}, 6")
@@ -488,11 +548,11 @@ def emit_dma_base(cd_s, bd_s):
 
 def emit_dma(k, s2i, cd_s=None, bd_s=None):
     """One LDS-DMA instruction: plane 2 wave + s2i of the chunk emit_dma_base was called for, region rows 64 k .. 64 k + 63."""
-    if S2 or F8:
+    if S2 or F8 or PM:
         # (k = the instruction's number 0 .. NDMA - 1; in the stream the two halves sit around an element's MFMAs)
-        emit_dma_m0(k, 0)
+        emit_dma_m0(k, s2i)
         E("s_nop 0", "hz: m0 write -> LDS-DMA")
-        emit_dma_issue(k, 0)
+        emit_dma_issue(k, s2i)
         return
     T = [v("t", i) for i in range(8, 12)]
     base = s2("dbase1") if s2i else s2("dbase")
@@ -507,11 +567,11 @@ def emit_dma(k, s2i, cd_s=None, bd_s=None):
 
 def emit_dma_m0(g_, _=0):
     """Stride-2 family, first half of LDS-DMA instruction g_ (region rows 16 g_ .. + 15 of this wave's parity plane): its LDS address."""
-    E(f"s_add_u32 m0, {s('dlds')}, {1024 * g_}", "hz: m0 write -> LDS-DMA: at least one instruction before the DMA")
+    E(f"s_add_u32 m0, {s('dlds')}, {1024 * g_ + (_ * PSTR if PM else 0)}", "hz: m0 write -> LDS-DMA: at least one instruction before the DMA")
 
 
 def emit_dma_issue(g_, _=0):
-    E(f"buffer_load_dwordx4 {v('voff', g_)}, {s4('srd')}, {s('coff')} offen lds")
+    E(f"buffer_load_dwordx4 {v('voff', g_)}, {s4('srd')}, {s('coff1') if PM and _ else s('coff')} offen lds")
 
 
 def emit_load_a(set_idx, k, base_s2, extra_off):
@@ -558,6 +618,7 @@ def emit_barrier():
 
 
 STAMPED = [False]
+ABL = [0]
 PH_PROLOGUE, PH_BARRIER, PH_STREAM, PH_SETUP, PH_EPILOGUE, PH_TOP = range(6)
 
 
@@ -580,6 +641,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     global out, W8, STEP_B
     out = []
     STAMPED[0] = stamped
+    ABL[0] = abl
     NLOAD = 6 if F8 else 3 if (w8 or KS == 1) else 6       # weight load instructions per tap: 1 KB fragments (or e4m3 fragment pairs)
     W8, STEP_B = w8, NLOAD * 1024
     assert not w8 or (RES_EARLY and LOOK == 2 and not A_IN_ACC and NB >= 12 and KS == 2)
@@ -610,15 +672,15 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     if F8:
         E(f"v_and_b32 {v('qps')}, 1, {v('q')}")
         E(f"v_lshlrev_b32 {v('qps')}, 5, {v('qps')}", "fp8 family: operand lanes 16 q .. hold the 32 channels 32 (q & 1) .. of their tap")
-    elif S2:
-        E(f"v_lshlrev_b32 {v('qps')}, 4, {v('q')}", "stride-2 family: channel group q is 16 q bytes into a (pixel-major) region row")
+    elif S2 or PM:
+        E(f"v_lshlrev_b32 {v('qps')}, 4, {v('q')}", "stride-2 / pixel-major families: channel group q is 16 q bytes into a (pixel-major) region row")
     else:
         E(f"v_mul_u32_u24 {v('qps')}, {PS}, {v('q')}")
     E("s_waitcnt lgkmcnt(0)")
     E(f"v_mov_b32 {v('insp')}, {s('in_sp')}")
     E(f"v_mov_b32 {v('zero_lo')}, {s('zero')}")
     E(f"v_mov_b32 {v('zero_hi')}, {s('zero', 1)}")
-    if S2 or F8:
+    if S2 or F8 or PM:
         # descriptor of this wave's parity plane (py, px) = (wave >> 1, wave & 1): base = inp + py in_row + px in_sp, raw buffer (stride 0),
         # num_records 2^31 (every valid offset is below it -- the host checks the tensor's size --, the padding rows' 0x80000000 is not)
         # (fp8 family: one plane, base = inp)
@@ -636,7 +698,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         E(f"s_add_u32 {s('srd', 0)}, {s('srd', 0)}, {s('in_sp')}")
         E(f"s_addc_u32 {s('srd', 1)}, {s('srd', 1)}, {s('in_sp', 1)}")
         label(lq)
-    if S2 or F8:
+    if S2 or F8 or PM:
         E(f"s_and_b32 {s('srd', 1)}, {s('srd', 1)}, 0xffff")
         E(f"s_mov_b32 {s('srd', 2)}, 0x80000000")
         E(f"s_mov_b32 {s('srd', 3)}, 0x00020000")
@@ -647,7 +709,8 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         E(f"v_bfe_u32 {v('t', 1)}, {v('lane')}, 4, 1", "bit 2 of that row (instructions start at multiples of 16 rows)")
         E(f"v_and_b32 {v('qoff')}, 3, {v('lane')}")
         E(f"v_lshl_add_u32 {v('t', 1)}, {v('t', 1)}, 1, 0")
-        E(f"v_xor_b32 {v('qoff')}, {v('qoff')}, {v('t', 1)}", "position (lane & 3) of a row holds channel group (lane & 3) ^ 2 bit2(row)")
+        if not PM:                                         # (pixel-major family: the swizzle bit is a property of the row's pixel, applied per tile)
+            E(f"v_xor_b32 {v('qoff')}, {v('qoff')}, {v('t', 1)}", "position (lane & 3) of a row holds channel group (lane & 3) ^ 2 bit2(row)")
         E(f"v_lshlrev_b32 {v('qoff')}, 4, {v('qoff')}")
     E(f"s_mul_i32 {s('HW')}, {s('H')}, {s('W')}")
     E(f"s_add_u32 {s('Wp')}, {s('W')}, 1")
@@ -655,7 +718,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_mul_i32 {s('HpWp')}, {s('tmp0')}, {s('Wp')}")
     E(f"s_add_u32 {s('lead')}, {s('W')}, 2")
     E(f"s_add_u32 {s('Hpad')}, {s('tmp0')}, {s('W')}", "H + W + 1")
-    E(f"s_lshl_b32 {s('tmp0')}, {s('Wp')}, {6 if S2 else 4}")
+    E(f"s_lshl_b32 {s('tmp0')}, {s('Wp')}, {6 if S2 or PM else 4}")
     E(f"s_mov_b32 {s('dRow')}, {s('tmp0')}", "kernel row r -> r + 1: Wp * 16 bytes (stride-2 family: Wp * 64)")
     if F8:
         # tapoff[p]: lanes 0-31 carry tap 2 p, lanes 32-63 tap 2 p + 1 (step 4: tap 8 again -- its weights are zeros there);
@@ -711,10 +774,11 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_mov_b32 {s('cd')}, 0")
     E(f"s_mov_b32 {s('bd')}, 0")
     emit_dma_base(s("cd"), s("bd"))
-    if S2 or F8:
+    if S2 or F8 or PM:
         for g_ in range(NDMA):
-            emit_dma(g_, 0)
-    for k in range(NG if not (S2 or F8) else 0):
+            for h_ in range(2 if PM else 1):
+                emit_dma(g_, h_)
+    for k in range(NG if not (S2 or F8 or PM) else 0):
         for s2i in range(PPW):
             emit_dma(k, s2i, s("cd"), s("bd"))
     # bias: 256 floats per wave by LDS-DMA (lane: floats wave * 256 + 4 lane .. + 3, or zeros beyond cout)
@@ -759,10 +823,11 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         E(f"s_mov_b32 {s('cd')}, 1")
         E(f"s_mov_b32 {s('bd')}, 1")
         emit_dma_base(s("cd"), s("bd"))
-        if F8:
+        if F8 or PM:
             for g_ in range(NDMA):
-                emit_dma(g_, 0)
-        for k in range(NG if not F8 else 0):
+                for h_ in range(2 if PM else 1):
+                    emit_dma(g_, h_)
+        for k in range(NG if not (F8 or PM) else 0):
             for s2i in range(PPW):
                 emit_dma(k, s2i, s("cd"), s("bd"))
     stamp(PH_PROLOGUE)
@@ -800,6 +865,21 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         E(f"v_add_u32 {v('oo', j)}, {v('oo', j)}, {T[7]}")
         emit_pp_of(T[5], T[4], T[0], T[1], T[2], T[3])
         E(f"v_subrev_u32 {T[5]}, {s('tmp2')}, {T[5]}")
+        if PM:
+            # three swizzled addresses per pixel block, one per column offset dx of the taps: region row (upper left neighbour) + dx, 64 B per
+            # row, channel group q at position q ^ 2 b with b = bit 2 of that row's column x - 1 + dx (a padding column holds zeros at every
+            # position); + the ring buffer.  emit_pp_of leaves rem = y W + x in T[1] and y in T[2].
+            E(f"v_mul_lo_u32 {T[0]}, {T[2]}, {s('W')}")
+            E(f"v_sub_u32 {T[0]}, {T[1]}, {T[0]}", "x")
+            E(f"v_lshl_add_u32 {T[5]}, {T[5]}, 6, {s('tmp3')}", "byte address of the row in this tile's first ring buffer")
+            for dx in range(3):
+                E(f"v_add_u32 {T[1]}, {dx - 1}, {T[0]}")
+                E(f"v_bfe_u32 {T[1]}, {T[1]}, 2, 1", "b")
+                E(f"v_lshlrev_b32 {T[1]}, 5, {T[1]}")
+                E(f"v_xor_b32 {T[1]}, {T[1]}, {v('qps')}", "16 (q ^ 2 b)")
+                E(f"v_add_u32 {T[1]}, {T[5]}, {T[1]}")
+                E(f"v_add_u32 {v('addr', 3 * j + dx)}, {64 * dx}, {T[1]}")
+            continue
         if F8:
             # linear byte address of (upper left neighbour's row, this lane's 32-byte channel half), in the tile's first ring buffer;
             # the tap offset and the swizzle are applied where the fragment is read
@@ -938,7 +1018,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             L(f"v_pk_mul_f32 v[{X + 2}:{X + 3}], v[{X + 2}:{X + 3}], v[{sc + 2}:{sc + 3}]")
 
         def unpack():
-            if F8:                                        # the residual waits in the accumulator file
+            if F8 or PM:                                  # the residual waits in the accumulator file
                 L(f"v_accvgpr_read_b32 v{Rr + 1}, a{r0}")
                 L(f"v_accvgpr_read_b32 v{Rr + 3}, a{r0 + 1}")
                 L(f"v_lshlrev_b32 v{Rr}, 16, v{Rr + 1}")
@@ -1179,6 +1259,15 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
                     E(f"ds_read_b128 v[{bq}:{bq + 3}], {T[2]}")
                     E(f"ds_read_b128 v[{bq + 4}:{bq + 7}], {T[2]} offset:16")
                 return
+            if PM:
+                # tap (dy, dx) = divmod(t, 3): the block's address for column offset dx, which moves to the chunk's ring buffer at its first
+                # use (taps 0, 1, 2) and one kernel row down at each later one; the k-step is the other half-plane
+                dy, dx = divmod(t, 3)
+                if ks == 0 and (dy == 0 or not WFIX):
+                    E(f"v_add_u32 {v('addr', 3 * j + dx)}, {s('delta0') if dy == 0 else s('dRow')}, {v('addr', 3 * j + dx)}")
+                if not abl & 4:
+                    E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', 3 * j + dx)} offset:{ks * PSTR + (dy * (WFIX + 1) * 64 if WFIX else 0)}")
+                return
             if S2:
                 # tap (dy, dx) = divmod(t, 3): parity plane (dy != 1, dx != 1) -- plane index as the waves load them, 2 py + px -- as the
                 # immediate offset; the (row, column) offset (dy >= 1, dx >= 1) picks one of the block's four swizzled addresses, each of
@@ -1228,7 +1317,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
                 ops += [(12 + 2 * k + h, "D", k, h) for k in range(NG) for h in range(2)]
             elif (S2 or F8) and not abl & 2:
                 ops += [(DPOS[i_], "D", g_, 0) for i_, g_ in enumerate(DMA_TAPS[t])]
-            elif not S2 and not F8 and not DMA_FRONT and t < NG and not abl & 2:
+            elif not S2 and not F8 and not DMA_FRONT and t < (NDMA if PM else NG) and not abl & 2:
                 ops += [(DPOS[h], "D", t, h) for h in range(PPW)]
             if in_stream_res and last:
                 for g, j in enumerate(res_groups[t]):
@@ -1288,7 +1377,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
                     if op[3] == 0:
                         emit_set_a_base("a_ld", t + LOOK)
                     emit_load_a((t + LOOK) % (LOOK + 1), op[3], s2("a_ld"), 0)
-                elif op[1] == "D" and KS == 1:
+                elif op[1] == "D" and (KS == 1 or PM):
                     emit_dma_m0(op[2], op[3])
                     post.append((op[2], op[3]))
                 elif op[1] == "D":
@@ -1304,7 +1393,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
                     if jr:
                         body.append(f"v_add_u32 {T[4]}, {16 * jr}, {T[4]}")
                     body += [f"v_min_i32 {T[4]}, {s('rlim')}, {T[4]}", f"v_mul_lo_u32 {T[4]}, {T[4]}, {s('res_ld')}", f"v_add_u32 {T[4]}, {T[4]}, {T[7]}"]
-                    body += [f"global_load_dwordx2 {'a' if F8 else 'v'}[{rreg(3 * jr + i)}:{rreg(3 * jr + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}" for i in range(3)]
+                    body += [f"global_load_dwordx2 {'a' if F8 or PM else 'v'}[{rreg(3 * jr + i)}:{rreg(3 * jr + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}" for i in range(3)]
                     cold.append((lx, body, ld))
             # one wait per PAIR of elements (fragments n and n + 1 have landed): the stream is bound by instruction issue
             allowed = min(PD, NE - 1 - n)
@@ -1336,10 +1425,10 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_cselect_b32 {s('tmp0')}, 0, {s('tmp0')}", "next buffer")
     E(f"s_sub_i32 {s('tmp1')}, {s('tmp0')}, {s('buf')}")
     E(f"s_mul_i32 {s('tmp1')}, {s('tmp1')}, {CHUNK}")
-    if S2 or F8:
-        E(f"s_mov_b32 {s('delta0')}, {s('tmp1')}", "stride-2 / fp8 families: the row offsets are not accumulated in the address registers")
+    if S2 or F8 or (PM and WFIX):
+        E(f"s_mov_b32 {s('delta0')}, {s('tmp1')}", "stride-2 / fp8 / fixed-width families: the row offsets are not accumulated in the address registers")
     else:
-        E(f"s_lshl_b32 {s('tmp2')}, {s('Wp')}, 5", "2 Wp * 16: back from kernel row 2 to row 0")
+        E(f"s_lshl_b32 {s('tmp2')}, {s('Wp')}, {7 if PM else 5}", "2 Wp * 16 (pixel-major rows: * 64): back from kernel row 2 to row 0")
         E(f"s_sub_i32 {s('delta0')}, {s('tmp1')}, {s('tmp2')}")
     E(f"s_mov_b32 {s('buf')}, {s('tmp0')}")
     E(f"s_mov_b32 {s('first')}, 0")
@@ -1604,8 +1693,10 @@ def main():
             variants += [(True, True, a, False) for a in (1, 2, 4, 7, 8)]
         if nb == 13:
             variants += [(False, False, 0, True), (True, False, 0, True), (True, True, 0, True)]     # fp8-weight stream
+        if DIAG and nb == "pm13w40":
+            variants += [(True, True, a, False) for a in (1, 2, 4, 8)]
         if DIAG and nb in (7, 13):
-            variants += [(True, True, a, False) for a in (1, 2, 3, 4, 7, 8)]
+            variants += [(True, True, a, False) for a in (1, 2, 3, 4, 7, 8) + ((16, 32) if nb == 13 else ())]
         for RES, stamped, abl, w8 in variants:
             name = f"conv3x3_pl_asm_{FAMILY}_res{int(RES)}" + ("_w8" if w8 else "") + ("_stamped" if stamped else "") + (f"_abl{abl}" if abl else "")
             text += [f"\t.globl\t{name}", "\t.p2align\t8", f"\t.type\t{name},@function"]

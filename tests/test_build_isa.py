@@ -137,13 +137,13 @@ def test_generated_planar_assembly_fits_its_occupancy(tmp_path):
     kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S)
     names = [k for k, _ in kernels]
     for want in ("conv3x3_pl_asm_nb13_res0", "conv3x3_pl_asm_nb13_res1", "conv3x3_pl_asm_nb7_res1", "conv3x3_pl_asm_nb8_res0", "conv3x3_pl_asm_nb13_res1_w8",
-                 "conv3x3_pl_asm_s2nb13_res0", "conv3x3_pl_asm_f8nb13_res0", "conv3x3_pl_asm_f8nb13_res1"):     # round 3: stride-2 and fp8 families
+                 "conv3x3_pl_asm_s2nb13_res0", "conv3x3_pl_asm_f8nb13_res0", "conv3x3_pl_asm_f8nb13_res1", "conv3x3_pl_asm_pm13_res0", "conv3x3_pl_asm_pm13_res1"):     # round 3: stride-2 and fp8 families
         assert want in names
     for name, body in kernels:
         regs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1))
         sgpr = int(re.search(r"\.amdhsa_next_free_sgpr (\d+)", body).group(1))
-        occ = 1 if "nb13_" in name else 2                   # (nb13, s2nb13, f8nb13: one workgroup per CU)
+        occ = 1 if ("nb13_" in name or "pm13_" in name) else 2      # (nb13, pm13, s2nb13, f8nb13: one workgroup per CU)
         assert regs <= 512 // occ and lds * occ <= 160 * 1024 and sgpr <= 102, (name, regs, lds, sgpr)
         assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) == 0      # no scratch: every memory operation is counted by hand
     # every hand-counted wait fits the 6-bit vmcnt field, and no kernel relies on a compiler: there is none

@@ -404,7 +404,7 @@ PL_CASES = [
 
 
 @pytest.mark.parametrize("case", PL_CASES)
-@pytest.mark.parametrize("nb", ["13asm", "7asm", "8asm", 13, 10, 7])
+@pytest.mark.parametrize("nb", ["13asm", "13slot-asm", "13pm-asm", "7asm", "8asm", 13, 10, 7])
 def test_planar_conv3x3_matches_reference(lib, case, nb, monkeypatch):
     """aq_conv3x3_pl vs F.conv2d on bf16-rounded operands; input, output and shortcut are channel slices of wider tensors; every
     pixel-block count of the kernel, tiles that end inside images, at image seams and past the end of the batch.  "13asm", "7asm", "8asm"
@@ -413,6 +413,11 @@ def test_planar_conv3x3_matches_reference(lib, case, nb, monkeypatch):
     from aquaculture_amd import engine
     B, H, W, cin, c, resmode, act = case
     monkeypatch.setenv("AQ_PL_ASM", "1" if isinstance(nb, str) else "0")
+    # "13asm": what the engine runs -- the pixel-major builds for 20- and 40-wide images (pm13w20 / pm13w40), the slot-major build (nb13)
+    # elsewhere; "13slot-asm": nb13 at every width; "13pm-asm": the any-width pixel-major build (pm13) at every width
+    if nb in ("13slot-asm", "13pm-asm"):
+        monkeypatch.setenv("AQ_PL_PM", "0" if nb == "13slot-asm" else "2")
+        nb = "13asm"
     if isinstance(nb, str) and not lib.aq_conv3x3_pl_asm_family(int(nb[:-3])):
         pytest.skip("experimental assembly family: built only with AQ_GEN_EXPERIMENTAL=1")
     nb = int(nb[:-3]) if isinstance(nb, str) else nb

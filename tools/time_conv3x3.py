@@ -93,8 +93,9 @@ def main():
                     print(f"{c}ch planar NB={nb}: {err}")
         os.environ.pop("AQ_PL_NB", None)
         os.environ.pop("AQ_PL_ASM", None)
-        asm_abl = [f"asm{nb}:{v}" for nb in (7, 13) for v in a.abl.split(",") if v]
-        for sab in (["asm13", "asm7", "asm8"] + asm_abl + [16] + [16 + int(v) for v in a.abl.split(",") if v and int(v) < 8] if a.stamp else []):
+        fams = [nb for nb in (13, 7, 8) if lib.aq_conv3x3_pl_asm_family(nb) == 1]       # (7, 8: only in AQ_GEN_EXPERIMENTAL=1 builds)
+        asm_abl = [f"asm{nb}:{v}" for nb in (7, 13) if nb in fams for v in a.abl.split(",") if v]
+        for sab in ([f"asm{nb}" for nb in fams] + asm_abl + [16] + [16 + int(v) for v in a.abl.split(",") if v and int(v) < 8] if a.stamp else []):
             buf = torch.zeros(1 << 16, dtype=torch.int64, device=dev)
             E._check(lib.aq_debug_conv_stamp(buf.data_ptr(), buf.numel() * 8))
             if isinstance(sab, str):
