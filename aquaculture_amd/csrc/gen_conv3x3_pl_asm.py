@@ -125,6 +125,9 @@ def configure(nb):
     g["LDS_BYTES"] = BIAS_OFF + 4096
     # where in a tap's element list its LDS-DMA instructions go (one region-row group per tap, PPW planes): behind the weight loads
     g["DPOS"] = [12, 12 + (2 * NB - 12) // 2]
+    import os as _os
+    if PM:
+        g["DPOS"] = [int(x) for x in _os.environ.get("AQ_GEN_DPOS", "14,22").split(",")]
     if S2:
         g["GROUPS"] = list(range(0, ROWS, 64))             # groups of 64 rows whose source pixels are computed (then dealt to the instructions)
         g["NG"] = len(GROUPS)
@@ -1311,7 +1314,11 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             assert nxt == NB and kD1 + 2 < 2 * NB
 
         def tap_ops(t, last=True):
-            ops = [(2 * k + 1, "A", (t + LOOK) % NT, k) for k in range(NLOAD) if not abl & 1]
+            import os as _os
+            # spacing of a tap's weight loads, in elements.  Pixel-major family, stream cycles (192 ch / 384 ch): every element 89.6 k / 81.1 k,
+            # every 2nd 87.1 k / 80.4 k, every 3rd 85.5 k / 80.7 k, every 4th (with the LDS-DMA at elements 14 and 22) 84.6 k / 79.8 k
+            astride = int(_os.environ.get("AQ_GEN_ASTRIDE", "4")) if PM else int(_os.environ.get("AQ_GEN_ASTRIDE_S2", "2")) if S2 else 2
+            ops = [(astride * k + 1, "A", (t + LOOK) % NT, k) for k in range(NLOAD) if not abl & 1]
             if DMA_FRONT and t == 0 and not abl & 2:
                 assert 12 + 2 * NG <= 2 * NB
                 ops += [(12 + 2 * k + h, "D", k, h) for k in range(NG) for h in range(2)]

@@ -27,10 +27,12 @@ def main():
     ap.add_argument("--scenes", type=int, default=0, help="scene mode: write this many 6144x6144 scene rasters (36 tiles each) and sweep them "
                                                           "with --tile-scenes instead of a jpeg directory")
     ap.add_argument("--jpeg-decode", default="auto", choices=("auto", "host", "split"))
+    ap.add_argument("--noise", type=float, default=0.0, help="Gaussian sensor noise (sigma, 8-bit levels) added before the JPEG encoder: the synthetic tiles are smooth "
+                                                             "(0.3 bit per pixel at q75); sigma 10 gives 1.1 bpp, about what detailed aerial imagery compresses to")
     ap.add_argument("--json", default="", help="append this run's numbers to a JSON file (profiles/e2e_latest.json: bench.py quotes it as `e2e`)")
     a = ap.parse_args()
     from aquaculture_amd import checkpoint, tiles
-    jp = os.path.join(a.dir, f"jpegs_{a.size}")
+    jp = os.path.join(a.dir, f"jpegs_{a.size}" + (f"_n{a.noise:g}" if a.noise else ""))
     if a.scenes:
         import numpy as np
         from PIL import Image
@@ -49,6 +51,10 @@ def main():
     elif not os.path.isdir(jp) or len(os.listdir(jp)) < a.n:
         os.makedirs(jp, exist_ok=True)
         base = [tiles.synthetic_tile(i, a.size) for i in range(64)]      # 64 distinct tiles, re-encoded under N names
+        if a.noise:
+            import numpy as np
+            rng = np.random.default_rng(7)
+            base = [np.clip(t + rng.normal(0, a.noise, t.shape), 0, 255).astype(np.uint8) for t in base]
         from PIL import Image
         def wr(i):
             Image.fromarray(base[i % 64]).save(os.path.join(jp, tiles.tile_name(i)), format="JPEG", quality=75)
@@ -91,7 +97,9 @@ def main():
         if doc.get("library_source_digest") != digest:
             doc = {"library_source_digest": digest, "what": "yolov5/detect.py end to end on one MI355X: image directory -> label files "
                    "(decode, H2D, device letterbox, engine, NMS, D2H, rescale, %g formatting, one file per tile with detections)", "runs": []}
-        doc["runs"].append({"input": ("6144x6144 scene rasters, tiles cut on the device (--tile-scenes)" if a.scenes else f"{a.size}x{a.size} jpegs (q75)"),
+        kb = sum(os.path.getsize(os.path.join(jp, f)) for f in os.listdir(jp)[:64]) / 64 / 1024 if not a.scenes else 0
+        doc["runs"].append({"input": ("6144x6144 scene rasters, tiles cut on the device (--tile-scenes)" if a.scenes else
+                                      f"{a.size}x{a.size} jpegs (q75, {kb:.0f} KB each = {kb * 8192 / a.size / a.size:.2f} bit per pixel" + (f", noise sigma {a.noise:g}" if a.noise else "") + ")"),
                             "images": a.n, "decode_workers": a.workers, "decode": "threads" if a.decode_threads else "worker processes", "jpeg_decode": a.jpeg_decode,
                             "batch_size": a.batch_size, "precision": a.precision, "images_per_s_steady": steady, "images_per_s_whole_sweep": whole,
                             "images_per_s_wall_incl_start": round(a.n / dt, 1), "host_cpus": os.cpu_count()})
