@@ -604,7 +604,8 @@ def emit_a_stream_base(dst, tile_s, c_s):
     E(f"s_sub_u32 {s('tmp0')}, {s('tmp0')}, 1")
     E(f"s_and_b32 {s('tmp0')}, {tile_s}, {s('tmp0')}", "mt")
     E(f"s_lshl_b32 {s('tmp0')}, {s('tmp0')}, 2")
-    E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {s('wave')}")
+    if not ABL[0] & 64:                                    # (timing-only ablation 64: all four waves stream wave 0's weights -- three of four loads hit the CU's L1)
+        E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {s('wave')}")
     E(f"s_mul_i32 {s('tmp0')}, {s('tmp0')}, {s('CC')}")
     E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {c_s}")
     E(f"s_mul_i32 {s('tmp1')}, {s('tmp0')}, {NT * STEP_B}")
@@ -1701,7 +1702,7 @@ def main():
         if nb == 13:
             variants += [(False, False, 0, True), (True, False, 0, True), (True, True, 0, True)]     # fp8-weight stream
         if DIAG and nb == "pm13w40":
-            variants += [(True, True, a, False) for a in (1, 2, 4, 8)]
+            variants += [(True, True, a, False) for a in (1, 2, 4, 8, 64)]
         if DIAG and nb in (7, 13):
             variants += [(True, True, a, False) for a in (1, 2, 3, 4, 7, 8) + ((16, 32) if nb == 13 else ())]
         for RES, stamped, abl, w8 in variants:

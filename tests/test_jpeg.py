@@ -116,3 +116,33 @@ def test_device_pixel_half_equals_pillow(jpeg_lib, lib):
         for i, data in enumerate(files):
             ref = _pil(data)
             assert np.array_equal(got[i], ref), f"{H}x{W} image {i}: {int((got[i] != ref).sum())} bytes differ"
+
+
+def test_entropy_decoder_survives_mutated_files_under_asan(tmp_path):
+    """The host decoder parses files it did not write: tests/fuzz_jpeg.c, built with AddressSanitizer + UBSan (CPU build only, as the pool
+    asks), decodes thousands of mutated baseline JPEGs into an output buffer of EXACTLY the size the header promises -- flips, truncations,
+    damaged tables and lengths, stray markers, runs of 0xFF: every one is either decoded or rejected with a code, none reads or writes out
+    of bounds."""
+    import shutil
+    import subprocess
+    from aquaculture_amd import tiles
+    cc = shutil.which("gcc")
+    if not cc:
+        pytest.skip("no gcc")
+    rng = np.random.default_rng(1)
+    files = []
+    for name, img, kw in (("tile.jpg", tiles.synthetic_tile(3, 256), dict(quality=75)),
+                          ("noise.jpg", rng.integers(0, 255, (100, 150, 3), dtype=np.uint8), dict(quality=50)),
+                          ("restart.jpg", rng.integers(0, 255, (64, 64, 3), dtype=np.uint8), dict(quality=90, restart_marker_blocks=3))):
+        (tmp_path / name).write_bytes(_jpeg(img, **kw))
+        files.append(str(tmp_path / name))
+    exe = str(tmp_path / "fuzz_jpeg")
+    r = subprocess.run([cc, "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe, os.path.join(ROOT, "tests", "fuzz_jpeg.c"),
+                        os.path.join(ROOT, "aquaculture_amd", "csrc", "jpeg_coef.c")], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("this gcc has no sanitizer runtime")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe, "1500"] + files, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fuzz_jpeg:" in r.stdout, r.stdout[-500:] + r.stderr[-3000:]
+    decoded, rejected = (int(x) for x in __import__("re").findall(r"(\d+) decoded, (\d+) rejected", r.stdout)[0])
+    assert decoded > 500 and rejected > 500          # the mutations reach both outcomes
