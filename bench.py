@@ -373,7 +373,7 @@ def main() -> int:
             pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": f"conv3x3_pl_asm_nb13 (planar 3x3/s1, assembly build) / conv3x3_pl_asm_s2nb13 (planar 3x3/s2, assembly) / downblock_kernel / conv_igemm_kernel (3x3 convs, kernel and tile shape autotuned per layer) on the {len(idx3)} 3x3 "
+                "kernel": f"conv3x3_pl_asm_pm13w40 / pm13w20 (planar 3x3/s1, pixel-major assembly builds; nb13 = slot-major for other widths) / conv3x3_pl_asm_s2nb13 (planar 3x3/s2, assembly) / downblock_kernel / conv_igemm_kernel (3x3 convs, kernel and tile shape autotuned per layer) on the {len(idx3)} 3x3 "
                           f"layers launched as plain convs ({len(idxb)} Bottlenecks run in bottleneck_kernel, reported separately)",
                 "launches_per_step": len(idx3), "avg_launch_ms": round(1e3 * t3 / len(idx3), 4),
                 "flops_per_step": f3, "steps_timed": calls,

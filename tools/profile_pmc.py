@@ -222,7 +222,7 @@ def main():
                 cfgs = {k: [v[i] for i, o in enumerate(plan.ops) if o.kind == spec.OP_CONV and o.meta.get("class") == "conv3x3"] for k, v in tc.items()}
             except (OSError, ValueError):
                 pass
-            json.dump({"kernel": f"conv3x3_pl_asm_nb13 / conv3x3_pl_asm_s2nb13 / downblock_kernel / conv_igemm_kernel on the {len(r3)} 3x3 layers launched as plain convs", "batch": a.batch, "launches_averaged": len(r3),
+            json.dump({"kernel": f"conv3x3_pl_asm_pm13w40 / pm13w20 (nb13) / conv3x3_pl_asm_s2nb13 / downblock_kernel / conv_igemm_kernel on the {len(r3)} 3x3 layers launched as plain convs", "batch": a.batch, "launches_averaged": len(r3),
                        "library_source_digest": lib_digest, "conv3x3_configs": cfgs,
                        "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr,
                        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 counts 128-B "
