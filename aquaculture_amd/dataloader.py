@@ -282,6 +282,8 @@ class LoadImages:
         env = dict(os.environ)
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):     # one decoder = one core: no BLAS / OpenMP teams in the workers
+            env.setdefault(var, "1")
         procs = [subprocess.Popen([sys.executable, "-m", "aquaculture_amd._decode_worker", shm.name, str(n_slots), str(H0), str(W0)] + (["coef"] if coef else []),
                                   stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1, env=env) for _ in range(nproc)]
         try:
@@ -307,9 +309,14 @@ class LoadImages:
                 return paths_, i_, sent_
 
             ahead = None
+            trace = os.environ.get("AQ_TRACE_LOADER") == "1"     # per batch: ms spent dispatching, waiting for the decoders' answers, and in the consumer
+            import time as _time
+            t_out = _time.perf_counter()
             for k in range(len(starts)):
+                t_a = _time.perf_counter()
                 paths, i, sent = ahead if ahead is not None else dispatch(k, True)
                 ahead = dispatch(k + 1, False) if k + 1 < len(starts) else None
+                t_b = _time.perf_counter()
                 for w in range(nproc):
                     for _ in range(sent[w]):
                         ans = procs[w].stdout.readline()
@@ -324,6 +331,11 @@ class LoadImages:
                     step = max(1, (n + ncopy - 1) // ncopy)
                     list(copiers.map(lambda a: stage[i][a:min(a + step, n)].copy_(ring_t[i][a:min(a + step, n)]), range(0, n, step)))
                     batch = stage[i][:n]
+                if trace:
+                    t_c = _time.perf_counter()
+                    print(f"loader batch {k}: consumer {1e3 * (t_a - t_out):.1f} ms, dispatch {1e3 * (t_b - t_a):.1f} ms (next batch {'sent' if ahead else 'NOT sent: buffer busy'}), "
+                          f"answers {1e3 * (t_c - t_b):.1f} ms", flush=True)
+                    t_out = _time.perf_counter()
                 yield paths, batch, [(H0, W0)] * len(paths), i
                 if ahead is None and k + 1 < len(starts):
                     ahead = dispatch(k + 1, True)            # its buffer was still in use a moment ago: wait for it now

@@ -123,6 +123,9 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     weights = weights[0] if isinstance(weights, (list, tuple)) else weights
     precision = precision or ("bf16" if half else "fp32")
 
+    # (yolov5/detect.py has set OMP_NUM_THREADS / OPENBLAS_NUM_THREADS / MKL_NUM_THREADS to 1 before numpy and torch were loaded: the CPU
+    # side of the sweep wants no thread teams; here the same for a caller that imported torch first)
+    torch.set_num_threads(max(1, int(os.environ.get("AQ_CPU_THREADS", "1"))))
     rank, world, local = aqdist.init()
     multi = world > 1 or aqdist.forced()                  # the collectives run (AQ_DIST_FORCE=1: also in a world of one -- RCCL on a one-GPU box)
     dev = int(device) if str(device).strip().isdigit() else local % max(torch.cuda.device_count(), 1)
