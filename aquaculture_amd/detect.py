@@ -199,12 +199,15 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                 cnt = counts_h.numpy()
                 det_all = dets_h.numpy()
                 written = []
+                same = all(sh == shapes0[0] for sh in shapes0)       # the pinned path: one original size per batch -> one numpy pass for all tiles
+                if same:
+                    rows_all, offs = postprocess.batch_rows(det_all, cnt[:len(paths)], (H, W), shapes0[0])
                 for b, p in enumerate(paths):
                     det = det_all[b, : cnt[b]]
                     ndet += det.shape[0]
-                    rows = postprocess.detections_to_rows(det, (H, W), shapes0[b])
+                    rows = rows_all[offs[b]:offs[b + 1]] if same else postprocess.detections_to_rows(det, (H, W), shapes0[b])
                     if save_txt and rows.shape[0]:       # no detections => no file (the consumer relies on it)
-                        f = open(os.path.join(labels_dir, Path(p).stem + ".txt"), "wb")     # "wb": a tile processed again after a crash leaves the same bytes
+                        f = open(os.path.join(labels_dir, os.path.splitext(os.path.basename(p))[0] + ".txt"), "wb")     # "wb": a tile processed again after a crash leaves the same bytes
                         f.write(format_label_rows(rows, save_conf))
                         f.flush()
                         written.append(f)

@@ -57,6 +57,34 @@ def detections_to_rows(det: np.ndarray, img1_shape, img0_shape) -> np.ndarray:
     return rows[::-1].copy()   # `for *xyxy, conf, cls in reversed(det)`
 
 
+def batch_rows(det_all: np.ndarray, counts: np.ndarray, img1_shape, img0_shape):
+    """detections_to_rows for a whole batch of tiles of ONE original size in a single pass: det_all [B, max_det, 6], counts [B] ->
+    (rows float32 [N, 6] with every tile's rows in file order, tile after tile; offsets int64 [B + 1]).  The arithmetic is elementwise,
+    so the values equal the per-tile function's bit for bit; what it saves is ~20 numpy calls per tile on threads that share one GIL."""
+    counts = np.asarray(counts, dtype=np.int64)
+    B = counts.shape[0]
+    offsets = np.zeros(B + 1, np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    n = int(offsets[-1])
+    if n == 0:
+        return np.zeros((0, 6), F32), offsets
+    valid = np.arange(det_all.shape[1])[None, :] < counts[:, None]
+    det = np.asarray(det_all[:B], dtype=F32)[valid]                     # [N, 6], tile-major, descending confidence inside a tile
+    xyxy = np.rint(scale_boxes(img1_shape, det[:, :4], img0_shape)).astype(F32)
+    h0, w0 = F32(img0_shape[0]), F32(img0_shape[1])
+    rows = np.empty((n, 6), F32)
+    rows[:, 0] = det[:, 5]
+    rows[:, 1] = ((xyxy[:, 0] + xyxy[:, 2]) / F32(2)) / w0
+    rows[:, 2] = ((xyxy[:, 1] + xyxy[:, 3]) / F32(2)) / h0
+    rows[:, 3] = (xyxy[:, 2] - xyxy[:, 0]) / w0
+    rows[:, 4] = (xyxy[:, 3] - xyxy[:, 1]) / h0
+    rows[:, 5] = det[:, 4]
+    tile = np.repeat(np.arange(B), counts)
+    pos = np.arange(n)
+    rev = offsets[tile] + (counts[tile] - 1) - (pos - offsets[tile])     # `for *xyxy, conf, cls in reversed(det)`, per tile
+    return rows[rev], offsets
+
+
 def format_rows(rows: np.ndarray, save_conf: bool = True) -> str:
     """Text of one label file.  Each value through ``%g`` of the double that equals the fp32 value
     (one C-level format call for the whole file: the same conversions as upstream's per-line ``%``)."""

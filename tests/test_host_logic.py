@@ -166,3 +166,28 @@ def test_shipped_tuned_tables_match_the_plans():
         for c, o in zip(cfgs, plan.ops):
             assert (c == -1) == (o.kind != spec.OP_CONV) or c >= -1, (key, o.name, c)
             assert o.kind == spec.OP_CONV or c == -1, (key, o.name, c)
+
+
+def test_batch_postprocess_equals_the_per_tile_one_bit_for_bit():
+    """postprocess.batch_rows (one numpy pass per batch, what the CLI's writer threads use) against detections_to_rows per tile: empty tiles,
+    full tiles, boxes outside the image, three original sizes."""
+    import numpy as np
+    from aquaculture_amd import postprocess as P
+    rng = np.random.default_rng(0)
+    B, M = 9, 50
+    cnt = rng.integers(0, M + 1, B)
+    cnt[3], cnt[5] = 0, M
+    det = np.zeros((B, M, 6), np.float32)
+    det[..., :2] = rng.uniform(-20, 700, (B, M, 2))
+    det[..., 2:4] = det[..., :2] + rng.uniform(0, 300, (B, M, 2))
+    det[..., 4] = rng.uniform(0, 1, (B, M))
+    det[..., 5] = rng.integers(0, 5, (B, M))
+    for shp in ((1024, 1024), (640, 640), (500, 700)):
+        rows, offs = P.batch_rows(det, cnt, (640, 640), shp)
+        assert offs[-1] == cnt.sum() == rows.shape[0]
+        for b in range(B):
+            want = P.detections_to_rows(det[b, :cnt[b]], (640, 640), shp)
+            got = rows[offs[b]:offs[b + 1]]
+            assert want.shape == got.shape and np.array_equal(want.view(np.uint32), got.view(np.uint32)), (shp, b)
+    rows, offs = P.batch_rows(det, np.zeros(B, np.int64), (640, 640), (640, 640))
+    assert rows.shape == (0, 6) and not offs.any()
