@@ -2,8 +2,10 @@
 
 Started by dataloader.LoadImages.pinned_batches as `python -m aquaculture_amd._decode_worker <shm name> <n_slots> <H> <W> [coef]`:
 a plain child process (never a fork of the GPU process) that imports only the standard library, numpy and PIL -- no torch, no HIP.
-Protocol, one line each way: parent -> `<slot> <path>`; worker decodes the image as RGB uint8 straight into slot `slot` of the
-shared-memory ring [n_slots][H][W][3] and answers `ok <slot>` or `err <slot> <message>`.  EOF on stdin ends the worker.
+Protocol: parent -> `<slot> <path>` per image, then `flush` after a batch's last one; the worker decodes each image as RGB uint8 straight
+into slot `slot` of the shared-memory ring [n_slots][H][W][3] and answers the `flush` with ONE line, `ok <images decoded>` or
+`err <slot> <path>: <message>` for the first failure of the batch (one pipe read per worker and batch on the parent's single thread, not one
+per image).  EOF on stdin ends the worker.
 
 [UPSTREAM utils/dataloaders.py LoadImages.__next__ -> cv2.imread]: same decoded pixels as the threaded path (PIL / libjpeg-turbo).
 
@@ -36,9 +38,17 @@ def main() -> int:
     else:
         ring = np.ndarray((n_slots, H, W, 3), dtype=np.uint8, buffer=shm.buf)
     out = sys.stdout
+    done, failed = 0, None             # answers are held back until the parent's "flush" line: one write + one read per worker and batch
     for line in sys.stdin:
         line = line.rstrip("\n")
         if not line:
+            continue
+        if line == "flush":
+            out.write(failed if failed is not None else f"ok {done}\n")
+            out.flush()
+            done, failed = 0, None
+            continue
+        if failed is not None:         # the batch is lost already: skip the rest of it
             continue
         slot_s, path = line.split(" ", 1)
         slot = int(slot_s)
@@ -51,8 +61,7 @@ def main() -> int:
                     raise ValueError(f"split JPEG decoder status {rc} (-1 unsupported coding, -2 corrupt data)")
                 if (info.width, info.height) != (W, H):
                     raise ValueError(f"{info.height}x{info.width} differs from the first image {H}x{W}; mixed sizes need batches()")
-                out.write(f"ok {slot}\n")
-                out.flush()
+                done += 1
                 continue
             with Image.open(path) as im:
                 if im.mode != "RGB":
@@ -61,10 +70,9 @@ def main() -> int:
                     raise ValueError(f"{im.size[1]}x{im.size[0]} differs from the first image {H}x{W}; mixed sizes need batches()")
                 im.load()
                 ring[slot] = np.asarray(im)
-            out.write(f"ok {slot}\n")
-        except Exception as e:  # reported to the parent, which raises
-            out.write(f"err {slot} {type(e).__name__}: {e}\n".replace("\r", " "))
-        out.flush()
+            done += 1
+        except Exception as e:  # reported to the parent (at the batch's flush), which raises
+            failed = f"err {slot} {path}: {type(e).__name__}: {e}".replace("\r", " ").replace("\n", " ") + "\n"
     del ring
     shm.close()
     return 0

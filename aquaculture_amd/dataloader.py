@@ -305,6 +305,7 @@ class LoadImages:
                     sent_[w] += 1
                 for w in range(nproc):
                     if sent_[w]:
+                        procs[w].stdin.write("flush\n")          # the worker answers once per batch: "ok <count>" or the first error
                         procs[w].stdin.flush()
                 return paths_, i_, sent_
 
@@ -318,12 +319,15 @@ class LoadImages:
                 ahead = dispatch(k + 1, False) if k + 1 < len(starts) else None
                 t_b = _time.perf_counter()
                 for w in range(nproc):
-                    for _ in range(sent[w]):
-                        ans = procs[w].stdout.readline()
-                        if not ans:
-                            raise RuntimeError(f"decode worker {w} died (exit code {procs[w].poll()})")
-                        if ans.startswith("err"):
-                            raise ValueError(ans.rstrip().split(" ", 2)[2])
+                    if not sent[w]:
+                        continue
+                    ans = procs[w].stdout.readline()
+                    if not ans:
+                        raise RuntimeError(f"decode worker {w} died (exit code {procs[w].poll()})")
+                    if ans.startswith("err"):
+                        raise ValueError(ans.rstrip().split(" ", 2)[2])
+                    if ans.split() != ["ok", str(sent[w])]:
+                        raise RuntimeError(f"decode worker {w}: unexpected answer {ans!r} to a batch of {sent[w]}")
                 if registered:
                     batch = ring_t[i][:len(paths)]
                 else:                                        # parallel memcpy (releases the GIL) into the hipHostMalloc buffer
