@@ -296,9 +296,12 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                 # split JPEG decode (Huffman on the host, the rest on the GPU) when every file of this part is a baseline 4:2:0 JPEG
                 split = False
                 if jpeg_decode != "host" and not decode_threads:
-                    split = all_split[0] or all(r is not None for r in sub.scan_split_decodable())
+                    scan = None if all_split[0] else sub.scan_split_decodable()
+                    split = all_split[0] or all(r is not None for r in scan)
                     if jpeg_decode == "split" and not split:
-                        raise ValueError("--jpeg-decode split: some images are not baseline 4:2:0 JPEGs (use auto or host)")
+                        bad = [sub.files[i] for i, r in enumerate(scan) if r is None]
+                        raise ValueError(f"--jpeg-decode split: {len(bad)} of {len(scan)} images are not baseline 4:2:0 JPEGs the split decoder reads "
+                                         f"(use auto or host): {', '.join(bad[:3])}{' ...' if len(bad) > 3 else ''}")
                 if split and not split_note[0]:
                     split_note[0] = True
                     log(f"jpeg decode: split (entropy decoding in {sub.workers} worker processes, IDCT / upsampling / colour conversion on the GPU)")

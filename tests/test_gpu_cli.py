@@ -344,3 +344,23 @@ def test_cli_with_the_collectives_on_rccl_writes_the_same_labels(workdir, lib):
     a = {f: open(ref / f, "rb").read() for f in sorted(os.listdir(ref))}
     b = {f: open(lab / f, "rb").read() for f in sorted(os.listdir(lab))}
     assert a and a == b
+
+
+def test_cli_names_the_file_a_decode_worker_rejects(workdir, lib, tmp_path):
+    """A file whose frame header passes the directory scan but whose scan header names a Huffman table that was never defined: the worker's
+    error reaches the parent at the batch's flush, the sweep stops with a non-zero exit code and the message names the file -- in both decode
+    modes (libjpeg refuses such a file as well; upstream: `assert im0 is not None, 'Image Not Found'`)."""
+    import shutil
+    src = tmp_path / "jpegs"
+    shutil.copytree(workdir / "jpegs", src)
+    victim = sorted(os.listdir(src))[3]
+    data = bytearray((src / victim).read_bytes())
+    sos = data.index(b"\xff\xda")
+    assert data[sos + 4] == 3                                     # three components: (id, tables) pairs follow
+    data[sos + 6] = 0x33                                          # component 1: DC table 3 / AC table 3 -- neither exists
+    (src / victim).write_bytes(bytes(data))
+    for mode in ("split", "host"):
+        cmd = [sys.executable, os.path.join(ROOT, "yolov5", "detect.py"), "--weights", str(workdir / "multilabel_farms_synth.pt"), "--source", str(src),
+               "--nosave", "--save-txt", "--save-conf", "--project", str(tmp_path / "runs"), "--name", "bad_" + mode, "--batch-size", "4", "--half", "--jpeg-decode", mode]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+        assert r.returncode != 0 and victim in (r.stderr + r.stdout), (mode, r.stdout[-1500:], r.stderr[-1500:])
