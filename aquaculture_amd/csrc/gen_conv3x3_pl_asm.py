@@ -29,6 +29,7 @@ import sys
 # registers fetched under the last chunk.  "nb7" / "nb8": TWO workgroups per CU (<= 256 registers per wave, <= 80 KB LDS), so that one
 # workgroup's chunk tops, epilogue and prologue run under the other's MFMAs; two ring buffers of 256 region rows, and the residual is
 # fetched at the start of the epilogue into registers the stream has finished with (weight set 2 and the B ring).
+# (Options measured in round 2 and REMOVED from the generator in round 3 -- the notes are the record of why.)
 # SPLIT = s > 0: a tile's LAST chunk has its own code: all 18 half-taps for pixel blocks 0 .. s - 1 first, then again for blocks s .. NB - 1
 # with the epilogue of the first group (accumulators final) issued between those MFMAs -- the epilogue is VALU-bound (v_exp + v_rcp at
 # quarter rate, 10 k cycles per tile) and one wave per SIMD has nothing else to overlap it with; this way it also pays for workgroups
@@ -68,10 +69,10 @@ import sys
 # (four address registers per pixel block -- one per (row, column) offset of the taps, since an XOR does not commute with the add).
 # ROWS = 304 = 208 pixels + row pads + an image seam + one-sided halo for W = 20 and 40; two ring buffers (2 x 76 KB + bias = 156 KB).
 CONFIGS = {
-    13: dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False),    # SPLIT=7, DMA_FRONT: measured slower, below
-    7: dict(NB=7, PD=8, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False),
-    8: dict(NB=8, PD=7, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False),
-    "s2nb13": dict(NB=13, PD=8, ROWS=304, RING=2, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=1, S2=True),
+    13: dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, KS=2, S2=False),
+    7: dict(NB=7, PD=8, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, KS=2, S2=False),
+    8: dict(NB=8, PD=7, ROWS=256, RING=2, OCC=2, RES_EARLY=False, LOOK=2, KS=2, S2=False),
+    "s2nb13": dict(NB=13, PD=8, ROWS=304, RING=2, OCC=1, RES_EARLY=True, LOOK=2, KS=1, S2=True),
     # F8 = the fp8 family of the stride-1 kernel (BASELINE.json configs[3], "fp8 weights (CDNA4 fp8 MFMA)"): OCP e4m3 on BOTH MFMA
     # operands, v_mfma_f32_16x16x128_f8f6f4 (33.5 cycles for 4x the K of the 16-cycle bf16 form: tools/ubench/mfma_f8_layout.hip).
     # A 64-channel chunk is 64 BYTES per pixel, so K = 128 spans two TAPS: MFMA step p multiplies taps 2 p and 2 p + 1 (step 4: tap 8
@@ -82,7 +83,7 @@ CONFIGS = {
     # fragment address is computed where it is read (add, shift, and, xor): nine tap offsets would cost 117 address registers.
     # LOOK = 4: five weight sets, one per step, each reloaded for the next chunk as soon as its step is done.  The residual waits in
     # the accumulator half of the register file (78 of the 100 registers free there).
-    "f8nb13": dict(NB=13, PD=4, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=4, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=1, S2=False, F8=True),
+    "f8nb13": dict(NB=13, PD=4, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=4, KS=1, S2=False, F8=True),
     # PM = the PIXEL-MAJOR build of the stride-1 bf16 kernel (round 3).  Family nb13's slot-major planes make every lane of an LDS-DMA
     # instruction touch a different 128-byte line (64 tag look-ups for 1 KB); the stamped ablations that round the source rows to
     # multiples of eight / to one row (abl 16 / 32: same instructions, 8 / 1 lines each) run the stream in 83.0 k / 81.6 k cycles
@@ -96,9 +97,9 @@ CONFIGS = {
     # WFIX = W: builds for one image width (yolov5m at 640 px: 40 and 20).  The first pixel-major build moved each address down a kernel row
     # with a v_add in front of the read that uses it -- 117 of them per chunk, each stalling its read: the stream WITHOUT any LDS-DMA took
     # 85.3 k cycles against the slot-major build's 81.8 k.  With the width known, dy Wp rows is an immediate offset like the k-step.
-    "pm13": dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False, PM=True),
-    "pm13w20": dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False, PM=True, WFIX=20),
-    "pm13w40": dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, A_IN_ACC=False, SPLIT=0, DMA_FRONT=False, KS=2, S2=False, PM=True, WFIX=40),
+    "pm13": dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, KS=2, S2=False, PM=True),
+    "pm13w20": dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, KS=2, S2=False, PM=True, WFIX=20),
+    "pm13w40": dict(NB=13, PD=8, ROWS=384, RING=3, OCC=1, RES_EARLY=True, LOOK=2, KS=2, S2=False, PM=True, WFIX=40),
 }
 STEP_B = 6 * 1024          # weight bytes per (wave, tap-step): six 1 KB bf16 fragments (KS = 1: three) ...
 W8 = False                 # ... or, in the fp8-weight kernels (set per kernel by gen_kernel), three 1 KB pairs of e4m3 fragments
@@ -164,7 +165,7 @@ def configure(nb):
         assert ROWS % 64 == 0 and NDMA == 6 and PSTR + 16 < 65536
     assert (KS == 1) == bool(S2 or F8)
     assert PS % 256 == 0 and NB >= 6 and NG + 2 <= 8
-    assert KS == 2 or (not SPLIT and not DMA_FRONT and not A_IN_ACC and RES_EARLY)
+    assert KS == 2 or RES_EARLY
     assert NT % (LOOK + 1) == 0, "the weight sets must come round at the end of a chunk"
     allocate_registers()
 
@@ -223,7 +224,8 @@ def allocate_registers():
     if KS == 2 and not F8 and not PM:
         S.alloc("dbase1", 2, 2)   # ... and of its second plane (32-channel chunks: one base, the planes are immediate offsets)
     S.alloc("t64", 2, 2)
-    S.alloc("actm", 2, 2)         # all ones when the layer has an activation (in-stream epilogue blocks select instead of branching)
+    S.alloc("actm", 2, 2)         # all ones when the layer has an activation (read by the removed SPLIT epilogue only; kept, with its two
+                                  # prologue instructions, so that the shipped kernels stay byte-identical)
     S.alloc("st_acc", 12, 2)      # stamped build only: cycle sums of six phases
     if S2:                        # (arguments the stride-2 kernels never read: no shortcut, channel groups 16 bytes apart)
         S.names["st_last"], S.names["st_rt0"] = S.names["res"], S.names["in_ss"]
@@ -242,7 +244,7 @@ def allocate_registers():
     V.alloc("insp")               # in_sp (low 32 bits) as a VGPR operand of v_mad_u64_u32
     V.alloc("zero_lo")
     V.alloc("zero_hi")
-    if not A_IN_ACC:
+    if True:                      # (kept as a block: the weight sets come first among the big arrays)
         V.alloc("A", (24 if F8 else 12 * KS) * (LOOK + 1), 4)
     V.alloc("B", (8 if F8 else 4) * (PD + 1), 4)
     V.alloc("addr", 4 * NB if S2 else 3 * NB if PM else NB)      # (stride 2: per pixel block one swizzled address per (row, column) offset of the taps; pixel-major: per column offset)
@@ -295,7 +297,7 @@ def rreg(b):
         return 12 * NB + 2 * b                             # (accumulator-file register number)
     if RES_EARLY:
         return V.names["R"][0] + 2 * b
-    assert 3 * NB <= 12 + 2 * (PD + 1) and LOOK == 2 and not A_IN_ACC
+    assert 3 * NB <= 12 + 2 * (PD + 1) and LOOK == 2
     return V.names["A"][0] + 48 + 2 * b if b < 12 else V.names["B"][0] + 2 * (b - 12)
 
 
@@ -305,16 +307,13 @@ def areg(set_idx, k):
         assert 0 <= set_idx <= LOOK and 0 <= k < 3
         return vr("A", 24 * set_idx + 8 * k, 8)
     assert 0 <= set_idx <= LOOK and 0 <= k < 3 * KS
-    if A_IN_ACC:
-        b = 12 * NB + 24 * set_idx + 4 * k
-        return f"a[{b}:{b + 3}]"
     return vr("A", 12 * KS * set_idx + 4 * k, 4)
 
 
 # fp8-weight kernels: the 72 weight registers hold three RAW sets of 12 (e4m3 codes as loaded), two converted bf16 half-sets of 12
 # (k-step 0 and k-step 1 of the tap being multiplied) and the 12 per-channel scales of the epilogue
 def rawreg(set_idx, pair):
-    assert W8 and not A_IN_ACC and 0 <= set_idx < 3 and 0 <= pair < 3
+    assert W8 and 0 <= set_idx < 3 and 0 <= pair < 3
     return vr("A", 12 * set_idx + 4 * pair, 4)
 
 
@@ -338,7 +337,7 @@ def emit_convert(tap, ks, i, step):
 
 
 def n_acc():
-    return 12 * NB + (24 * (LOOK + 1) if A_IN_ACC else 0) + (6 * NB if F8 or PM else 0)
+    return 12 * NB + (6 * NB if F8 or PM else 0)
 
 
 def acc(i, j):
@@ -648,7 +647,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     ABL[0] = abl
     NLOAD = 6 if F8 else 3 if (w8 or KS == 1) else 6       # weight load instructions per tap: 1 KB fragments (or e4m3 fragment pairs)
     W8, STEP_B = w8, NLOAD * 1024
-    assert not w8 or (RES_EARLY and LOOK == 2 and not A_IN_ACC and NB >= 12 and KS == 2)
+    assert not w8 or (RES_EARLY and LOOK == 2 and NB >= 12 and KS == 2)
     assert not (S2 and RES), "the stride-2 layers have no shortcut"
     _uid[0], _uid[1] = 0, name.split("asm_", 1)[1].replace("_", "")
     E(f"; conv3x3_pl assembly, family {FAMILY}, NB = {NB}, {OCC} workgroup(s) per CU, RES = {int(RES)}: generated by gen_conv3x3_pl_asm.py -- do not edit")
@@ -1000,14 +999,13 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         label(l_pd)
     stamp(PH_TOP)
 
-    SPLIT_ON = bool(SPLIT) and not w8 and not abl
     cold = []                             # out-of-line code: (label, immediate or instruction list, label to return to)
     T7RES = RES and RES_EARLY
 
-    def epilogue_block(i, j, mode, lines, tb=0, own_exec=True):
+    def epilogue_block(i, j, mode, lines, tb=0):
         """Appends the instructions of one 16 x 16 output block (M block i, pixel block j): accumulators -> (x scale) -> SiLU -> + residual ->
-        bf16 -> store.  mode: "act" / "noact" (the two copies behind a branch after the stream) or "select" (branch-free, for the copy
-        issued between MFMAs).  The store's EXEC mask is in t64 (per pixel block, set by the caller)."""
+        bf16 -> store.  mode: "act" / "noact" (the two copies behind a branch after the stream).  The caller has set EXEC to the pixel
+        block's store mask."""
         X = V.names["t"][0] + tb + 0
         Y = V.names["t"][0] + tb + 4
         Rr = V.names["t"][0] + tb + 8
@@ -1035,7 +1033,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             L(f"v_lshlrev_b32 v{Rr + 2}, 16, v{r0 + 1}")
             L(f"v_and_b32 v{Rr + 3}, 0xffff0000, v{r0 + 1}")
 
-        if mode in ("act", "select"):
+        if mode == "act":
             L(f"v_pk_mul_f32 v[{Y}:{Y + 1}], v[{X}:{X + 1}], {s2('klog2e2')}")
             L(f"v_pk_mul_f32 v[{Y + 2}:{Y + 3}], v[{X + 2}:{X + 3}], {s2('klog2e2')}")
             for e in range(4):
@@ -1048,9 +1046,6 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
                 unpack()
             else:
                 L("s_nop 0")
-            if mode == "select":                          # no activation: multiply by 1 (a lane's exp may have overflowed; the select drops it)
-                for e in range(4):
-                    L(f"v_cndmask_b32 v{Y + e}, 1.0, v{Y + e}, {s2('actm')}")
             L(f"v_pk_mul_f32 v[{X}:{X + 1}], v[{X}:{X + 1}], v[{Y}:{Y + 1}]")
             L(f"v_pk_mul_f32 v[{X + 2}:{X + 3}], v[{X + 2}:{X + 3}], v[{Y + 2}:{Y + 3}]")
         elif RES:
@@ -1060,371 +1055,185 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             L(f"v_pk_add_f32 v[{X + 2}:{X + 3}], v[{X + 2}:{X + 3}], v[{Rr + 2}:{Rr + 3}]")
         L(f"v_cvt_pk_bf16_f32 v{Y}, v{X}, v{X + 1}")
         L(f"v_cvt_pk_bf16_f32 v{Y + 1}, v{X + 2}, v{X + 3}")
-        if own_exec:
-            # one unit: nothing (no MFMA, no other block's instruction) may sit between the EXEC switch and the store
-            L("\n\t".join([f"s_mov_b64 exec, {s2('t64')}", f"global_store_dwordx2 {v('oo', j)}, v[{Y}:{Y + 1}], {s2('out')} offset:{32 * i}",
-                             "s_mov_b64 exec, -1"]))
-        else:
-            L(f"global_store_dwordx2 {v('oo', j)}, v[{Y}:{Y + 1}], {s2('out')} offset:{32 * i}")
+        L(f"global_store_dwordx2 {v('oo', j)}, v[{Y}:{Y + 1}], {s2('out')} offset:{32 * i}")
 
-    def block_mask_lines(j, lines):
-        lines.append(f"s_sub_i32 {s('lim')}, {s('npix')}, {s('n0')}")
-        lines.append(f"s_sub_i32 {s('lim')}, {s('lim')}, {16 * j}")
-        lines.append(f"v_cmp_gt_i32 {s2('t64')}, {s('lim')}, {v('l15')}")
-
-    if SPLIT_ON:
-        NBA = SPLIT
-
-        def make_body(last):
-            """Tap sequence and element list of a chunk body.  taps[p] = (tap 0..8, pixel blocks); elems[n] = (p, e, t, ks, j)."""
-            passes = [list(range(NBA)), list(range(NBA, NB))] if last else [list(range(NB))]
-            taps, elems = [], []
-            for js in passes:
-                for t in range(9):
-                    p = len(taps)
-                    taps.append((t, js))
-                    e = 0
-                    for ks in (0, 1):
-                        for j in js:
-                            elems.append((p, e, t, ks, j))
-                            e += 1
-            return taps, elems
-
-        def body_ops(last):
-            """Vector-memory operations of a body in issue order: (p, e, kind, x, y).  A: weight load y (0..5) of tap sequence number x
-            (x >= len(taps): tap x - len(taps) of the NEXT chunk); D: LDS-DMA (group x, half y); R: residual load (pixel block x, M block y);
-            S: store of the epilogue block issued between the MFMAs (filled in by the emitter)."""
-            taps, _ = make_body(last)
-            ops = []
-            for p, (t, js) in enumerate(taps):
-                ne = 2 * len(js)
-                assert ne >= 12
-                ops += [(p, 2 * k + 1, "A", p + LOOK, k) for k in range(6)]
-                if p < NG:
-                    ops += [(p, 12, "D", p, 0), (p, 12 + (ne - 12) // 2 if ne > 13 else 13, "D", p, 1)]
-                if last and RES and p < 7:
-                    groups = [2 * p, 2 * p + 1] if p < 6 else [12]
-                    for gi, jr in enumerate(g for g in groups if g < NB):
-                        ops += [(p, (6, 10)[gi], "R", jr, i) for i in range(3)]
-            return ops
-
-        def emit_body(last, label_name):
-            taps, elems = make_body(last)
-            m = len(taps)
-            ops = body_ops(last)
-            # epilogue slices (last body): the blocks of the first group, issued from the second element of the second pass on
-            slices = {}
-            if last:
-                lines = []
-                for j in range(NBA):
-                    block_mask_lines(j, lines)
-                    for i in range(3):
-                        epilogue_block(i, j, "select", lines)
-                first = next(n for n, el in enumerate(elems) if el[0] == 9) + 1
-                slots = [n for n in range(first, len(elems) - 2 * len(taps[-1][1]) * 2)]       # done before the last two taps: their
-                per = -(-len(lines) // len(slots))                                             # tails then look like a plain body's
-                for k, n in enumerate(slots):
-                    slices[n] = lines[k * per:(k + 1) * per]
-                assert sum(len(v_) for v_ in slices.values()) == len(lines) and per <= 9
-                for n, ls in slices.items():
-                    for l in ls:
-                        if "global_store" in l:
-                            ops.append((elems[n][0], elems[n][1] + 0.5, "S", 0, 0))
-            ops.sort(key=lambda o: (o[0], o[1]))
-            flat = [(o, (o[0], o[1])) for o in ops]
-
-            def seq_until(p_w, e_w):
-                return [o for o in ops if (o[0], o[1]) < (p_w, e_w)]
-
-            return taps, elems, ops, slices, m, seq_until
-
-        bodies = {False: emit_body(False, "plain"), True: emit_body(True, "last")}
-        rem_stores = 3 * (NB - NBA)
-
-        def prev_tail(kind):
-            """Operations that precede a body: a plain chunk, or a last chunk followed by the rest of the epilogue (its stores)."""
-            if kind == "plain":
-                return list(bodies[False][2])
-            return list(bodies[True][2]) + [(99, k, "S", 0, 0) for k in range(rem_stores)]
-
-        def younger(prev_kind, last, tapseq, k_last, p_w, e_w):
-            taps, elems, ops, slices, m, seq_until = bodies[last]
-            prev = prev_tail(prev_kind)
-            m_prev = 9 if prev_kind == "plain" else 18
-            seq = []
-            for o in prev:                                   # weight loads of the previous body for "tap m_prev + k" are this body's tap k
-                if o[2] == "A":
-                    seq.append(("A", o[3] - m_prev, o[4]))
-                else:
-                    seq.append((o[2], -1, -1))
-            for o in seq_until(p_w, e_w):
-                seq.append(("A", o[3], o[4]) if o[2] == "A" else (o[2], -1, -1))
-            idx = max(i for i, o in enumerate(seq) if o == ("A", tapseq, k_last))
-            return len(seq) - 1 - idx
-
-        def emit_stream(last):
-            taps, elems, ops, slices, m, seq_until = bodies[last]
-            ne_all = len(elems)
-
-            def b_read(n):
-                p, e, t, ks, j = elems[n]
-                if ks == 0 and t == 0:
-                    E(f"v_add_u32 {v('addr', j)}, {s('delta0')}, {v('addr', j)}")
-                elif ks == 0 and t % 3 == 0:
-                    E(f"v_add_u32 {v('addr', j)}, {s('dRow')}, {v('addr', j)}")
-                E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)} offset:{16 * (t % 3) + (4 * PS if ks else 0)}")
-
-            for n in range(PD):
-                b_read(n)
-            res_waited = False
-            for n in range(ne_all):
-                p, e, t, ks, j = elems[n]
-                js = taps[p][1]
-                if n + PD < ne_all:
-                    b_read(n + PD)
-                if j == js[0]:                               # first element of a half-tap: its three weight fragments
-                    k_last = 2 + 3 * ks
-                    if last:
-                        kN = younger("plain", True, p, k_last, p, e)
-                        assert kN <= 63
-                        E(f"s_waitcnt vmcnt({kN})", f"weights of tap {p}, k-step {ks}")
-                    else:
-                        kN = younger("plain", False, p, k_last, p, e)
-                        assert kN <= 63
-                        ld = uid("wd")
-                        if p < LOOK:                         # loaded before the previous tile's epilogue finished: more is in flight
-                            kX = min(63, younger("last", False, p, k_last, p, e))
-                            lx = uid("wx")
-                            E(f"s_cmp_eq_u32 {s('extra')}, 1")
-                            E(f"s_cbranch_scc1 {lx}")
-                            cold.append((lx, kX, ld))
-                        E(f"s_waitcnt vmcnt({kN})", f"weights of tap {p}, k-step {ks}")
-                        label(ld)
-                for o in ops:
-                    if (o[0], o[1]) != (p, e):
-                        continue
-                    if o[2] == "A":
-                        tp = o[3]
-                        if o[4] == 0:
-                            if tp < m:
-                                emit_set_a_base("a_ld", taps[tp][0])
-                            else:
-                                emit_set_a_base("a_ld", 9 + tp - m)
-                        emit_load_a(tp % (LOOK + 1), o[4], s2("a_ld"), 0)
-                    elif o[2] == "D":
-                        emit_dma(o[3], o[4], s("cd"), s("bd"))
-                    elif o[2] == "R":
-                        jr, i = o[3], o[4]
-                        if i == 0:
-                            E(f"v_add_u32 {T[4]}, {s('n0')}, {v('l15')}")
-                            if jr:
-                                E(f"v_add_u32 {T[4]}, {16 * jr}, {T[4]}")
-                            E(f"v_min_i32 {T[4]}, {s('rlim')}, {T[4]}")
-                            E(f"v_mul_lo_u32 {T[4]}, {T[4]}, {s('res_ld')}")
-                            E(f"v_add_u32 {T[4]}, {T[4]}, {T[7]}")
-                        E(f"global_load_dwordx2 v[{rreg(3 * jr + i)}:{rreg(3 * jr + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}")
-                if n % 2 == 0:
-                    E(f"s_waitcnt lgkmcnt({max(min(PD, ne_all - 1 - n) - 1, 0) if n + 1 < ne_all else 0})")
-                for i in range(3):
-                    E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {areg(p % (LOOK + 1), 3 * ks + i)}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
-                if n in slices:
-                    if RES and not res_waited:               # the residual of the first group (loaded in the first pass) has landed
-                        seq = seq_until(p, e + 0.25)
-                        k_r = len(seq) - 1 - max(i for i, o in enumerate(seq) if o[2] == "R" and o[3] < NBA)
-                        E(f"s_waitcnt vmcnt({min(63, k_r)})", "residual of the pixel blocks whose epilogue starts here")
-                        res_waited = True
-                    for l in slices[n]:
-                        E(l)
-
-        l_last, l_cend = uid("lastbody"), uid("cend")
-        E(f"s_cmp_eq_u32 {s('lastc')}, 1")
-        E(f"s_cbranch_scc1 {l_last}")
-        emit_stream(False)
-        E(f"s_branch {l_cend}")
-        label(l_last)
-        emit_stream(True)
-        label(l_cend)
-    if not SPLIT_ON:
-        # first B fragments
-        def b_read(n):
-            h, j = divmod(n, NB)
-            t, ks = divmod(h, KS)
-            # the pixel block's address moves once per kernel ROW (taps 0, 3, 6); the column and the k-step are immediate offsets
-            if F8:
-                # step t = tap pair: this lane's tap offset, then the swizzle (byte bit 5 ^= bit 8), two reads of 16 bytes
-                bq = V.names["B"][0] + 8 * (n % (PD + 1))
-                if t == 0:
-                    E(f"v_add_u32 {v('addr', j)}, {s('delta0')}, {v('addr', j)}")
-                E(f"v_add_u32 {T[2]}, {v('tapoff', t)}, {v('addr', j)}")
-                E(f"v_lshrrev_b32 {T[3]}, 3, {T[2]}")
-                E(f"v_and_b32 {T[3]}, 32, {T[3]}")
-                E(f"v_xor_b32 {T[2]}, {T[2]}, {T[3]}")
-                if not abl & 4:
-                    E(f"ds_read_b128 v[{bq}:{bq + 3}], {T[2]}")
-                    E(f"ds_read_b128 v[{bq + 4}:{bq + 7}], {T[2]} offset:16")
-                return
-            if PM:
-                # tap (dy, dx) = divmod(t, 3): the block's address for column offset dx, which moves to the chunk's ring buffer at its first
-                # use (taps 0, 1, 2) and one kernel row down at each later one; the k-step is the other half-plane
-                dy, dx = divmod(t, 3)
-                if ks == 0 and (dy == 0 or not WFIX):
-                    E(f"v_add_u32 {v('addr', 3 * j + dx)}, {s('delta0') if dy == 0 else s('dRow')}, {v('addr', 3 * j + dx)}")
-                if not abl & 4:
-                    E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', 3 * j + dx)} offset:{ks * PSTR + (dy * (WFIX + 1) * 64 if WFIX else 0)}")
-                return
-            if S2:
-                # tap (dy, dx) = divmod(t, 3): parity plane (dy != 1, dx != 1) -- plane index as the waves load them, 2 py + px -- as the
-                # immediate offset; the (row, column) offset (dy >= 1, dx >= 1) picks one of the block's four swizzled addresses, each of
-                # which moves to the chunk's ring buffer at its first use (taps 0, 1, 3, 4)
-                dy, dx = divmod(t, 3)
-                o = 2 * (dy >= 1) + (dx >= 1)
-                if t in (0, 1, 3, 4):
-                    E(f"v_add_u32 {v('addr', 4 * j + o)}, {s('delta0')}, {v('addr', 4 * j + o)}")
-                if not abl & 4:
-                    E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', 4 * j + o)} offset:{(2 * (dy != 1) + (dx != 1)) * PSTR}")
-                return
-            if ks == 0 and t == 0:
+    # first B fragments
+    def b_read(n):
+        h, j = divmod(n, NB)
+        t, ks = divmod(h, KS)
+        # the pixel block's address moves once per kernel ROW (taps 0, 3, 6); the column and the k-step are immediate offsets
+        if F8:
+            # step t = tap pair: this lane's tap offset, then the swizzle (byte bit 5 ^= bit 8), two reads of 16 bytes
+            bq = V.names["B"][0] + 8 * (n % (PD + 1))
+            if t == 0:
                 E(f"v_add_u32 {v('addr', j)}, {s('delta0')}, {v('addr', j)}")
-            elif ks == 0 and t % 3 == 0:
-                E(f"v_add_u32 {v('addr', j)}, {s('dRow')}, {v('addr', j)}")
-            off = 16 * (t % 3) + (4 * PS if ks else 0)
+            E(f"v_add_u32 {T[2]}, {v('tapoff', t)}, {v('addr', j)}")
+            E(f"v_lshrrev_b32 {T[3]}, 3, {T[2]}")
+            E(f"v_and_b32 {T[3]}, 32, {T[3]}")
+            E(f"v_xor_b32 {T[2]}, {T[2]}, {T[3]}")
             if not abl & 4:
-                E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)} offset:{off}")
+                E(f"ds_read_b128 v[{bq}:{bq + 3}], {T[2]}")
+                E(f"ds_read_b128 v[{bq + 4}:{bq + 7}], {T[2]} offset:16")
+            return
+        if PM:
+            # tap (dy, dx) = divmod(t, 3): the block's address for column offset dx, which moves to the chunk's ring buffer at its first
+            # use (taps 0, 1, 2) and one kernel row down at each later one; the k-step is the other half-plane
+            dy, dx = divmod(t, 3)
+            if ks == 0 and (dy == 0 or not WFIX):
+                E(f"v_add_u32 {v('addr', 3 * j + dx)}, {s('delta0') if dy == 0 else s('dRow')}, {v('addr', 3 * j + dx)}")
+            if not abl & 4:
+                E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', 3 * j + dx)} offset:{ks * PSTR + (dy * (WFIX + 1) * 64 if WFIX else 0)}")
+            return
+        if S2:
+            # tap (dy, dx) = divmod(t, 3): parity plane (dy != 1, dx != 1) -- plane index as the waves load them, 2 py + px -- as the
+            # immediate offset; the (row, column) offset (dy >= 1, dx >= 1) picks one of the block's four swizzled addresses, each of
+            # which moves to the chunk's ring buffer at its first use (taps 0, 1, 3, 4)
+            dy, dx = divmod(t, 3)
+            o = 2 * (dy >= 1) + (dx >= 1)
+            if t in (0, 1, 3, 4):
+                E(f"v_add_u32 {v('addr', 4 * j + o)}, {s('delta0')}, {v('addr', 4 * j + o)}")
+            if not abl & 4:
+                E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', 4 * j + o)} offset:{(2 * (dy != 1) + (dx != 1)) * PSTR}")
+            return
+        if ks == 0 and t == 0:
+            E(f"v_add_u32 {v('addr', j)}, {s('delta0')}, {v('addr', j)}")
+        elif ks == 0 and t % 3 == 0:
+            E(f"v_add_u32 {v('addr', j)}, {s('dRow')}, {v('addr', j)}")
+        off = 16 * (t % 3) + (4 * PS if ks else 0)
+        if not abl & 4:
+            E(f"ds_read_b128 {vr('B', 4 * (n % (PD + 1)), 4)}, {v('addr', j)} offset:{off}")
 
-        for n in range(PD):
-            b_read(n)
-        # ---- the element stream ----
-        # Vector-memory operations of one tap, in issue order: (element, kind, ...).  Weights of tap t + 2 at the odd elements 1 .. 11,
-        # two LDS-DMA instructions in the first NG taps, residual loads (one or two pixel blocks of three) in taps 0 .. 6.
-        kD0, kD1 = DPOS[0], DPOS[-1]
-        in_stream_res = RES and RES_EARLY
-        res_groups = []                       # res_groups[t] = pixel blocks whose residual is loaded in tap t
-        if in_stream_res and F8:
-            nxt = 0
-            for t in range(NT):
-                cnt = min(NB - nxt, -(-(NB - nxt) // (4 - t)), len(RPOS)) if t < 4 else 0
-                res_groups.append(list(range(nxt, nxt + cnt)))
-                nxt += cnt
-            assert nxt == NB
-        elif in_stream_res:
-            nxt = 0
-            for t in range(9):
-                cnt = min(NB - nxt, -(-(NB - nxt) // (7 - t))) if t < 7 else 0
-                res_groups.append(list(range(nxt, nxt + cnt)))
-                nxt += cnt
-            assert nxt == NB and kD1 + 2 < 2 * NB
+    for n in range(PD):
+        b_read(n)
+    # ---- the element stream ----
+    # Vector-memory operations of one tap, in issue order: (element, kind, ...).  Weights of tap t + 2 at the odd elements 1 .. 11,
+    # two LDS-DMA instructions in the first NG taps, residual loads (one or two pixel blocks of three) in taps 0 .. 6.
+    kD0, kD1 = DPOS[0], DPOS[-1]
+    in_stream_res = RES and RES_EARLY
+    res_groups = []                       # res_groups[t] = pixel blocks whose residual is loaded in tap t
+    if in_stream_res and F8:
+        nxt = 0
+        for t in range(NT):
+            cnt = min(NB - nxt, -(-(NB - nxt) // (4 - t)), len(RPOS)) if t < 4 else 0
+            res_groups.append(list(range(nxt, nxt + cnt)))
+            nxt += cnt
+        assert nxt == NB
+    elif in_stream_res:
+        nxt = 0
+        for t in range(9):
+            cnt = min(NB - nxt, -(-(NB - nxt) // (7 - t))) if t < 7 else 0
+            res_groups.append(list(range(nxt, nxt + cnt)))
+            nxt += cnt
+        assert nxt == NB and kD1 + 2 < 2 * NB
 
-        def tap_ops(t, last=True):
-            import os as _os
-            # spacing of a tap's weight loads, in elements.  Pixel-major family, stream cycles (192 ch / 384 ch): every element 89.6 k / 81.1 k,
-            # every 2nd 87.1 k / 80.4 k, every 3rd 85.5 k / 80.7 k, every 4th (with the LDS-DMA at elements 14 and 22) 84.6 k / 79.8 k
-            astride = int(_os.environ.get("AQ_GEN_ASTRIDE", "4")) if PM else int(_os.environ.get("AQ_GEN_ASTRIDE_S2", "2")) if S2 else 2
-            ops = [(astride * k + 1, "A", (t + LOOK) % NT, k) for k in range(NLOAD) if not abl & 1]
-            if DMA_FRONT and t == 0 and not abl & 2:
-                assert 12 + 2 * NG <= 2 * NB
-                ops += [(12 + 2 * k + h, "D", k, h) for k in range(NG) for h in range(2)]
-            elif (S2 or F8) and not abl & 2:
-                ops += [(DPOS[i_], "D", g_, 0) for i_, g_ in enumerate(DMA_TAPS[t])]
-            elif not S2 and not F8 and not DMA_FRONT and t < (NDMA if PM else NG) and not abl & 2:
-                ops += [(DPOS[h], "D", t, h) for h in range(PPW)]
-            if in_stream_res and last:
-                for g, j in enumerate(res_groups[t]):
-                    ops += [((RPOS[g] if F8 else (kD0, kD1)[g] + 2), "R", j, i) for i in range(3)]
-            return sorted(ops, key=lambda o: o[0])
+    def tap_ops(t, last=True):
+        import os as _os
+        # spacing of a tap's weight loads, in elements.  Pixel-major family, stream cycles (192 ch / 384 ch): every element 89.6 k / 81.1 k,
+        # every 2nd 87.1 k / 80.4 k, every 3rd 85.5 k / 80.7 k, every 4th (with the LDS-DMA at elements 14 and 22) 84.6 k / 79.8 k
+        astride = int(_os.environ.get("AQ_GEN_ASTRIDE", "4")) if PM else int(_os.environ.get("AQ_GEN_ASTRIDE_S2", "2")) if S2 else 2
+        ops = [(astride * k + 1, "A", (t + LOOK) % NT, k) for k in range(NLOAD) if not abl & 1]
+        if (S2 or F8) and not abl & 2:
+            ops += [(DPOS[i_], "D", g_, 0) for i_, g_ in enumerate(DMA_TAPS[t])]
+        elif not S2 and not F8 and t < (NDMA if PM else NG) and not abl & 2:
+            ops += [(DPOS[h], "D", t, h) for h in range(PPW)]
+        if in_stream_res and last:
+            for g, j in enumerate(res_groups[t]):
+                ops += [((RPOS[g] if F8 else (kD0, kD1)[g] + 2), "R", j, i) for i in range(3)]
+        return sorted(ops, key=lambda o: o[0])
 
-        def younger_than(tap, k_last, t_wait, e_wait, last):
-            """Vector-memory operations issued after weight load k_last of tap `tap` and before element e_wait of tap t_wait, in a tile's
-            last chunk (with the residual loads) or another one; the chunk before is never a last chunk that matters: its residual loads
-            are older than the weights of taps 0 and 1."""
-            seq = [o for tt in range(NT) for o in tap_ops(tt, False)] + [o for tt in range(t_wait) for o in tap_ops(tt, last)]
-            seq += [o for o in tap_ops(t_wait, last) if o[0] < e_wait]
-            idx = max(i for i, o in enumerate(seq) if o[1] == "A" and o[2] == tap and o[3] == k_last)
-            return len(seq) - 1 - idx
+    def younger_than(tap, k_last, t_wait, e_wait, last):
+        """Vector-memory operations issued after weight load k_last of tap `tap` and before element e_wait of tap t_wait, in a tile's
+        last chunk (with the residual loads) or another one; the chunk before is never a last chunk that matters: its residual loads
+        are older than the weights of taps 0 and 1."""
+        seq = [o for tt in range(NT) for o in tap_ops(tt, False)] + [o for tt in range(t_wait) for o in tap_ops(tt, last)]
+        seq += [o for o in tap_ops(t_wait, last) if o[0] < e_wait]
+        idx = max(i for i, o in enumerate(seq) if o[1] == "A" and o[2] == tap and o[3] == k_last)
+        return len(seq) - 1 - idx
 
-        def wait_weights(tap, k_last, t_wait, e_wait):
-            """Weight loads 0 .. k_last of tap `tap` have landed, at element e_wait of tap t_wait."""
-            if abl & 1:
-                return
-            kN = younger_than(tap, k_last, t_wait, e_wait, False)
-            kL = younger_than(tap, k_last, t_wait, e_wait, True)
-            assert kN <= kL <= 63
-            cases = []                                        # (flag register, immediate)
-            if kL != kN:
-                cases.append((s("lastc"), kL))
-            if tap < LOOK and t_wait < LOOK:                  # loaded before the previous tile's epilogue
-                cases.append((s("extra"), min(63, kN + n_extra)))
-            # the common case falls through (a taken branch costs the wave its instruction buffer); the others wait out of line
-            ld = uid("wd")
-            for flag, imm in cases:
-                lx = uid("wx")
-                E(f"s_cmp_eq_u32 {flag}, 1")
+    def wait_weights(tap, k_last, t_wait, e_wait):
+        """Weight loads 0 .. k_last of tap `tap` have landed, at element e_wait of tap t_wait."""
+        if abl & 1:
+            return
+        kN = younger_than(tap, k_last, t_wait, e_wait, False)
+        kL = younger_than(tap, k_last, t_wait, e_wait, True)
+        assert kN <= kL <= 63
+        cases = []                                        # (flag register, immediate)
+        if kL != kN:
+            cases.append((s("lastc"), kL))
+        if tap < LOOK and t_wait < LOOK:                  # loaded before the previous tile's epilogue
+            cases.append((s("extra"), min(63, kN + n_extra)))
+        # the common case falls through (a taken branch costs the wave its instruction buffer); the others wait out of line
+        ld = uid("wd")
+        for flag, imm in cases:
+            lx = uid("wx")
+            E(f"s_cmp_eq_u32 {flag}, 1")
+            E(f"s_cbranch_scc1 {lx}")
+            cold.append((lx, imm, ld))
+        E(f"s_waitcnt vmcnt({kN})", f"weights of tap {tap}, loads 0 .. {k_last}")
+        label(ld)
+
+    for n in range(NE):
+        h, j = divmod(n, NB)
+        t, ks = divmod(h, KS)
+        e = ks * NB + j
+        post = []                                         # KS = 1 families: the LDS-DMA itself, behind this element's MFMAs
+        if n + PD < NE:
+            b_read(n + PD)
+        if j == 0 and F8:
+            wait_weights(t, 5, t, e)                      # the step's three 8-register fragments: six loads
+        elif j == 0 and not w8:
+            wait_weights(t, 2 + 3 * ks, t, e)             # bf16 fragments: three per k-step
+        elif j == 0 and ks == 0:
+            wait_weights(t, 2, t, e)                      # raw pair 2 of this tap: converted (k-step 1) under this k-step's MFMAs
+        elif j == 0:
+            wait_weights((t + 1) % 9, 1, t, e)            # raw pairs 0, 1 of the next tap: its k-step 0 is converted under this one
+        for op in tap_ops(t):
+            if op[0] != e:
+                continue
+            if op[1] == "A":
+                if op[3] == 0:
+                    emit_set_a_base("a_ld", t + LOOK)
+                emit_load_a((t + LOOK) % (LOOK + 1), op[3], s2("a_ld"), 0)
+            elif op[1] == "D" and (KS == 1 or PM):
+                emit_dma_m0(op[2], op[3])
+                post.append((op[2], op[3]))
+            elif op[1] == "D":
+                emit_dma(op[2], op[3], s("cd"), s("bd"))
+            elif op[1] == "R" and op[3] == 0:
+                # out of line as well: only a tile's last chunk takes the branch
+                jr = op[2]
+                lx, ld = uid("res"), uid("resd")
+                E(f"s_cmp_eq_u32 {s('lastc')}, 1")
                 E(f"s_cbranch_scc1 {lx}")
-                cold.append((lx, imm, ld))
-            E(f"s_waitcnt vmcnt({kN})", f"weights of tap {tap}, loads 0 .. {k_last}")
-            label(ld)
-
-        for n in range(NE):
-            h, j = divmod(n, NB)
-            t, ks = divmod(h, KS)
-            e = ks * NB + j
-            post = []                                         # KS = 1 families: the LDS-DMA itself, behind this element's MFMAs
-            if n + PD < NE:
-                b_read(n + PD)
-            if j == 0 and F8:
-                wait_weights(t, 5, t, e)                      # the step's three 8-register fragments: six loads
-            elif j == 0 and not w8:
-                wait_weights(t, 2 + 3 * ks, t, e)             # bf16 fragments: three per k-step
-            elif j == 0 and ks == 0:
-                wait_weights(t, 2, t, e)                      # raw pair 2 of this tap: converted (k-step 1) under this k-step's MFMAs
-            elif j == 0:
-                wait_weights((t + 1) % 9, 1, t, e)            # raw pairs 0, 1 of the next tap: its k-step 0 is converted under this one
-            for op in tap_ops(t):
-                if op[0] != e:
-                    continue
-                if op[1] == "A":
-                    if op[3] == 0:
-                        emit_set_a_base("a_ld", t + LOOK)
-                    emit_load_a((t + LOOK) % (LOOK + 1), op[3], s2("a_ld"), 0)
-                elif op[1] == "D" and (KS == 1 or PM):
-                    emit_dma_m0(op[2], op[3])
-                    post.append((op[2], op[3]))
-                elif op[1] == "D":
-                    emit_dma(op[2], op[3], s("cd"), s("bd"))
-                elif op[1] == "R" and op[3] == 0:
-                    # out of line as well: only a tile's last chunk takes the branch
-                    jr = op[2]
-                    lx, ld = uid("res"), uid("resd")
-                    E(f"s_cmp_eq_u32 {s('lastc')}, 1")
-                    E(f"s_cbranch_scc1 {lx}")
-                    label(ld)
-                    body = [f"v_add_u32 {T[4]}, {s('n0')}, {v('l15')}"]
-                    if jr:
-                        body.append(f"v_add_u32 {T[4]}, {16 * jr}, {T[4]}")
-                    body += [f"v_min_i32 {T[4]}, {s('rlim')}, {T[4]}", f"v_mul_lo_u32 {T[4]}, {T[4]}, {s('res_ld')}", f"v_add_u32 {T[4]}, {T[4]}, {T[7]}"]
-                    body += [f"global_load_dwordx2 {'a' if F8 or PM else 'v'}[{rreg(3 * jr + i)}:{rreg(3 * jr + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}" for i in range(3)]
-                    cold.append((lx, body, ld))
-            # one wait per PAIR of elements (fragments n and n + 1 have landed): the stream is bound by instruction issue
-            allowed = min(PD, NE - 1 - n)
+                label(ld)
+                body = [f"v_add_u32 {T[4]}, {s('n0')}, {v('l15')}"]
+                if jr:
+                    body.append(f"v_add_u32 {T[4]}, {16 * jr}, {T[4]}")
+                body += [f"v_min_i32 {T[4]}, {s('rlim')}, {T[4]}", f"v_mul_lo_u32 {T[4]}, {T[4]}, {s('res_ld')}", f"v_add_u32 {T[4]}, {T[4]}, {T[7]}"]
+                body += [f"global_load_dwordx2 {'a' if F8 or PM else 'v'}[{rreg(3 * jr + i)}:{rreg(3 * jr + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}" for i in range(3)]
+                cold.append((lx, body, ld))
+        # one wait per PAIR of elements (fragments n and n + 1 have landed): the stream is bound by instruction issue
+        allowed = min(PD, NE - 1 - n)
+        if F8:
+            E(f"s_waitcnt lgkmcnt({2 * allowed})", "two reads per fragment")
+        elif n % 2 == 0:
+            E(f"s_waitcnt lgkmcnt({max(allowed - 1, 0) if n + 1 < NE else allowed})")
+        for i in range(3 if not abl & 8 else 0):
             if F8:
-                E(f"s_waitcnt lgkmcnt({2 * allowed})", "two reads per fragment")
-            elif n % 2 == 0:
-                E(f"s_waitcnt lgkmcnt({max(allowed - 1, 0) if n + 1 < NE else allowed})")
-            for i in range(3 if not abl & 8 else 0):
-                if F8:
-                    E(f"v_mfma_f32_16x16x128_f8f6f4 {acc(i, j)}, {areg(t % (LOOK + 1), i)}, {vr('B', 8 * (n % (PD + 1)), 8)}, {acc(i, j)}")
-                    continue
-                srca = bfreg(ks, i) if w8 else areg(t % (LOOK + 1), 3 * ks + i)
-                E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {srca}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
-            for k_, h_ in post:
-                if abl & 8:
-                    E("s_nop 0", "hz: m0 write -> LDS-DMA (no MFMAs in between in this ablation)")
-                emit_dma_issue(k_, h_)
-            if w8 and j < 12:
-                # one quarter of a fragment of the NEXT half-tap per element: two VALU instructions in the shadow of three MFMAs
-                if ks == 0:
-                    emit_convert(t, 1, j // 4, j % 4)
-                else:
-                    emit_convert((t + 1) % 9, 0, j // 4, j % 4)
+                E(f"v_mfma_f32_16x16x128_f8f6f4 {acc(i, j)}, {areg(t % (LOOK + 1), i)}, {vr('B', 8 * (n % (PD + 1)), 8)}, {acc(i, j)}")
+                continue
+            srca = bfreg(ks, i) if w8 else areg(t % (LOOK + 1), 3 * ks + i)
+            E(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {srca}, {vr('B', 4 * (n % (PD + 1)), 4)}, {acc(i, j)}")
+        for k_, h_ in post:
+            if abl & 8:
+                E("s_nop 0", "hz: m0 write -> LDS-DMA (no MFMAs in between in this ablation)")
+            emit_dma_issue(k_, h_)
+        if w8 and j < 12:
+            # one quarter of a fragment of the NEXT half-tap per element: two VALU instructions in the shadow of three MFMAs
+            if ks == 0:
+                emit_convert(t, 1, j // 4, j % 4)
+            else:
+                emit_convert((t + 1) % 9, 0, j // 4, j % 4)
     # ---- chunk end ----
     stamp(PH_STREAM)
     # next chunk: delta0 = (next buffer - this buffer) * CHUNK - 2 Wp * 16
@@ -1464,11 +1273,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     else:
         E("s_nop 15", "hz: MFMA result -> VALU read")
         E("s_nop 15")
-    if RES and RES_EARLY and SPLIT_ON:
-        tail = bodies[True][2]
-        k_res = len(tail) - 1 - max(i for i, o in enumerate(tail) if o[2] == "R")
-        E(f"s_waitcnt vmcnt({min(63, k_res)})", "the residual (loads return in order: at most 63 younger operations can be outstanding)")
-    elif RES and RES_EARLY:
+    if RES and RES_EARLY:
         tail = [o for tt in range(NT) for o in tap_ops(tt, True)]
         k_res = len(tail) - 1 - max(i for i, o in enumerate(tail) if o[1] == "R")
         E(f"s_waitcnt vmcnt({k_res})", "the residual (only weight loads of the next tile's first taps are younger)")
@@ -1495,17 +1300,14 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         else:
             label(lact)
         E(f"s_sub_i32 {s('lim')}, {s('npix')}, {s('n0')}")
-        j0 = SPLIT if SPLIT_ON else 0
-        if j0:
-            E(f"s_sub_i32 {s('lim')}, {s('lim')}, {16 * j0}")
-        for j in range(j0, NB):
+        for j in range(NB):
             E(f"v_cmp_gt_i32 {s2('t64')}, {s('lim')}, {v('l15')}", "pixel n0 + 16 j + l15 inside the batch?")
             E(f"s_sub_i32 {s('lim')}, {s('lim')}, 16")
             E(f"s_mov_b64 exec, {s2('t64')}")
             la, lb, lc = [], [], []
-            epilogue_block(0, j, "act" if ACT else "noact", la, 0, False)
-            epilogue_block(1, j, "act" if ACT else "noact", lb, 12, False)
-            epilogue_block(2, j, "act" if ACT else "noact", lc, 0, False)
+            epilogue_block(0, j, "act" if ACT else "noact", la, 0)
+            epilogue_block(1, j, "act" if ACT else "noact", lb, 12)
+            epilogue_block(2, j, "act" if ACT else "noact", lc, 0)
             for k in range(max(len(la), len(lb))):
                 if k < len(la):
                     E(la[k])
@@ -1522,7 +1324,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             E(f"s_cbranch_scc1 {lact}")
         else:
             label(lact)
-        for j in range(SPLIT if SPLIT_ON else 0, NB):        # (split last chunk: the first pixel blocks were done between its MFMAs)
+        for j in range(NB):
             E(f"s_sub_i32 {s('lim')}, {s('npix')}, {s('n0')}")
             E(f"s_sub_i32 {s('lim')}, {s('lim')}, {16 * j}", "pixels of this block inside the batch")
             E(f"v_cmp_gt_i32 {s2('t64')}, {s('lim')}, {v('l15')}", "pixel n0 + 16 j + l15 inside the batch?")
