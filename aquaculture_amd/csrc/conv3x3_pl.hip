@@ -22,6 +22,12 @@
 //   * every vector-memory operation of the loop (LDS-DMA, weight loads, residual loads, output stores) is inline asm
 //     with hand-counted s_waitcnt vmcnt(N): the compiler never sees them, so it never drains them (round 1's vmcnt(0)
 //     findings); fragment reads and MFMAs are ordinary code that it schedules and pads for hazards.
+//
+// Round 3: the generated assembly (gen_conv3x3_pl_asm.py) has a second region layout for the same kernel -- families pm13w20 / pm13w40,
+// chosen by pl_conv() for 20- and 40-wide images: two half-planes of 64-byte PIXEL-MAJOR rows per chunk, loaded 16 rows per instruction
+// through a buffer descriptor (out-of-range lanes write the zero padding), channel group q at position q ^ 2 b with b = bit 2 of the
+// pixel's column.  The slot-major planes above cost one cache-line look-up per LANE of every LDS-DMA instruction, and that -- not the
+// bytes -- was what the stream waited for (point 7).  This HIP-source kernel keeps the slot-major layout.
 #include "conv_device.h"
 #include <cmath>
 #include <mutex>

@@ -226,6 +226,8 @@ int aq_conv3x3s2_direct(const void* in_dev, int in_ld, int in_choff, void* out_d
  * yolov5m's 192 -> 192 and 384 -> 384 [UPSTREAM models/common.py Bottleneck.cv2]): four waves, one per SIMD, weights streamed from L2
  * straight into registers in MFMA-fragment order (aq_pack_conv3x3_pl), the input region staged in LDS as padded, slot-major planes
  * (conflict-free fragment reads for every tap with no masks), a three-buffer chunk ring with ONE workgroup barrier per 64-channel chunk.
+ * (Round 3: on 20- and 40-pixel-wide images -- yolov5m's two widths -- the region is staged as 64-byte pixel-major rows through a buffer
+ * descriptor instead, a quarter of the cache-line look-ups per LDS-DMA instruction; same tiles, packed weights and results.)
  * Same operation as aq_conv2d with k = 3, stride = 1, pad = 1; the engine's autotuner times it per layer under AQ_CONV_CFG_PL3X3.
  * in_dev: first channel of the input; element (pixel P, 16-byte channel group g) lives at in_dev + P * in_pixel_stride_b +
  * g * in_group_stride_b (NHWC: row bytes and 16).  out / res: NHWC bf16 slices as in aq_conv2d (res may alias out: in-place shortcut). */
