@@ -151,6 +151,11 @@ class LoadImages:
     def scan_split_decodable(self) -> List[Optional[Tuple[int, int]]]:
         """Per file: (width, height) when the split JPEG decoder covers it (aquaculture_amd/jpeg.py: baseline 4:2:0), else None."""
         from . import jpeg
+        if len(self.files) >= 16384 and self.workers > 1 and os.environ.get("AQ_SCAN_PROCS", "1") != "0":
+            try:                                   # a long sweep: scanner processes (threads do not scale: the per-file Python holds the GIL)
+                return jpeg.scan_files_in_processes(self.files, min(self.workers, 16))
+            except Exception:                      # the threaded scan below still works
+                pass
         with ThreadPoolExecutor(self.workers) as ex:
             return list(ex.map(jpeg.scan_file, self.files))
 

@@ -146,3 +146,18 @@ def test_entropy_decoder_survives_mutated_files_under_asan(tmp_path):
     assert r.returncode == 0 and "fuzz_jpeg:" in r.stdout, r.stdout[-500:] + r.stderr[-3000:]
     decoded, rejected = (int(x) for x in __import__("re").findall(r"(\d+) decoded, (\d+) rejected", r.stdout)[0])
     assert decoded > 500 and rejected > 500          # the mutations reach both outcomes
+
+
+def test_header_scan_in_processes_equals_the_in_process_one(jpeg_lib, tmp_path):
+    """Long sweeps scan their files' headers in child processes (jpeg.scan_files_in_processes): same answers as scan_file, file by file --
+    sizes for what the split decoder reads, None for a progressive file and for a file that is no JPEG."""
+    from aquaculture_amd import tiles
+    for i in range(25):
+        (tmp_path / f"{i:03d}.jpeg").write_bytes(_jpeg(tiles.synthetic_tile(i, 64 + 16 * (i % 3)), quality=75))
+    (tmp_path / "zz_progressive.jpeg").write_bytes(_jpeg(tiles.synthetic_tile(1, 64), quality=75, progressive=True))
+    (tmp_path / "zzz_text.jpeg").write_bytes(b"not a jpeg")
+    paths = sorted(str(tmp_path / f) for f in os.listdir(tmp_path))
+    want = [jpeg_lib.scan_file(p) for p in paths]
+    assert want[:3] == [(64, 64), (80, 80), (96, 96)] and want[-2:] == [None, None]
+    assert jpeg_lib.scan_files_in_processes(paths, 3) == want
+    assert jpeg_lib.scan_files_in_processes(paths[:1], 8) == want[:1]
