@@ -451,6 +451,31 @@ def test_planar_conv3x3_matches_reference(lib, case, nb, monkeypatch):
     torch.testing.assert_close(got, ref.bfloat16().float(), rtol=2 ** -7, atol=4e-3)
 
 
+@pytest.mark.parametrize("case", [(5, 40, 40, 192, 192, True), (9, 20, 20, 384, 384, True), (3, 40, 40, 256, 192, False), (2, 13, 24, 128, 192, True)])
+def test_planar_builds_are_bit_identical(lib, case, monkeypatch):
+    """The pixel-major builds (pm13w40 / pm13w20; pm13 at other widths under AQ_PL_PM=2), the slot-major assembly build (nb13) and the
+    HIP-source kernel are the same algorithm on the same tiles with the same MFMA order: their outputs are equal BIT FOR BIT, so which one
+    the launcher picks for an image width never changes a label byte."""
+    from aquaculture_amd import engine
+    B, H, W, cin, c, with_res = case
+    g = torch.Generator().manual_seed(H * 31 + cin)
+    x = (torch.randn(B, H, W, cin, generator=g) * 0.8).bfloat16().cuda()
+    w = torch.randn(c, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(c, generator=g) * 0.2
+    res = torch.randn(B, H, W, c, generator=g).bfloat16().cuda() if with_res else None
+    outs = {}
+    for name, env in (("default", {}), ("slot-major", {"AQ_PL_PM": "0"}), ("pixel-major any width", {"AQ_PL_PM": "2"}), ("HIP source", {"AQ_PL_ASM": "0", "AQ_PL_NB": "13"})):
+        for k in ("AQ_PL_PM", "AQ_PL_ASM", "AQ_PL_NB"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = torch.zeros(B, H, W, c, dtype=torch.bfloat16, device="cuda")
+        engine.conv3x3_pl_nhwc(x, w, b, True, residual=res, out=out)
+        outs[name] = out.view(torch.int16).cpu()
+    for name, o in outs.items():
+        assert torch.equal(o, outs["default"]), f"{name} differs from the default build in {int((o != outs['default']).sum())} values"
+
+
 def test_planar_conv3x3_in_engine(lib, synth_ck):
     """Forcing the planar kernel on every 3x3/s1 layer it supports leaves the head outputs within bf16 noise of the default engine."""
     from aquaculture_amd import engine, tiles
