@@ -112,7 +112,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     import fcntl
     with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        if not force and os.path.exists(LIB) and os.path.exists(JPEG_LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
             return LIB
         return _build_locked(dig, stamp, verbose)
 

@@ -57,6 +57,8 @@ typedef struct {
     uint64_t acc;                 /* bit accumulator, MSB first in the low `nbits` bits */
     int nbits;
     int marker;                   /* a marker was met: only zero bits follow */
+    int fake;                     /* zero bits appended after a marker / the end of the data; nbits < fake <=> the decoder has consumed
+                                     bits the file does not contain (truncated or marker-interrupted scan) */
 } Bits;
 
 static void fill(Bits* b) {
@@ -77,6 +79,7 @@ static void fill(Bits* b) {
         } else if (!b->marker) {
             b->marker = 1;
         }
+        if (b->marker) b->fake += 8;
         b->acc = (b->acc << 8) | c;
         b->nbits += 8;
     }
@@ -88,6 +91,8 @@ static int build(HuffTab* t, const uint8_t* counts, const uint8_t* vals, int nva
     memcpy(t->vals, vals, (size_t)nvals);
     for (int len = 1; len <= 16; ++len) {
         t->valoff[len] = k - code;
+        /* over-subscribed length: refuse BEFORE the look-up table is written (codes >= 2^len index past look[]) */
+        if (code + counts[len - 1] > (1 << len)) return AQJ_CORRUPT;
         for (int i = 0; i < counts[len - 1]; ++i, ++k, ++code) {
             if (k >= nvals) return AQJ_CORRUPT;
             if (len <= LOOK) {
@@ -96,7 +101,6 @@ static int build(HuffTab* t, const uint8_t* counts, const uint8_t* vals, int nva
             }
         }
         t->maxcode[len] = counts[len - 1] ? code - 1 : -1;
-        if (code > (1 << len)) return AQJ_CORRUPT;
         code <<= 1;
     }
     t->maxcode[17] = 0x7fffffff;
@@ -200,6 +204,9 @@ static int decode_block(Bits* b, const HuffTab* dc, const HuffTab* ac, int* pred
     }
 done:
     b->p = p; b->acc = acc; b->nbits = nbits;
+    /* bits past a marker or the end of the file were consumed: the scan is truncated or interrupted.  (fill() pads with zeros so that the
+     * bit reader never reads out of bounds; a decoder that went on would turn them into plausible grey blocks -- PIL raises here.) */
+    if (rc == AQJ_OK && nbits < b->fake) rc = AQJ_CORRUPT;
     return rc;
 }
 #undef REFILL
@@ -218,6 +225,7 @@ int aq_jpeg_decode_coeffs(const uint8_t* data, size_t n, int16_t* coef_out, size
     for (int i = 0; i < 4; ++i) hdc[i].present = hac[i].present = 0;
     int comp_id[3] = {0, 0, 0}, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0};
     int restart = 0, have_sof = 0;
+    int saw_jfif = 0, saw_adobe = 0, adobe_transform = 0;      /* colour-space signalling, as libjpeg's default_decompress_parms reads it */
     size_t pos = 2;
     while (pos + 4 <= n) {
         if (data[pos] != 0xFF) return AQJ_CORRUPT;
@@ -276,11 +284,21 @@ int aq_jpeg_decode_coeffs(const uint8_t* data, size_t n, int16_t* coef_out, size
             have_sof = 1;
         } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
             return AQJ_UNSUPPORTED;                              /* progressive, lossless, arithmetic */
+        } else if (m == 0xE0) {                                  /* APP0: "JFIF\0" means YCbCr whatever else the file says */
+            if (sl >= 5 && !memcmp(seg, "JFIF", 5)) saw_jfif = 1;
+        } else if (m == 0xEE) {                                  /* APP14: "Adobe" + version, flags0, flags1, transform (0 = RGB / CMYK as stored) */
+            if (sl >= 12 && !memcmp(seg, "Adobe", 5)) { saw_adobe = 1; adobe_transform = seg[11]; }
         } else if (m == 0xDD) {                                  /* DRI */
             if (sl < 2) return AQJ_CORRUPT;
             restart = (int)be16(seg);
         } else if (m == 0xDA) {                                  /* SOS: the one scan */
             if (!have_sof || sl < 1 || seg[0] != info->ncomp || sl < 1u + 2u * (unsigned)info->ncomp + 3u) return AQJ_UNSUPPORTED;
+            if (info->ncomp == 3 && !saw_jfif) {
+                /* libjpeg (jdapimin.c) and therefore Pillow / OpenCV treat the three components as RGB -- no colour conversion -- when an
+                 * Adobe marker says transform 0, or when there is no JFIF / Adobe marker and the component ids spell "RGB".  The device half
+                 * always converts YCbCr -> RGB, so such files go to the software decoder. */
+                if (saw_adobe ? adobe_transform == 0 : (comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B')) return AQJ_UNSUPPORTED;
+            }
             int tdc[3], tac[3];
             for (int c = 0; c < info->ncomp; ++c) {
                 if (seg[1 + 2 * c] != comp_id[c]) return AQJ_UNSUPPORTED;
@@ -301,7 +319,7 @@ int aq_jpeg_decode_coeffs(const uint8_t* data, size_t n, int16_t* coef_out, size
             if (!coef_out || total * 64 > cap) return AQJ_SPACE;
             memset(coef_out, 0, total * 64 * sizeof(int16_t));     /* one pass over the whole image: the blocks only write what is non-zero */
             Bits b;
-            b.p = data + pos + len; b.end = data + n; b.acc = 0; b.nbits = 0; b.marker = 0;
+            b.p = data + pos + len; b.end = data + n; b.acc = 0; b.nbits = 0; b.marker = 0; b.fake = 0;
             int pred[3] = {0, 0, 0};
             int left = restart, next_rst = 0;
             int16_t* cb = coef_out + ny * 64;
@@ -309,7 +327,7 @@ int aq_jpeg_decode_coeffs(const uint8_t* data, size_t n, int16_t* coef_out, size
             for (int my = 0; my < info->mcu_rows; ++my)
                 for (int mx = 0; mx < info->mcu_cols; ++mx) {
                     if (restart && left == 0) {                 /* expect RSTn: byte align, skip the marker, reset the predictors */
-                        b.nbits = 0; b.acc = 0;
+                        b.nbits = 0; b.acc = 0; b.fake = 0;
                         const uint8_t* q = b.p;
                         while (q + 1 < b.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) {
                             if (q[0] == 0xFF && q[1] != 0x00 && q[1] != 0xFF) return AQJ_CORRUPT;
@@ -339,7 +357,11 @@ int aq_jpeg_decode_coeffs(const uint8_t* data, size_t n, int16_t* coef_out, size
                     }
                     if (restart) --left;
                 }
-            return AQJ_OK;
+            /* the scan must be followed by EOI (fill() stops b.p at the first marker): a file cut right after its last MCU is as
+             * truncated for libjpeg / Pillow ("image file is truncated") as one cut earlier */
+            for (const uint8_t* q = b.p; q + 1 < b.end; ++q)
+                if (q[0] == 0xFF && q[1] != 0x00 && q[1] != 0xFF) return q[1] == 0xD9 ? AQJ_OK : AQJ_CORRUPT;
+            return AQJ_CORRUPT;
         }
         pos += len;
     }

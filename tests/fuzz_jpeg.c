@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
             size_t m = (size_t)n;
             uint8_t* buf = (uint8_t*)malloc(m + 64);
             memcpy(buf, orig, m);
-            const int kind = (int)(rnd() % 5);
+            const int kind = (int)(rnd() % 6);
             if (kind == 0) {                                        /* flip a few bytes anywhere */
                 for (int k = 0, c = 1 + (int)(rnd() % 8); k < c; ++k) buf[rnd() % m] ^= (uint8_t)(1u << (rnd() % 8));
             } else if (kind == 1) {                                 /* truncate */
@@ -43,6 +43,31 @@ int main(int argc, char** argv) {
             } else if (kind == 3) {                                 /* garbage in the entropy-coded data, incl. stray markers */
                 const size_t at = 700 + rnd() % (m > 800 ? m - 750 : 1);
                 for (size_t k = at; k < at + 1 + rnd() % 40 && k < m; ++k) buf[k] = (rnd() & 3) ? (uint8_t)rnd() : 0xFF;
+            } else if (kind == 4) {                                 /* rewrite a DHT's sixteen counts, keeping their SUM (so the segment length stays
+                                                                       consistent and the table builder is reached with over- or under-subscribed
+                                                                       lengths; ADVICE r03: random flips never got past the length check) */
+                size_t at = 2;
+                int nth = (int)(rnd() % 4);
+                while (at + 4 < m) {
+                    if (buf[at] != 0xFF) break;
+                    const unsigned mk = buf[at + 1], ln = ((unsigned)buf[at + 2] << 8) | buf[at + 3];
+                    if (mk == 0xDA) break;
+                    if (mk == 0xC4 && ln >= 19 && at + 2 + ln <= m && nth-- <= 0) {
+                        uint8_t* c = buf + at + 5;
+                        int sum = 0;
+                        for (int k = 0; k < 16; ++k) sum += c[k];
+                        memset(c, 0, 16);
+                        while (sum > 0) {                           /* pile the codes onto a few (mostly short) lengths */
+                            const int k = (rnd() & 3) ? (int)(rnd() % 4) : (int)(rnd() % 16);
+                            const int take = 1 + (int)(rnd() % (unsigned)sum);
+                            const int put = c[k] + take > 255 ? 255 - c[k] : take;
+                            c[k] = (uint8_t)(c[k] + put);
+                            sum -= put;
+                        }
+                        break;
+                    }
+                    at += 2 + ln;
+                }
             } else {                                                /* all ones / all zeros tail */
                 const size_t at = 2 + rnd() % (m - 2);
                 memset(buf + at, (rnd() & 1) ? 0xFF : 0x00, m - at);
