@@ -146,21 +146,45 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     # interrupted run recorded (reference idiom: skip-if-exists, src/load_data/tile_tifs.py:40-41 -- which label files cannot express)
     from .manifest import DoneManifest, check_run_params, file_digest, fsync_dir, sync_filesystem_of
     durable = not tile_scenes and os.environ.get("AQ_NO_FSYNC") != "1"     # (AQ_NO_FSYNC=1: only process kills are covered, as before round 3)
-    if rank == 0 and not tile_scenes:
-        # what the label bytes depend on; --resume refuses to continue a directory written with anything else
-        check_run_params(str(save_dir), {"weights_sha256": file_digest(weights) if os.path.isfile(str(weights)) else str(weights),
-                                         "conf_thres": float(conf_thres), "iou_thres": float(iou_thres), "max_det": int(max_det),
-                                         "imgsz": [int(v) for v in imgsz], "precision": precision, "save_conf": bool(save_conf)}, resume)
-    if multi:
-        aqdist.barrier()                                   # nobody processes a tile before rank 0 has accepted the directory
+    # what the label bytes depend on; --resume refuses to continue a directory written with anything else.  Collective: nobody processes
+    # a tile before rank 0 has accepted the directory, and a refusal reaches every rank.
+    aqdist.on_rank0(lambda: None if tile_scenes else check_run_params(
+        str(save_dir), {"weights_sha256": file_digest(weights) if os.path.isfile(str(weights)) else str(weights),
+                        "conf_thres": float(conf_thres), "iou_thres": float(iou_thres), "max_det": int(max_det),
+                        "imgsz": [int(v) for v in imgsz], "precision": precision, "save_conf": bool(save_conf)}, resume))
     done_before = DoneManifest.load(str(save_dir)) if resume else set()
     manifest = DoneManifest(str(save_dir), rank)
     if not tile_scenes:
         manifest.open()
 
     ck = load_checkpoint(weights)
-    eng = Engine(ck, precision, dev)
+    eng = Engine(ck, precision, dev, fp8_calibration="defer")
     imgsz = check_img_size(list(imgsz), s=int(max(ck.stride)))
+    if precision == "fp8":
+        # e4m3 activation scales from THIS sweep's imagery and tile size (the engine's default calibrates on synthetic 640-px
+        # tiles; real tiles beyond that range would saturate silently).  Rank 0 calibrates on tiles sampled across the whole file list, every
+        # rank installs the same scales, and they are recorded next to run_params.json so that --resume quantises the rest of the sweep
+        # exactly as the interrupted run did.
+        import json
+        rec = save_dir / "fp8_scales.json"
+
+        def calibrate():
+            if resume and rec.exists():
+                return json.loads(rec.read_text())
+            sc = eng.calibrate_fp8(_calibration_tiles(source, tile_scenes, imgsz, int(max(ck.stride)), dev))
+            tmp = str(rec) + ".tmp"
+            with open(tmp, "w") as f:
+                json.dump(sc, f, indent=1, sort_keys=True)
+                f.flush()
+                os.fsync(f.fileno())
+            os.replace(tmp, rec)
+            return sc
+        scales = aqdist.on_rank0(calibrate)
+        eng.set_fp8_scales(scales)
+        if rank == 0:
+            log(f"fp8: {len(scales)} activation scales calibrated on this sweep's tiles (recorded in {rec}); "
+                f"|t| range covered {min(scales.values()) * 448:.3g} .. {max(scales.values()) * 448:.3g}" if scales else
+                "fp8: no layer of this model runs in fp8 at this geometry (bf16 throughout)")
     # decoded images go to the GPU as they are; the letterbox (resize INTER_LINEAR + pad 114) runs on the device
     if tile_scenes:
         from .scenes import SceneTiles
@@ -449,6 +473,30 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     manifest.close()
     eng.close()
     return save_dir
+
+
+def _calibration_tiles(source, tile_scenes, imgsz, stride, dev, n=16):
+    """Up to `n` letterboxed tiles sampled evenly over the sweep's sorted file list (not its first files, which all come from one scene):
+    uint8 CUDA [b, H, W, 3], every tile of the first sample's original size.  Host decode -- it runs once per sweep."""
+    from .engine import letterbox_device
+    if tile_scenes:
+        from .scenes import list_scenes, read_scene, tile_grid
+        scenes = list_scenes(source)
+        picks = []
+        for sp in scenes[:: max(1, len(scenes) // 4)][:4]:
+            arr = read_scene(sp)
+            grid = tile_grid(arr.shape[1], arr.shape[0], int(tile_scenes))
+            grid = [g for g in grid if (g[2], g[3]) == (int(tile_scenes), int(tile_scenes))] or grid     # (scenes smaller than one tile: edge tiles)
+            for x, y, w, h in grid[:: max(1, len(grid) // 4)][:4]:
+                picks.append(np.ascontiguousarray(arr[y:y + h, x:x + w, :3]))
+    else:
+        from .dataloader import list_images, read_rgb
+        files = list_images(source)
+        picks = [read_rgb(f) for f in files[:: max(1, len(files) // n)][:n]]
+    picks = [p for p in picks if p.shape == picks[0].shape]
+    if not picks:
+        raise ValueError("fp8 calibration: no tiles to calibrate on")
+    return letterbox_device(torch.from_numpy(np.stack(picks)).to(dev), tuple(imgsz), stride, True)
 
 
 def main(argv: Optional[List[str]] = None) -> int:

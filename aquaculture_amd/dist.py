@@ -166,3 +166,24 @@ def reduce_counters(tiles: int, labels: int, dets: int, elapsed_s: float, device
 def barrier() -> None:
     if active():
         dist.barrier()
+
+
+def on_rank0(fn):
+    """Runs ``fn`` on rank 0 and hands its (picklable) result to every rank.  If it raises there, EVERY rank raises -- rank 0 the original
+    exception, the others a RuntimeError quoting it -- instead of the others waiting in their next collective until the launcher's timeout
+    kills them (the run-directory check of a --resume, the fp8 calibration record).  One broadcast; a plain call in a world of one."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    result, error = None, None
+    if rank == 0:
+        try:
+            result = fn()
+        except Exception as e:
+            error = e
+    if active():
+        wire = [result, None if error is None else f"{type(error).__name__}: {error}"]
+        dist.broadcast_object_list(wire, src=0)
+        if rank != 0:
+            result, error = wire[0], None if wire[1] is None else RuntimeError(f"rank 0 refused the run: {wire[1]}")
+    if error is not None:
+        raise error
+    return result

@@ -238,7 +238,9 @@ class Engine:
         self._ws: Optional[torch.Tensor] = None
         self._slots: Dict[int, torch.Tensor] = {}     # one workspace per in-flight batch (stream slot)
         self.fp8_scales: Dict[str, float] = {}        # fp8 engines: consumer op name -> e4m3 scale of its input tensor
-        if precision == "fp8":
+        if precision == "fp8" and not (isinstance(fp8_calibration, str) and fp8_calibration == "defer"):
+            # "defer": the caller calibrates on its own imagery (calibrate_fp8) or installs recorded scales (set_fp8_scales) before the first
+            # batch -- yolov5/detect.py does, on tiles sampled from the sweep; until then every pair runs in bf16 (scale 0)
             if fp8_calibration is None:
                 from . import tiles as _tiles
                 fp8_calibration = _tiles.synthetic_batch(list(range(8)), 640)
@@ -279,6 +281,22 @@ class Engine:
                 self.fp8_scales[self.plan.ops[cons].name] = float(scales[cons])
         _check(self.lib.aq_engine_set_fp8_scales(self.handle, scales, n))
         return dict(self.fp8_scales)
+
+    def set_fp8_scales(self, by_name: Dict[str, float]) -> None:
+        """Installs e4m3 activation scales recorded elsewhere (consumer op name -> scale, as calibrate_fp8 returns them): the other ranks of a
+        sweep take rank 0's, a resumed sweep takes the interrupted run's, so that every tile is quantised with the same scales."""
+        n = len(self.plan.ops)
+        scales = (C.c_float * n)()
+        names = {self.plan.ops[cons].name: cons for _, cons in self.fp8_pairs()}
+        unknown = sorted(set(by_name) - set(names))
+        if unknown:
+            raise ValueError(f"fp8 scales for ops this engine does not run in fp8: {unknown}")
+        for name, v in by_name.items():
+            if not (np.isfinite(v) and v > 0.0):
+                raise ValueError(f"fp8 scale of {name} must be positive and finite, got {v}")
+            scales[names[name]] = float(v)
+        _check(self.lib.aq_engine_set_fp8_scales(self.handle, scales, n))
+        self.fp8_scales = {k: float(v) for k, v in by_name.items()}
 
     def close(self) -> None:
         if getattr(self, "handle", None):

@@ -153,3 +153,45 @@ def test_shard_is_a_partition():
     g.add(torch.arange(3, dtype=torch.int32), torch.ones(3, aqdist.ROW))
     g.finish()
     assert g.total == 3 and g.table()[1].shape == (3, aqdist.ROW)
+
+
+def _rank0_worker(rank, world, port, fail, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    aqdist.init("gloo")
+    calls = []
+
+    def fn():
+        calls.append(rank)
+        if fail:
+            raise ValueError("directory was written with other settings")
+        return {"model.6.m.0.cv2": 0.125, "n": 3}
+    try:
+        got = aqdist.on_rank0(fn)
+        outcome = ("ok", got)
+    except Exception as e:
+        outcome = (type(e).__name__, str(e))
+    assert calls == ([0] if rank == 0 else [])          # fn runs on rank 0 only
+    aqdist.barrier()                                     # every rank is still in step afterwards (nobody is stuck in a collective)
+    torch.save(outcome, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("fail", [False, True])
+def test_on_rank0_hands_the_result_or_the_failure_to_every_rank(tmp_path, fail):
+    """rank 0's run-directory check could raise before a barrier the other ranks were already waiting in.  on_rank0
+    broadcasts the outcome: a result reaches every rank, a failure raises on every rank (the original exception on rank 0)."""
+    world = 3
+    mp.spawn(_rank0_worker, args=(world, _free_port(), fail, str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(str(tmp_path / f"r{r}.pt")) for r in range(world)]
+    if not fail:
+        assert all(o == ("ok", {"model.6.m.0.cv2": 0.125, "n": 3}) for o in outs)
+    else:
+        assert outs[0] == ("ValueError", "directory was written with other settings")
+        assert all(o[0] == "RuntimeError" and "rank 0 refused the run: ValueError: directory was written" in o[1] for o in outs[1:])
+
+
+def test_on_rank0_without_a_process_group_is_a_plain_call():
+    assert aqdist.on_rank0(lambda: 7) == 7
+    with pytest.raises(KeyError):
+        aqdist.on_rank0(lambda: {}["x"])

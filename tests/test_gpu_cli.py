@@ -364,3 +364,54 @@ def test_cli_names_the_file_a_decode_worker_rejects(workdir, lib, tmp_path):
                "--nosave", "--save-txt", "--save-conf", "--project", str(tmp_path / "runs"), "--name", "bad_" + mode, "--batch-size", "4", "--half", "--jpeg-decode", mode]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
         assert r.returncode != 0 and victim in (r.stderr + r.stdout), (mode, r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_cli_fp8_calibrates_on_the_sweeps_tiles_and_records_the_scales(workdir, lib):
+    """`--precision fp8` used to quantise every sweep with scales calibrated on eight synthetic 640-px tiles.  The CLI
+    now calibrates on tiles sampled from --source before the first batch, records the scales beside run_params.json, and a --resume
+    installs the recorded ones (so the rest of an interrupted sweep is quantised as its beginning was): the label bytes of a resumed fp8
+    sweep equal the uninterrupted one's."""
+    import json
+    import shutil
+    out, full = _run(workdir, "fp8_full", extra=("--quiet", "--precision", "fp8"))
+    assert "fp8: 14 activation scales calibrated on this sweep's tiles" in out
+    rec = json.load(open(workdir / "runs" / "fp8_full" / "fp8_scales.json"))
+    assert len(rec) == 14 and all(v > 0 for v in rec.values()) and all(k.endswith(".cv2") for k in rec)
+    assert json.load(open(workdir / "runs" / "fp8_full" / "run_params.json"))["precision"] == "fp8"
+    # an interrupted sweep: first six tiles, then --resume over the whole directory with the recorded scales
+    part = workdir / "jpegs_fp8_part"
+    part.mkdir(exist_ok=True)
+    names = sorted(os.listdir(workdir / "jpegs"))
+    for n in names[:6]:
+        shutil.copy(workdir / "jpegs" / n, part / n)
+    cmd = [sys.executable, os.path.join(ROOT, "yolov5", "detect.py"), "--weights", str(workdir / "multilabel_farms_synth.pt"), "--source", str(part),
+           "--nosave", "--save-txt", "--save-conf", "--project", str(workdir / "runs"), "--name", "fp8_resume", "--batch-size", "4", "--precision", "fp8", "--quiet"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run = workdir / "runs" / "fp8_resume"
+    shutil.copy(workdir / "runs" / "fp8_full" / "fp8_scales.json", run / "fp8_scales.json")      # (the part directory calibrated on other tiles)
+    out, labels = _run(workdir, "fp8_resume", extra=("--resume", "--quiet", "--precision", "fp8"))
+    assert json.load(open(run / "fp8_scales.json")) == rec
+    for f in sorted(os.listdir(full)):
+        stem = f[:-4]
+        if any(n.startswith(stem) for n in names[:6]):
+            continue                                               # written by the first part with ITS calibration
+        assert open(labels / f, "rb").read() == open(full / f, "rb").read(), f
+
+
+def test_cli_refuses_a_truncated_tile_in_both_decode_modes(workdir, lib, tmp_path):
+    """a half-written tile used to decode to grey blocks in split mode, get no labels and be recorded as done.  Both
+    modes now stop with the file's name, and the done-manifest does not list it."""
+    import shutil
+    src = tmp_path / "jpegs"
+    shutil.copytree(workdir / "jpegs", src)
+    victim = sorted(os.listdir(src))[5]
+    data = (src / victim).read_bytes()
+    (src / victim).write_bytes(data[: len(data) * 2 // 3])
+    for mode in ("split", "host"):
+        cmd = [sys.executable, os.path.join(ROOT, "yolov5", "detect.py"), "--weights", str(workdir / "multilabel_farms_synth.pt"), "--source", str(src),
+               "--nosave", "--save-txt", "--save-conf", "--project", str(tmp_path / "runs"), "--name", "trunc_" + mode, "--batch-size", "4", "--half", "--jpeg-decode", mode]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+        assert r.returncode != 0 and victim in r.stderr, (mode, r.stderr[-1500:])
+        done = tmp_path / "runs" / ("trunc_" + mode) / "done.rank0.txt"
+        assert not done.exists() or victim[:-5] not in open(done).read().split()
