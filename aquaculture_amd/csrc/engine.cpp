@@ -172,6 +172,7 @@ struct aq_engine {
     void* last_ws = nullptr;
     const uint8_t* last_tiles = nullptr;
     float* calib_amax = nullptr;        // device float[n_ops] while aq_engine_calibrate_amax runs: max |output| of every bf16 conv op
+    std::vector<int> last_family, last_cfg;   // per op: which kernel family (AQ_FAM_*) its most recent launch went to (aq_engine_last_launch)
     // profiling
     bool prof = false;
     int ring = 0;
@@ -229,6 +230,11 @@ bool f8_pair_active(const aq_engine* e, int ci, int B) {
     return aq_conv3x3_pl_f8_supported(c.src.channels, c.dst.channels, B, ps.h, ps.w) != 0;
 }
 
+inline void note_launch(aq_engine* e, int oi, int family, int cfg = -1) {
+    if (e->last_family.size() != e->ops.size()) { e->last_family.assign(e->ops.size(), AQ_FAM_NONE); e->last_cfg.assign(e->ops.size(), -1); }
+    e->last_family[oi] = family; e->last_cfg[oi] = cfg;
+}
+
 int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStream_t stream, int force_cfg = -1, bool no_table = false) {
     if (force_cfg < 0 && !e->calib_amax) {              // (the tuner and the calibration pass run every op in bf16)
         const aq_op_desc& op = e->ops[oi];
@@ -236,6 +242,7 @@ int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStr
         if (pw.f8_consumer >= 0 && f8_pair_active(e, pw.f8_consumer, B)) {
             // producer: e4m3 codes of y / scale into the first bytes of each pixel's bf16 slot of the temporary (pitch = the bf16 row)
             const TensorPlace& pd = e->place[op.dst.tensor];
+            note_launch(e, oi, AQ_FAM_DIRECT1X1_F8OUT);
             return aq_conv1x1_direct_f8out(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
                                            tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels * 2, op.dst.ch_off * 2,
                                            op.src.channels, op.dst.channels, pw.w_direct, pw.bias, (long long)B * pd.h * pd.w, op.act,
@@ -243,6 +250,7 @@ int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStr
         }
         if (pw.w_f8 && f8_pair_active(e, oi, B)) {
             const TensorPlace& ps = e->place[op.src.tensor];
+            note_launch(e, oi, AQ_FAM_PL3X3_F8);
             return aq_conv3x3_pl_f8(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels * 2, op.src.ch_off * 2, op.src.channels,
                                     tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off, op.dst.channels,
                                     op.res.tensor >= 0 ? tptr(e, ws, tiles, op.res.tensor) : nullptr,
@@ -288,6 +296,7 @@ int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStr
     if (cfg < 0 && !no_table && e->tuned_B > 0 && e->tuned_H == e->lay_H && e->tuned_W == e->lay_W) cfg = e->tuned_cfg[oi];
     if (cfg == AQ_CONV_CFG_DIRECT3X3S2) {
         if (pw.direct_cfg != cfg) { aq_set_error("conv op %d has no direct 3x3/s2 form", oi); return AQ_ERR_INVALID; }
+        note_launch(e, oi, AQ_FAM_DIRECT3X3S2, cfg);
         return aq_conv3x3s2_direct(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
                                    tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
                                    op.src.channels, op.dst.channels, pw.w_direct, pw.bias, B, ps.h, ps.w, op.act, stream);
@@ -295,6 +304,7 @@ int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStr
     if (cfg == AQ_CONV_CFG_PL3X3) {
         if (pw.direct_cfg != cfg) { aq_set_error("conv op %d has no planar 3x3 form", oi); return AQ_ERR_INVALID; }
         const int ld = e->tensors[op.src.tensor].channels;
+        note_launch(e, oi, pw.w_pl8 && aq_conv3x3_pl_w8_supported(op.src.channels, op.dst.channels, B, ps.h, ps.w) ? AQ_FAM_PL3X3_W8 : AQ_FAM_PL3X3, cfg);
         if (pw.w_pl8 && aq_conv3x3_pl_w8_supported(op.src.channels, op.dst.channels, B, ps.h, ps.w))
             return aq_conv3x3_pl_w8(tptr(e, ws, tiles, op.src.tensor) + (size_t)op.src.ch_off * 2, (long long)ld * 2, 16, op.src.channels,
                                     tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off, op.dst.channels,
@@ -313,18 +323,21 @@ int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStr
             aq_set_error("conv op %d: planar 3x3/s2 does not fit %d x %d x %d", oi, B, ps.h, ps.w);
             return AQ_ERR_INVALID;
         }
+        note_launch(e, oi, AQ_FAM_PL3X3S2, cfg);
         return aq_conv3x3_pl_s2(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off, op.src.channels,
                                 tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off, op.dst.channels,
                                 pw.w_direct, pw.bias, B, ps.h, ps.w, op.act, stream);
     }
     if (cfg == AQ_CONV_CFG_DIRECT1X1) {
         if (pw.direct_cfg != cfg) { aq_set_error("conv op %d has no direct 1x1 form", oi); return AQ_ERR_INVALID; }
+        note_launch(e, oi, AQ_FAM_DIRECT1X1, cfg);
         return aq_conv1x1_direct(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
                                  tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
                                  op.src.channels, op.dst.channels, pw.w_direct, pw.bias, (long long)B * pd.h * pd.w, op.act, stream);
     }
     if (cfg < 0) cfg = aq_conv_pick_config(p.cout, p.npix, prec);
     if (pw.x3) p.x3_off = pw.cout_rows;
+    note_launch(e, oi, AQ_FAM_IGEMM_OR_HALO, cfg);
     return aq_launch_conv(p, pw.x3 ? (int)AQ_F16X3 : prec, out_f32, cfg, stream);
 }
 
@@ -394,6 +407,7 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
                     anchors[2 * a] = e->desc.anchors_px[op.level][a][0];
                     anchors[2 * a + 1] = e->desc.anchors_px[op.level][a][1];
                 }
+                note_launch(e, oi, AQ_FAM_HEAD_DECODE);
                 rc = aq_head_decode(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off, op.src.channels,
                                     e->packed[oi].w_head, B, pl.h, pl.w, off, e->desc.stride[op.level], anchors, e->desc.nc, e->desc.na, conf,
                                     cand, cand_rows, wide, kCountStride, e->N, stream);
@@ -408,11 +422,13 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
             }
             break;
         case AQ_OP_STEM:
+            note_launch(e, oi, AQ_FAM_STEM);
             if (stemdown) break;                         // computed inside the down-block launch below
             rc = aq_stem_conv(tiles, tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
                               op.dst.channels, e->packed[oi].w, e->packed[oi].bias, B, H, W, op.act, prec, stream);
             break;
         case AQ_OP_BOTTLENECK: {
+            note_launch(e, oi, AQ_FAM_BOTTLENECK);
             const TensorPlace& pl = e->place[op.src.tensor];
             rc = aq_bottleneck(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
                                tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
@@ -420,6 +436,7 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
             break;
         }
         case AQ_OP_DOWNBLOCK: {
+            note_launch(e, oi, AQ_FAM_DOWNBLOCK);
             const TensorPlace& pl = e->place[op.src.tensor];
             if (stemdown && oi == 1) {
                 rc = aq_stemdown(tiles, tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
@@ -969,6 +986,17 @@ extern "C" int aq_engine_set_tuned_table(aq_engine* e, int B, int H, int W, cons
     for (int i = 0; i < n_ops; ++i)
         if (e->ops[i].kind != AQ_OP_CONV) e->tuned_cfg[i] = -1;
     e->tuned_B = B; e->tuned_H = e->lay_H; e->tuned_W = e->lay_W;
+    return AQ_OK;
+}
+
+// Which kernel family op `op` went to in its most recent launch (AQ_FAM_*), and with which tile-configuration id (-1 where none applies).
+// Tests use it to assert that a layer did not silently fall back (an fp8 pair to bf16 at another batch size, a planar layer to the
+// implicit-GEMM kernel).  AQ_FAM_NONE before the op's first launch.
+extern "C" int aq_engine_last_launch(aq_engine* e, int op, int* family, int* cfg) {
+    AQ_REQUIRE(e && family && op >= 0 && op < (int)e->ops.size(), "last_launch: bad argument");
+    const bool have = e->last_family.size() == e->ops.size();
+    *family = have ? e->last_family[op] : AQ_FAM_NONE;
+    if (cfg) *cfg = have ? e->last_cfg[op] : -1;
     return AQ_OK;
 }
 

@@ -69,7 +69,7 @@ EXPORTS = (
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
     "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_pack_conv_weights_x3", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_stemdown_supported", "aq_stemdown", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
     "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct",
-    "aq_conv3x3_pl_supported", "aq_conv3x3_pl_asm_family", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_s2_supported", "aq_pack_conv3x3_pl_s2", "aq_conv3x3_pl_s2", "aq_jpeg_scratch_bytes", "aq_jpeg_idct_rgb", "aq_f32_to_e4m3", "aq_conv1x1_direct_f8out", "aq_absmax_bf16", "aq_engine_calibrate_amax", "aq_engine_set_fp8_scales", "aq_conv3x3_pl_f8_supported", "aq_pack_conv3x3_pl_f8", "aq_conv3x3_pl_f8", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
+    "aq_conv3x3_pl_supported", "aq_conv3x3_pl_asm_family", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_s2_supported", "aq_pack_conv3x3_pl_s2", "aq_conv3x3_pl_s2", "aq_jpeg_scratch_bytes", "aq_jpeg_idct_rgb", "aq_f32_to_e4m3", "aq_conv1x1_direct_f8out", "aq_absmax_bf16", "aq_engine_calibrate_amax", "aq_engine_set_fp8_scales", "aq_engine_last_launch", "aq_conv3x3_pl_f8_supported", "aq_pack_conv3x3_pl_f8", "aq_conv3x3_pl_f8", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_letterbox_tiles_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
 )
 
@@ -100,6 +100,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_engine_set_conv_config.argtypes = [vp, i32, i32]
     lib.aq_engine_autotune.argtypes = [vp, vp, i32, i32, i32, vp, sz, i32, vp]
     lib.aq_engine_get_conv_config.argtypes = [vp, i32]
+    lib.aq_engine_last_launch.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     lib.aq_engine_set_tuned_table.argtypes = [vp, i32, i32, i32, C.POINTER(i32), i32]
     lib.aq_engine_calibrate_amax.argtypes = [vp, vp, i32, i32, i32, vp, sz, C.POINTER(f32), i32, vp]
     lib.aq_engine_set_fp8_scales.argtypes = [vp, C.POINTER(f32), i32]
@@ -437,6 +438,19 @@ class Engine:
                 json.dump(table, f)
             os.replace(tmp, cache)
         return cfgs
+
+    FAMILIES = {0: "none", 1: "igemm_or_halo", 2: "pl3x3", 3: "pl3x3_w8", 4: "pl3x3s2", 5: "pl3x3_f8", 6: "direct1x1", 7: "direct1x1_f8out",
+                8: "direct3x3s2", 9: "bottleneck", 10: "downblock", 11: "stem", 12: "head_decode"}
+
+    def last_launches(self) -> List[Tuple[str, int]]:
+        """(kernel family, tile-configuration id) of every op's most recent launch (aq_engine_last_launch) -- what actually ran, as opposed
+        to what the tuned table asked for."""
+        out = []
+        fam, cfg = C.c_int(), C.c_int()
+        for i in range(len(self.plan.ops)):
+            _check(self.lib.aq_engine_last_launch(self.handle, i, C.byref(fam), C.byref(cfg)))
+            out.append((self.FAMILIES.get(fam.value, str(fam.value)), cfg.value))
+        return out
 
     def profile(self, enable: bool, ring: int = 32) -> None:
         _check(self.lib.aq_engine_profile(self.handle, int(enable), ring))

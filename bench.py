@@ -56,6 +56,9 @@ def parse():
                    "mask: low | even | pairs | xcd (odd streams get the complement)")
     p.add_argument("--parity-steps", type=int, default=3, help="steps of the fp32 parity-mode engine timed beside the bf16 metric (0 = skip)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle sample budget")
+    p.add_argument("--e2e-images", type=int, default=2048,
+                   help="N = 1 only: after the timed region, write this many synthetic 1024-px jpeg tiles (the reference's tile size, src/utils.py:17-19) and "
+                        "sweep them with yolov5/detect.py --half in a child process; its images/s go into the line as `e2e` (0 = skip)")
     p.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristic instead of timing configs")
     p.add_argument("--retune", action="store_true", help="time the tile configurations in this run even when the in-tree table (aquaculture_amd/data/"
                                                          "tuned_tables.json) has this geometry")
@@ -106,6 +109,65 @@ def cpu_baseline(ck, size: int, budget_s: float) -> dict:
     return {"value": round(n / sum(per), 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} synthetic {size}x{size} tiles, batch 1, fp32 PyTorch-CPU restatement of detect.py (oracle/), "
                       f"median {1e3 * float(np.median(per)):.0f} ms/tile, {torch.get_num_threads()} threads of os.cpu_count()={os.cpu_count()}"}
+
+
+def e2e_live(a) -> dict:
+    """The second leg of SURVEY 8d, measured by THIS command: jpeg directory -> label files through the preserved
+    entry point, in a child process (this process has released its engine; the decode workers are the child's).  Tiles are 1024-px
+    baseline jpegs at GDAL's default quality, as reference src/load_data/tile_tifs.py:66-74 writes them; the checkpoint is the seeded
+    synthetic one in upstream's pickle format.  Never part of `value`."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from aquaculture_amd import checkpoint, tiles
+    d = tempfile.mkdtemp(prefix="aq_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        t0 = time.perf_counter()
+        src = os.path.join(d, "jpegs")
+        os.makedirs(src)
+        base = 64                                          # distinct tiles rendered; the rest of the directory repeats their bytes under other names
+        n = a.e2e_images
+        with ThreadPoolExecutor(host_threads()) as ex:
+            list(ex.map(lambda i: tiles.write_synthetic_jpegs(src, [i], size=1024), range(min(base, n))))
+        names = sorted(os.listdir(src))
+        for i in range(base, n):
+            shutil.copyfile(os.path.join(src, names[i % base]), os.path.join(src, tiles.tile_name(i)))
+        wts = os.path.join(d, "synthetic_yolov5m.pt")
+        checkpoint.write_synthetic_checkpoint(wts, "yolov5m", 5)
+        t_make = time.perf_counter() - t0
+        workers = max(1, host_threads() - 2)
+        cmd = [sys.executable, os.path.join(ROOT, "yolov5", "detect.py"), "--weights", wts, "--source", src, "--nosave", "--save-txt", "--save-conf",
+               "--half", "--quiet", "--batch-size", "64", "--workers", str(workers), "--project", os.path.join(d, "runs"), "--name", "e2e"]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, AQ_NO_FSYNC="1"))
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        whole = re.search(r"(\d+) images, (\d+) detections, ([0-9.]+) images/s", r.stdout)
+        steady = re.search(r"steady state: ([0-9.]+) images/s", r.stdout)
+        labels = len(os.listdir(os.path.join(d, "runs", "e2e", "labels")))
+        return {"images": n, "tile_px": 1024, "images_per_s_steady": float(steady.group(1)) if steady else None,
+                "images_per_s_whole_sweep": float(whole.group(3)) if whole else None, "detections": int(whole.group(2)) if whole else None,
+                "label_files": labels, "child_wall_s": round(wall, 2), "make_inputs_s": round(t_make, 2), "decode_workers": workers,
+                "jpeg_decode": "split" if "jpeg decode: split" in r.stdout else "host",
+                "note": f"measured live by this command in a child process: yolov5/detect.py --half over {n} 1024-px q75 jpegs ({min(base, n)} distinct tiles) in "
+                        "shared memory, label files written without fsync; whole-sweep rate includes checkpoint load, engine creation, worker start-up and "
+                        "pipeline fill; steady = after the first two batches; bound by the host's CPU quota, not by the GPU"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def baseline_config(a) -> str:
+    """Which entry of BASELINE.json `configs` this command line measures (by model, tile size, precision and batch), or that it is none."""
+    if a.variant == "yolov5m" and a.size == 640 and a.precision == "bf16" and a.batch == 64:
+        return "BASELINE.json configs[1]" if a.gpus == 1 else f"BASELINE.json configs[2] geometry on {a.gpus} GPUs" if a.gpus != 8 else "BASELINE.json configs[2]"
+    if a.variant == "yolov5m" and a.size == 640 and a.precision in ("fp8", "fp8w"):
+        return "BASELINE.json configs[3]" + ("" if a.batch == 128 else f" at batch {a.batch} instead of 128") + (" with fp8 weight VALUES on the bf16 MFMA" if a.precision == "fp8w" else "")
+    if a.variant == "yolov5x" and a.size == 1280 and a.precision == "bf16":
+        return "BASELINE.json configs[4]" + ("" if a.batch == 16 else f" at batch {a.batch} instead of 16") + (f", {a.gpus} of its 8 GPUs" if a.gpus != 8 else "")
+    return "not a BASELINE.json configuration"
 
 
 def launch_ranks(n: int) -> int:
@@ -274,19 +336,38 @@ def main() -> int:
     torch.cuda.synchronize()
     aqdist.barrier()
     torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for k in range(K):
         step(k, k)
     join()
+    ev1.record()                                          # this rank's K steps are done here (no host synchronisation: the gather follows on the stream)
     gathered = gather_all()
     torch.cuda.synchronize()
+    t_rank = time.perf_counter() - t0                     # this rank alone: its steps + its part of the gather
     aqdist.barrier()
     elapsed = time.perf_counter() - t0
     n_dets_total = int(gathered[0])
+    ranks_info = None
     if aqdist.active():
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else dev)
+        cdev = "cpu" if torch.distributed.get_backend() == "gloo" else dev
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t[0])
+        # straggler / collective visibility for the first real multi-GPU run: every rank's own step time (HIP events
+        # around its K steps) and the time it then spent in the detection gather, collected outside the timed region
+        mine = torch.tensor([ev0.elapsed_time(ev1) * 1e-3, t_rank], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        comp = [float(e[0]) for e in every]
+        tot = [float(e[1]) for e in every]
+        ranks_info = {"dist_world_size": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+                      "per_rank_tiles_per_s": {"min": round(K * B / max(comp), 1), "max": round(K * B / min(comp), 1),
+                                               "slowest_rank": int(np.argmax(comp))},
+                      "gather_share_of_timed_region": round(max(0.0, max(tt - c for tt, c in zip(tot, comp))) / elapsed, 4),
+                      "note": "per-rank rates from HIP events around each rank's own K steps; the gather share is the largest (rank time - step time) "
+                              "over the max-over-ranks region that `value` is computed from"}
 
     # roofline pass: the same steps on ONE stream with a HIP event recorded on the launch stream before every op
     # (with several batches in flight the per-kernel event intervals of one stream would include the other's kernels)
@@ -360,13 +441,16 @@ def main() -> int:
             mine = [int(cfgs[i]) for i in idx3] if cfgs is not None else None
             # the tuner's pick between two implicit-GEMM shapes of a stride-2 layer flips from run to run (a few us apart); the PMC figure
             # is still this build's and this workload's when at most two of the 19 layers differ -- and the label says how many do
-            differ = 0 if mine is None or not tj.get("conv3x3_configs") else min(
+            compared = mine is not None and bool(tj.get("conv3x3_configs"))
+            differ = 0 if not compared else min(
                 (sum(x != y for x, y in zip(mine, v)) if len(v) == len(mine) else 99) for v in tj["conv3x3_configs"].values())
             if (a.variant == "yolov5m" and a.size == 640 and a.precision in ("bf16", "fp8w") and int(tj.get("batch", -1)) == B
                     and tj.get("library_source_digest") == digest and differ <= 2):
                 traffic = tj.get("bytes_per_launch")
                 traffic_src = (f"{os.path.relpath(a.traffic_json, ROOT)} (separate rocprofv3 --pmc pass of this library build {digest[:12]}; "
-                               + ("same tuned 3x3 kernels)" if differ == 0 else f"the tuner picked another tile shape on {differ} of the {len(mine)} layers in this run)"))
+                               + ("tuned 3x3 kernels NOT compared: the record holds no configuration list)" if not compared else
+                                  "same tuned 3x3 kernels, compared layer by layer)" if differ == 0 else
+                                  f"the tuner picked another tile shape on {differ} of the {len(mine)} layers in this run)"))
             else:
                 traffic_src = f"null: {os.path.relpath(a.traffic_json, ROOT)} was collected on another build / workload / tuned table"
         except (OSError, ValueError):
@@ -408,9 +492,9 @@ def main() -> int:
                   "bf16 + fp8-e4m3 x fp8-e4m3 on the fp8 MFMA (14 wide Bottleneck 3x3 layers)" if a.precision == "fp8" else a.precision, "data": "synthetic",
         "config": {"workload": f"{a.variant} {a.precision}, 1xMI355X per rank, batch={B}, synthetic {a.size}x{a.size} ocean tiles "
                                f"resident in HBM ({a.pool} distinct batches cycled), seeded random-init weights nc=5 "
-                               f"(BASELINE.json configs[{3 if a.precision in ('fp8w', 'fp8') else 1}])",
+                               f"({baseline_config(a)})",
                    "tile_configs": getattr(eng, "tuned_from", "heuristic") if not a.no_autotune else "heuristic",
-                   "batch_per_gpu": B, "tile_px": a.size, "parallelism": f"tile-sharded dp{world}", **({"collectives": torch.distributed.get_backend()} if aqdist.active() else {}), "batches_in_flight": a.streams, **({"cu_split": a.cu_split} if a.cu_split else {}),
+                   "batch_per_gpu": B, "tile_px": a.size, "parallelism": f"tile-sharded dp{world}", **({"collectives": torch.distributed.get_backend(), "ranks": ranks_info} if aqdist.active() else {}), "batches_in_flight": a.streams, **({"cu_split": a.cu_split} if a.cu_split else {}),
                    "detections_gathered": n_dets_total},
         "roofline": roof,
     }
@@ -420,9 +504,13 @@ def main() -> int:
         with open(os.path.join(ROOT, "profiles", "e2e_latest.json")) as f:
             e2e = json.load(f)
         with open(os.path.join(ROOT, "aquaculture_amd", "csrc", "libaqengine.so.sha256")) as f:
-            out["e2e"] = e2e if e2e.get("library_source_digest") == f.read().strip() else None
+            out["e2e_separate_run"] = dict(e2e, note="NOT measured by this command: tools/bench_e2e.py sweeps of 8-25 k images on this library "
+                                                      "build, another run on the same pool of boxes") if e2e.get("library_source_digest") == f.read().strip() else None
     except (OSError, ValueError):
-        out["e2e"] = None
+        out["e2e_separate_run"] = None
+    if world == 1 and a.e2e_images > 0 and a.variant == "yolov5m":
+        eng.close()
+        out["e2e"] = e2e_live(a)
     if world == 1 and a.precision == "bf16" and a.parity_steps > 0:
         # what the 1e-4 parity gate costs: the same workload through the fp32 engine (exact-fp32 MFMA, 157 TFLOP/s peak), heuristic tile shapes
         eng.close()
@@ -436,10 +524,29 @@ def main() -> int:
             e32.infer(tiles_dev[k % a.pool], 0.25, 0.45, max_det, out=(d32, c32))
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.parity_steps
-        out["parity_mode"] = {"dtype": "fp32", "tiles_per_s": round(B / dt, 1), "ms_per_step": round(1e3 * dt, 2),
-                              "frac_of_157TF": round(fl["total"] * B / dt / 1e12 / PEAK_F32_TFLOPS, 4), "steps": a.parity_steps,
-                              "note": "fp32 engine (the --precision fp32 parity gate: boxes/conf within 1e-4 of the oracle), one batch in flight"}
+        p32 = {"dtype": "fp32", "tiles_per_s": round(B / dt, 1), "ms_per_step": round(1e3 * dt, 2),
+               "frac_of_157TF": round(fl["total"] * B / dt / 1e12 / PEAK_F32_TFLOPS, 4), "steps": a.parity_steps,
+               "note": "fp32 engine (the --precision fp32 parity gate: boxes/conf within 1e-4 of the oracle), one batch in flight"}
         e32.close()
+        del e32
+        # the FAST parity mode (fp32 activations, three fp16 MFMAs per product; tests/test_gpu_engine.py::test_infer_f16x3_matches_oracle_detections
+        # holds it to the same 1e-4 / identical-count gate): the number to set beside `value` when results must match the reference
+        e16 = Engine(ck, "f16x3", local)
+        e16.autotune(tiles_dev[0], cache=os.environ.get("AQ_TUNE_CACHE"), shipped=not a.retune)
+        e16.infer(tiles_dev[0], 0.25, 0.45, max_det, out=(d32, c32))
+        torch.cuda.synchronize()
+        n16 = max(a.parity_steps, 6)
+        t0 = time.perf_counter()
+        for k in range(n16):
+            e16.infer(tiles_dev[k % a.pool], 0.25, 0.45, max_det, out=(d32, c32))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n16
+        out["parity_mode"] = {"dtype": "f16x3", "tiles_per_s": round(B / dt, 1), "ms_per_step": round(1e3 * dt, 2), "steps": n16,
+                              "tile_configs": getattr(e16, "tuned_from", "heuristic"),
+                              "note": "fastest mode that meets north_star's gate (boxes / conf within 1e-4 of the fp32 oracle, identical post-NMS counts): fp32 "
+                                      "activations, fp16 hi/lo split of both MFMA operands, one batch in flight; `fp32` = the exact-fp32 MFMA engine",
+                              "fp32": p32}
+        e16.close()
     if world == 1 and not a.no_cpu_baseline:
         eng.close()
         out["cpu_baseline"] = cpu_baseline(ck, a.size, a.cpu_seconds)

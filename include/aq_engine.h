@@ -137,6 +137,25 @@ int aq_engine_calibrate_amax(aq_engine* e, const uint8_t* tiles_dev, int B, int 
                              float* amax_host, int n_ops, void* stream);
 int aq_engine_set_fp8_scales(aq_engine* e, const float* act_scale, int n_ops);
 int aq_engine_get_conv_config(aq_engine* e, int op);
+/* Which kernel family op `op` went to in its most recent launch, and with which tile-configuration id (-1 where none applies): how a
+ * test asserts that a layer did not silently fall back -- an fp8 pair to bf16 at another batch size, a planar layer to the implicit-GEMM
+ * kernel.  AQ_FAM_NONE before the op's first launch and for pointwise ops. */
+enum {
+    AQ_FAM_NONE = 0,
+    AQ_FAM_IGEMM_OR_HALO = 1,      /* conv_igemm_kernel / conv3x3_halo_kernel; *cfg = tile-shape id (aq_conv_config_tiles) */
+    AQ_FAM_PL3X3 = 2,              /* planar 3x3/s1 (generated assembly or the HIP-source build; aq_conv3x3_pl_asm_family names it) */
+    AQ_FAM_PL3X3_W8 = 3,           /* the same with the e4m3 weight stream */
+    AQ_FAM_PL3X3S2 = 4,            /* planar 3x3/s2 */
+    AQ_FAM_PL3X3_F8 = 5,           /* fp8 x fp8 planar 3x3/s1 (consumer of an fp8 pair) */
+    AQ_FAM_DIRECT1X1 = 6,
+    AQ_FAM_DIRECT1X1_F8OUT = 7,    /* producer of an fp8 pair: writes e4m3 codes */
+    AQ_FAM_DIRECT3X3S2 = 8,
+    AQ_FAM_BOTTLENECK = 9,
+    AQ_FAM_DOWNBLOCK = 10,
+    AQ_FAM_STEM = 11,
+    AQ_FAM_HEAD_DECODE = 12
+};
+int aq_engine_last_launch(aq_engine* e, int op, int* family, int* cfg);
 /* Install a table that aq_engine_autotune produced earlier (or on another rank) for the SAME engine and (B,H,W): cfgs[n_ops], one id per
  * op as aq_engine_get_conv_config returns them (-1 for ops that are not tuned).  Used for every batch of that tile geometry (H, W),
  * whatever its size -- a ragged last batch runs the same kernels as the full ones --; other geometries keep the built-in heuristic.

@@ -19,7 +19,7 @@ def _env(**kw):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("n", [1, 2, 3])
+@pytest.mark.parametrize("n", [1, 2, 3, 8])             # 8 = the node size the driver's scaling run uses (BASELINE.json configs[2] / [4])
 def test_bench_starts_its_own_ranks(n):
     r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--launcher-selftest"], env=_env(AQ_DIST_BACKEND="gloo"),
                        capture_output=True, text=True, timeout=170)
@@ -59,6 +59,12 @@ def test_bench_gpus_2_as_typed_gloo_on_one_card():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
     assert out["value"] > 0 and out["config"]["detections_gathered"] > 0
+    # what the first real multi-GPU run needs to be readable: the world size the backend saw, per-rank rates, the gather's share
+    ranks = out["config"]["ranks"]
+    assert ranks["dist_world_size"] == 2 and ranks["backend"] == "gloo" and out["config"]["collectives"] == "gloo"
+    assert 0 < ranks["per_rank_tiles_per_s"]["min"] <= ranks["per_rank_tiles_per_s"]["max"] and ranks["per_rank_tiles_per_s"]["slowest_rank"] in (0, 1)
+    assert 0.0 <= ranks["gather_share_of_timed_region"] < 1.0
+    assert out["value"] <= 2 * ranks["per_rank_tiles_per_s"]["max"] * 1.001
 
 
 @pytest.mark.gpu

@@ -163,6 +163,9 @@ def test_infer_deterministic(lib, synth_ck, tiles_640):
             assert torch.equal(d0[b, :c0[b]], d1[b, :c1[b]])
 
 
+MAX_DIFFERING_LINES = 6      # of ~5,500 golden label lines (0.5 % would be 27); tightened to the measured count + margin in round 4
+
+
 def test_fp32_engine_reproduces_golden_detections_and_label_text(lib, synth_ck):
     """All 16 config-1 tiles against the committed fixtures (tests/golden/g3_*): same box count per tile, boxes/conf
     within 1e-4, and the label text the reference's consumer parses is the same (a digit may differ only where a
@@ -180,6 +183,7 @@ def test_fp32_engine_reproduces_golden_detections_and_label_text(lib, synth_ck):
     dets, counts = dets.cpu().numpy(), counts.cpu().numpy()
     _match(dets, counts, [g[f"det_{i}"] for i in range(16)], box_tol=640 * 1e-4, conf_tol=1e-4)
     total = same = 0
+    differing = []                                        # (tile, golden line) without a partner in the engine's file
     for i in range(16):
         got = postprocess.format_rows(postprocess.detections_to_rows(dets[i, :counts[i]], (640, 640), (640, 640))).splitlines()
         want = labels[tiles.tile_name(i)].split("\n")
@@ -197,8 +201,14 @@ def test_fp32_engine_reproduces_golden_detections_and_label_text(lib, synth_ck):
             if hit:
                 cands.remove(hit[0])
                 same += 1
+            else:
+                differing.append((i, l))
         total += len(want)
-    assert same >= 0.995 * total, f"only {same}/{total} label lines agree"
+    # The consumer is digit-sensitive, so the bound is a COUNT of named lines, not a percentage: a box whose fp32 coordinate
+    # sits within the engine-vs-oracle difference (<= 1e-4 x 640 px, asserted above) of a .5 rounding boundary prints a neighbouring integer
+    # pixel.  Measured on MI355X (round 4): see MAX_DIFFERING_LINES below; every such line must be one of those boundary cases.
+    print(f"golden labels: {same}/{total} lines identical as text (conf compared as a number); differing: {differing}")
+    assert len(differing) <= MAX_DIFFERING_LINES, f"{len(differing)} of {total} label lines differ: {differing}"
 
 
 def test_full_batch_is_batch_invariant(lib, synth_ck):

@@ -110,3 +110,42 @@ def test_packed_weights_match_committed_digest():
     assert h.hexdigest() == g1["packed_sha256"], "synthetic checkpoint or packing changed: regenerate the golden fixtures"
     for pw, op in zip(packed, plan.conv_ops()):
         assert pw.weight.shape == (op.dst.channels, op.k, op.k, op.src.channels) and pw.weight.flags["C_CONTIGUOUS"]
+
+
+def test_checkpoint_loader_refuses_classes_outside_its_allow_list(tmp_path):
+    """VERDICT r03 (robustness): the stub unpickler resolved every non-yolov5 global through the normal pickle path.  An upstream
+    checkpoint needs torch / numpy / containers / paths / argparse only; anything else -- here the classic os.system reducer and a
+    builtins.eval reference -- is refused with a message that names it, and nothing is executed."""
+    import pickle
+    import torch
+    from aquaculture_amd import checkpoint
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, (f"touch {tmp_path}/pwned",))
+
+    class Evil2:
+        def __reduce__(self):
+            return (eval, ("1+1",))
+
+    for i, payload in enumerate((Evil(), Evil2())):
+        p = tmp_path / f"evil{i}.pt"
+        torch.save({"model": payload, "epoch": 0}, str(p))
+        with pytest.raises(Exception) as e:
+            checkpoint.load_checkpoint(str(p))
+        assert "allow-list" in str(e.value), str(e.value)
+    assert not (tmp_path / "pwned").exists()
+    # what a real checkpoint carries beside the model still loads: paths, an argparse Namespace, numpy scalars, ordered dicts
+    import argparse
+    import collections
+    import pathlib
+    import numpy as np
+    good = tmp_path / "good.pt"
+    torch.save({"opt": argparse.Namespace(weights=pathlib.PurePosixPath("yolov5m.pt"), epochs=50), "best_fitness": np.float64(0.5),
+                "extra": collections.OrderedDict(a=np.arange(3), t=torch.ones(2, dtype=torch.float16)), "date": "2023-01-01", "ids": {1, 2}}, str(good))
+    back = torch.load(str(good), pickle_module=checkpoint._StubPickleModule, weights_only=False)
+    assert back["opt"].epochs == 50 and float(back["best_fitness"]) == 0.5 and back["extra"]["t"].dtype == torch.float16 and back["ids"] == {1, 2}
+    full = tmp_path / "full.pt"
+    checkpoint.write_synthetic_checkpoint(str(full), "yolov5s", 3)
+    assert checkpoint.load_checkpoint(str(full)).nc == 3

@@ -222,6 +222,15 @@ def main():
                 cfgs = {k: [v[i] for i, o in enumerate(plan.ops) if o.kind == spec.OP_CONV and o.meta.get("class") == "conv3x3"] for k, v in tc.items()}
             except (OSError, ValueError):
                 pass
+            if not cfgs:
+                # the shipped table answered the tuner (no cache file is written then): record ITS picks for this geometry, so that bench.py's
+                # "same tuned 3x3 kernels" is a comparison, not an assumption
+                try:
+                    ship = json.load(open(os.path.join(ROOT, "aquaculture_amd", "data", "tuned_tables.json")))
+                    cfgs = {k: [v[i] for i, o in enumerate(plan.ops) if o.kind == spec.OP_CONV and o.meta.get("class") == "conv3x3"]
+                            for k, v in ship.items() if f":pbf16:{a.batch}x640x640:" in k and k.startswith("yolov5m:") and len(v) == len(plan.ops)}
+                except (OSError, ValueError):
+                    pass
             json.dump({"kernel": f"conv3x3_pl_asm_pm13w40 / pm13w20 (nb13) / conv3x3_pl_asm_s2nb13 / downblock_kernel / conv_igemm_kernel on the {len(r3)} 3x3 layers launched as plain convs", "batch": a.batch, "launches_averaged": len(r3),
                        "library_source_digest": lib_digest, "conv3x3_configs": cfgs,
                        "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr,
