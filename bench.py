@@ -56,7 +56,7 @@ def parse():
                    "mask: low | even | pairs | xcd (odd streams get the complement)")
     p.add_argument("--parity-steps", type=int, default=3, help="steps of the fp32 parity-mode engine timed beside the bf16 metric (0 = skip)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle sample budget")
-    p.add_argument("--e2e-images", type=int, default=2048,
+    p.add_argument("--e2e-images", type=int, default=8192,
                    help="N = 1 only: after the timed region, write this many synthetic 1024-px jpeg tiles (the reference's tile size, src/utils.py:17-19) and "
                         "sweep them with yolov5/detect.py --half in a child process; its images/s go into the line as `e2e` (0 = skip)")
     p.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristic instead of timing configs")

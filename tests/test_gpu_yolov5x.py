@@ -25,9 +25,9 @@ def test_yolov5x_fp32_matches_oracle(lib, ck_x):
     assert (pred[..., 4:] - ref_pred[..., 4:]).abs().max().item() <= 1e-4
     dbox = (pred[..., :4] - ref_pred[..., :4]).abs().max().item()
     print(f"yolov5x fp32 vs oracle at 128 px: max |d box| {dbox:.3e} px, max |d conf| {(pred[..., 4:] - ref_pred[..., 4:]).abs().max().item():.3e}")
-    # 1e-4 of the range of a box coordinate, which the anchors set (up to 373 px x 4), not the 128-px tile: the same 640e-4 px as every
-    # other fp32 parity test (round 3: 128e-4 + 1e-3 of unexplained slack)
-    assert dbox <= 640 * 1e-4
+    # north_star's 1e-4 of the tile size, with no slack on top (round 3 added 1e-3 px): measured on MI355X (round 4) 9.1e-3 px on boxes
+    # whose extent the anchors set (up to 373 px x 4, whatever the tile size), and 2.5e-5 on confidences
+    assert dbox <= 128 * 1e-4
     ref = O.non_max_suppression(ref_pred.numpy())
     dets, counts = eng.infer(torch.from_numpy(x).cuda())
     assert counts.cpu().tolist() == [r.shape[0] for r in ref]
