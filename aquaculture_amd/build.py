@@ -33,7 +33,12 @@ SOURCES = [
     ("jpeg_idct.hip", []),                       # device half of the split JPEG decode (IDCT, chroma upsampling, colour conversion)
     ("engine.cpp", ["-x", "hip"]),
 ]
-COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# -packed-fp32-ops: no v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 in compiled kernels.  The SiLU epilogues run beside other waves' MFMAs (two
+# or three waves per SIMD in the fused kernels and the direct 1x1 kernel); there a packed fp32 instruction takes 20.7 cycles against 8.3 for a
+# plain one (tools/ubench/valu_issue.hip, profiles/NOTES_r04.md): measured in the engine, same box, interleaved: C = 96 Bottlenecks - 2.5 %, direct
+# 1x1 layers - 3 %, whole step + 0.5-1.5 % tiles/s.  (The host pass of each compile warns that it does not know the feature; it is a device feature.)
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+          "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def hipcc() -> str:
@@ -70,25 +75,27 @@ def llvm_bin(cc: str) -> str:
 
 
 def _assemble_planar(verbose: bool, cc: str) -> None:
-    """The hand-scheduled assembly build of the planar 3x3 kernel: generate the .s (gen_conv3x3_pl_asm.py), assemble and link it into a
-    gfx950 code object with the ROCm clang / lld, and write it as a byte list that conv3x3_pl.hip embeds (hipModuleLoadData)."""
+    """The hand-scheduled assembly kernels: generate each .s (gen_conv3x3_pl_asm.py: the planar 3x3 families; gen_bottleneck_asm.py: the fused
+    C = 48 Bottleneck), assemble and link it into a gfx950 code object with the ROCm clang / lld, and write it as a byte list that the
+    .hip file of the same family embeds (hipModuleLoadData)."""
     llvm = llvm_bin(cc)
-    src, obj, co = (os.path.join(CSRC, n) for n in ("conv3x3_pl_asm.s", "conv3x3_pl_asm.o", "conv3x3_pl_asm.hsaco"))
-    cmds = [[sys.executable, os.path.join(CSRC, "gen_conv3x3_pl_asm.py"), src],
-            [os.path.join(llvm, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-c", src, "-o", obj],
-            [os.path.join(llvm, "ld.lld"), "-shared", obj, "-o", co]]
-    for cmd in cmds:
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"{cmd[0]} failed:\n{r.stdout}\n{r.stderr}")
-    data = open(co, "rb").read()
-    inc = os.path.join(CSRC, "conv3x3_pl_asm_hsaco.inc")
-    with open(inc + ".tmp", "w") as f:
-        for i in range(0, len(data), 32):
-            f.write(",".join(str(b) for b in data[i:i + 32]) + ",\n")
-    os.replace(inc + ".tmp", inc)
+    for gen, stem in (("gen_conv3x3_pl_asm.py", "conv3x3_pl_asm"), ("gen_bottleneck_asm.py", "bottleneck_asm")):
+        src, obj, co = (os.path.join(CSRC, stem + ext) for ext in (".s", ".o", ".hsaco"))
+        cmds = [[sys.executable, os.path.join(CSRC, gen), src],
+                [os.path.join(llvm, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-c", src, "-o", obj],
+                [os.path.join(llvm, "ld.lld"), "-shared", obj, "-o", co]]
+        for cmd in cmds:
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"{cmd[0]} failed:\n{r.stdout}\n{r.stderr}")
+        data = open(co, "rb").read()
+        inc = os.path.join(CSRC, stem + "_hsaco.inc")
+        with open(inc + ".tmp", "w") as f:
+            for i in range(0, len(data), 32):
+                f.write(",".join(str(b) for b in data[i:i + 32]) + ",\n")
+        os.replace(inc + ".tmp", inc)
 
 
 def build_jpeg_lib() -> str:

@@ -560,6 +560,108 @@ int launch_btl(BtlParams p, hipStream_t stream) {
     return AQ_OK;
 }
 
+// ---- C = 48: the hand-scheduled assembly build (gen_bottleneck_asm.py; round 4) -- 8 waves, every wave owns all three M blocks of its
+// two output rows, the two waves of a SIMD run half a tile out of step.  Code object embedded at build time. ----
+struct BtlAsmArgs {                // must match ARG in gen_bottleneck_asm.py
+    const char* in; char* out; const char* w; const float* bias;
+    int in_ld_b, out_ld_b, B, H, W, tiles_x, tpi, ntiles, shortcut, G;
+    unsigned magic_tpi, magic_tx, in_bytes, pad;
+    unsigned long long* debug;
+};
+static_assert(sizeof(BtlAsmArgs) == 96, "kernel argument block");
+const unsigned char kBtlAsmCode[] = {
+#include "bottleneck_asm_hsaco.inc"
+};
+hipModule_t g_btl_asm_mod[64];
+hipFunction_t g_btl_asm_fn[64][2];           // plain, stamped
+constexpr size_t kBtlAsmWBytes = (size_t)(6 + 42) * 1024;     // six A fragments of the 1x1, 42 of the 3x3
+
+int btl_asm_load(int dev) {
+    if (g_btl_asm_mod[dev]) return AQ_OK;
+    hipModule_t mod = nullptr;
+    AQ_CHECK_HIP(hipModuleLoadData(&mod, kBtlAsmCode));
+    AQ_CHECK_HIP(hipModuleGetFunction(&g_btl_asm_fn[dev][0], mod, "bottleneck_asm_c48"));
+    AQ_CHECK_HIP(hipModuleGetFunction(&g_btl_asm_fn[dev][1], mod, "bottleneck_asm_c48_stamped"));
+    g_btl_asm_mod[dev] = mod;
+    return AQ_OK;
+}
+
+// AQ_BTL_ASM=0: the HIP-source kernel everywhere (A/B and fallback).
+bool btl_asm_enabled() {
+    static const bool on = [] { const char* e = getenv("AQ_BTL_ASM"); return !(e && *e == '0'); }();
+    return on;
+}
+
+// Does the assembly kernel take this launch?  (16 x 16 tiles; 32-bit buffer offsets; magic-number tile decode needs >= 2 tiles per row and image.)
+bool btl_asm_fits(int C, int B, int H, int W, int in_ld, int out_ld) {
+    if (C != 48 || !btl_asm_enabled() || btl_wide()) return false;
+    const long long tx = (W + 15) / 16, ty = (H + 15) / 16, tpi = tx * ty, nt = tpi * B;
+    if (tx < 2 || tpi < 2 || nt >= (1LL << 24) || nt * tpi >= (1LL << 32)) return false;
+    if ((long long)B * H * W * in_ld * 2 >= (1LL << 30) || (long long)B * H * W * out_ld * 2 >= (1LL << 31)) return false;
+    return true;
+}
+
+int launch_btl_asm(const BtlParams& p, hipStream_t stream) {
+    int dev = 0;
+    AQ_CHECK_HIP(hipGetDevice(&dev));
+    AQ_REQUIRE(dev >= 0 && dev < 64, "bottleneck: device ordinal %d", dev);
+    { const int rc = btl_asm_load(dev); if (rc) return rc; }
+    BtlAsmArgs a{};
+    a.in = p.in; a.out = p.out; a.bias = p.bias;
+    a.w = p.w;                                                 // (the caller passes the assembly image: it follows the HIP kernel's in the packed buffer)
+    a.in_ld_b = p.in_ld_b; a.out_ld_b = p.out_ld_b; a.B = p.B; a.H = p.H; a.W = p.W;
+    a.tiles_x = (p.W + 15) / 16;
+    a.tpi = a.tiles_x * ((p.H + 15) / 16);
+    a.ntiles = a.tpi * p.B;
+    a.shortcut = p.shortcut;
+    long long grid = g_btl_cus;
+    if (grid > a.ntiles) grid = a.ntiles;
+    a.G = (int)grid;
+    a.magic_tpi = (unsigned)((1ULL << 32) / (unsigned)a.tpi + 1);
+    a.magic_tx = (unsigned)((1ULL << 32) / (unsigned)a.tiles_x + 1);
+    // bytes of the input slice from its first channel to the end of its last pixel: lanes beyond it (and "negative" offsets) read zeros
+    a.in_bytes = (unsigned)(((long long)p.B * p.H * p.W - 1) * p.in_ld_b + 96);
+    int which = 0;
+    size_t sbytes = 0;
+    unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
+    if (sbuf && (size_t)grid * 8 * 64 <= sbytes) { a.debug = sbuf; which = 1; }
+    hipFunction_t fn = g_btl_asm_fn[dev][which];
+    const char* exp_kernel = getenv("AQ_BTL_ASM_KERNEL");      // timing experiments: another kernel of the code object, by name (tools/time_bottleneck.py)
+    if (exp_kernel && *exp_kernel) {
+        char name[96];
+        snprintf(name, sizeof name, "%s%s", exp_kernel, which ? "_stamped" : "");
+        AQ_CHECK_HIP(hipModuleGetFunction(&fn, g_btl_asm_mod[dev], name));
+    }
+    size_t asz = sizeof(a);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+    AQ_CHECK_HIP(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 512, 1, 1, 0, stream, nullptr, extra));
+    return AQ_OK;
+}
+
+// A-fragment image of the assembly kernel (C = 48): six fragments of the 1x1 [k-step 2][M block 3], then 42 of the 3x3
+// [k-step 14][M block 3], 64 lanes x 8 bf16 each.  Lane (r = lane & 15, g = lane >> 4) of M block m holds output channel 16 m + r.
+// 1x1, k-step s: input channels 8 (4 s + g) .. + 7 (zero past 48).  3x3: k-steps 0-8 = channels 8 g .. + 7 of tap s; k-steps 9-13 =
+// channels 32 + 8 (g & 1) .. + 7 of tap pa[g >> 1] for the pairs (0,1), (3,4), (6,7), (2,5), (8,-)  (gen_bottleneck_asm.py KSTEPS).
+void btl_asm_pack(const float* w1, const float* w2, bf16_t* dst) {
+    const int C = 48;
+    static const int pairs[5][2] = {{0, 1}, {3, 4}, {6, 7}, {2, 5}, {8, -1}};
+    for (int s = 0; s < 2; ++s)
+        for (int m = 0; m < 3; ++m)
+            for (int lane = 0; lane < 64; ++lane, dst += 8) {
+                const int co = 16 * m + (lane & 15), blk = 4 * s + (lane >> 4);
+                for (int e = 0; e < 8; ++e) dst[e] = blk < 6 ? aq_f2bf(w1[(size_t)co * C + blk * 8 + e]) : aq_f2bf(0.0f);
+            }
+    for (int s = 0; s < 14; ++s)
+        for (int m = 0; m < 3; ++m)
+            for (int lane = 0; lane < 64; ++lane, dst += 8) {
+                const int co = 16 * m + (lane & 15), g = lane >> 4;
+                int tap, c0;
+                if (s < 9) { tap = s; c0 = 8 * g; }
+                else { tap = pairs[s - 9][g >> 1]; c0 = 32 + 8 * (g & 1); }
+                for (int e = 0; e < 8; ++e) dst[e] = tap >= 0 ? aq_f2bf(w2[((size_t)co * 9 + tap) * C + c0 + e]) : aq_f2bf(0.0f);
+            }
+}
+
 }  // namespace
 
 // Packs the fused fp32 weights of one Bottleneck -- w1 KRSC (C,1,1,C), w2 KRSC (C,3,3,C) -- into the A-fragment image the
@@ -571,7 +673,8 @@ extern "C" int aq_pack_bottleneck_weights(const float* w1_host, const float* w2_
     AQ_REQUIRE(w1_host && w2_host && bytes && btl_shape(C, &sh), "pack_bottleneck: C must be 16, 32, 48, 64 or 96 (got %d)", C);
     const int cb = C / 8, ks1 = (cb + 3) / 4, ks2 = (9 * cb + 3) / 4;
     const size_t frags = (size_t)sh.msplit * (ks1 + ks2) * sh.mbw;
-    *bytes = frags * 64 * 16;
+    const size_t hip_bytes = frags * 64 * 16;
+    *bytes = hip_bytes + (C == 48 ? kBtlAsmWBytes : 0);      // C = 48: the assembly kernel's image follows the HIP kernel's
     if (!packed_dev) return AQ_OK;
     bf16_t* host = (bf16_t*)calloc(1, *bytes);
     AQ_REQUIRE(host, "pack_bottleneck: out of host memory");
@@ -593,6 +696,7 @@ extern "C" int aq_pack_bottleneck_weights(const float* w1_host, const float* w2_
                         }
                     }
                 }
+    if (C == 48) btl_asm_pack(w1_host, w2_host, (bf16_t*)((char*)host + hip_bytes));
     hipError_t e = hipMemcpyAsync(packed_dev, host, *bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     free(host);
@@ -629,6 +733,12 @@ extern "C" int aq_bottleneck(const void* in_dev, int in_ld, int in_choff, void* 
         g_btl_cus = cus;
     }
     const hipStream_t st = (hipStream_t)stream;
+    if (btl_asm_fits(C, B, H, W, in_ld, out_ld)) {
+        BtlShape sh48;
+        btl_shape(48, &sh48);
+        p.w += (size_t)sh48.msplit * ((48 / 8 + 3) / 4 + (9 * 48 / 8 + 3) / 4) * sh48.mbw * 64 * 16;      // skip the HIP kernel's image
+        return launch_btl_asm(p, st);
+    }
     switch (C) {
         case 16: return launch_btl<1, 1, 4, 32, 0, false, false>(p, st);
         case 32: return launch_btl<2, 1, 4, 16, 0, false, false>(p, st);

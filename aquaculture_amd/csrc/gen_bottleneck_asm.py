@@ -55,8 +55,8 @@ KS2 = 14
 KSTEPS = [("A", t) for t in range(9)] + [("P1", 0, 1), ("P1", 3, 4), ("P1", 6, 7), ("P2", 2, 5), ("P1", 8, -1)]
 assert len(KSTEPS) == KS2
 
-ARG = dict(inp=0, out=8, w=16, bias=24, debug=32, in_ld=40, out_ld=44, B=48, H=52, W=56, tiles_x=60, tpi=64, ntiles=68, shortcut=72, G=76,
-           magic_tpi=80, magic_tx=84, in_bytes=88, pad=92)
+ARG = dict(inp=0, out=8, w=16, bias=24, in_ld=32, out_ld=36, B=40, H=44, W=48, tiles_x=52, tpi=56, ntiles=60, shortcut=64, G=68,
+           magic_tpi=72, magic_tx=76, in_bytes=80, pad=84, debug=88)
 ARG_BYTES = 96
 
 
@@ -79,10 +79,11 @@ S = Regs("s", 100)
 S.alloc("karg", 2)
 S.alloc("wg")
 S.alloc("pad0")
-for nm in ("inp", "out", "w", "bias", "debug"):
+for nm in ("inp", "out", "w", "bias"):
     S.alloc(nm, 2, 2)
 for nm in ("in_ld", "out_ld", "B", "H", "W", "tiles_x", "tpi", "ntiles", "shortcut", "G", "magic_tpi", "magic_tx", "in_bytes", "pad"):
     S.alloc(nm)
+S.alloc("debug", 2, 2)
 S.alloc("srd", 4, 4)
 for nm in ("wave", "group", "tmp0", "tmp1", "tmp2", "tmp3", "tmp4", "tmp5",
            "d_tile", "d_ok", "d_b", "d_y0", "d_x0",            # stage D: the tile whose x patch is being fetched
@@ -155,10 +156,33 @@ def acc(j, m):
 out = []
 _uid = [0]
 STAMPED = [False]
-PH_PROLOGUE, PH_DMA, PH_B, PH_C_MFMA, PH_C_EPI, PH_BARRIER = range(6)
+OPT = dict(stagger=True, nosilu=False, nomfma=False, nopk=False, nodma=False, nold=False, nost=False, prio=0)      # experiment switches of a kernel variant (main() sets them per kernel)
+PH_PROLOGUE, PH_DMA, PH_B, PH_C_MFMA, PH_C_EPI, PH_BARRIER = range(6)      # (PH_DMA: the vmcnt wait in front of the epilogue)
 
 
 def E(line="", comment=None):
+    if OPT["nomfma"] and line.startswith("v_mfma"):
+        return
+    if (OPT["nodma"] and line.startswith("buffer_load_dwordx4")) or (OPT["nold"] and line.startswith("global_load_dwordx2")) or (OPT["nost"] and line.startswith("global_store_dwordx2")):
+        return
+    if OPT["nosilu"] and line.split(" ")[0] in ("v_exp_f32", "v_rcp_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_mul_f32", "v_add_f32"):
+        return
+    if OPT["nopk"] and line.split(" ")[0] in ("v_pk_mul_f32", "v_pk_add_f32"):
+        # experiment: the packed fp32 forms as two plain VOP2 / VOP3 instructions (tools/ubench/valu_issue.hip: beside another wave's MFMAs a
+        # v_pk_mul_f32 takes 20.7 cycles, a v_mul_f32 8.3)
+        op = "v_mul_f32" if "mul" in line else "v_add_f32"
+        import re
+        m_ = re.match(r"v_pk_\w+ v\[(\d+):\d+\], v\[(\d+):\d+\], (.*)$", line)
+        d, a, rest = int(m_.group(1)), int(m_.group(2)), m_.group(3)
+        for h in range(2):
+            r2 = re.match(r"v\[(\d+):\d+\]$", rest)
+            if r2:
+                b_ = f"v{int(r2.group(1)) + h}"
+            else:
+                r3 = re.match(r"s\[(\d+):\d+\]$", rest)
+                b_ = f"s{int(r3.group(1)) + h}"
+            out.append(f"\t{op}_e64 v{d + h}, v{a + h}, {b_}")
+        return
     out.append(("\t" + line if line and not line.endswith(":") else line) + (f"\t; {comment}" if comment else ""))
 
 
@@ -204,7 +228,7 @@ def emit_decode(stage):
     label(skip)
 
 
-def emit_dma():
+def emit_dma(temps_base=None):
     """Stage D's x patch -> LDS buffer dma_lds: this wave's four 1 KB instructions (slots 256 wave .. + 255 of the patch image)."""
     skip = uid("dma")
     E(f"s_cmp_eq_u32 {s('d_ok')}, 0")
@@ -219,7 +243,7 @@ def emit_dma():
     E(f"s_mul_i32 {s('org')}, {s('tmp0')}, {s('in_ld')}")
     E(f"s_lshl_b32 {s('tmp1')}, {s('wave')}, 12")
     E(f"s_add_u32 {s('tmp1')}, {s('tmp1')}, {s('dma_lds')}")
-    T = V.names["F"][0] + 8
+    T = V.names["F"][0] + 8 if temps_base is None else temps_base
     for i in range(4):
         E(f"v_add_u32 v{T + i}, {s('org')}, {v('pre' + str(i))}")
     for i in range(4):
@@ -229,45 +253,38 @@ def emit_dma():
     label(skip)
 
 
-def emit_silu4(a0, y0):
-    """In place on v[a0 : a0 + 4): a = a / (1 + 2^(-a log2 e)); temporaries v[y0 : y0 + 4).  (Same sequence as the planar kernels' epilogue.)"""
-    E(f"v_pk_mul_f32 v[{y0}:{y0 + 1}], v[{a0}:{a0 + 1}], {s2('klog2e2')}")
-    E(f"v_pk_mul_f32 v[{y0 + 2}:{y0 + 3}], v[{a0 + 2}:{a0 + 3}], {s2('klog2e2')}")
-    for e in range(4):
-        E(f"v_exp_f32 v{y0 + e}, v{y0 + e}")
-    E(f"v_pk_add_f32 v[{y0}:{y0 + 1}], v[{y0}:{y0 + 1}], {s2('kone2')}")
-    E(f"v_pk_add_f32 v[{y0 + 2}:{y0 + 3}], v[{y0 + 2}:{y0 + 3}], {s2('kone2')}")
-    for e in range(4):
-        E(f"v_rcp_f32 v{y0 + e}, v{y0 + e}")
+def emit_silu(regs, temps):
+    """SiLU in place on the accumulator registers `regs` (a multiple of 4 numbers, each group of 4 consecutive), one temporary per
+    register: a = a / (1 + 2^(-a log2 e)), evaluated STAGE BY STAGE over all of them -- every instruction's operands were produced at least
+    len(regs) / 2 instructions earlier, so neither the transcendental unit's latency nor a dependent VALU issue stalls the wave (round 4,
+    first build: four registers at a time, 49 % of the wave cycles in SQ_WAIT_INST_ANY).  Leaves the reciprocals in `temps`; the caller
+    multiplies (it may have independent work to put in front)."""
+    n = len(regs)
+    assert n % 4 == 0 and len(temps) >= n
+    for i in range(0, n, 2):
+        assert regs[i + 1] == regs[i] + 1 and temps[i + 1] == temps[i] + 1 and regs[i] % 2 == 0 and temps[i] % 2 == 0
+        E(f"v_pk_mul_f32 v[{temps[i]}:{temps[i] + 1}], v[{regs[i]}:{regs[i] + 1}], {s2('klog2e2')}")
+    for i in range(n):
+        E(f"v_exp_f32 v{temps[i]}, v{temps[i]}")
+    for i in range(0, n, 2):
+        E(f"v_pk_add_f32 v[{temps[i]}:{temps[i] + 1}], v[{temps[i]}:{temps[i] + 1}], {s2('kone2')}")
+    for i in range(n):
+        E(f"v_rcp_f32 v{temps[i]}, v{temps[i]}")
 
 
-def emit_phase_b():
-    """t = SiLU(W1 x + b1) for this wave's blocks (wave, wave + 8, wave + 16 < 21) of stage B's patch, zero outside the image."""
-    skip = uid("pb")
-    E(f"s_cmp_eq_u32 {s('b_ok')}, 0")
-    E(f"s_cbranch_scc1 {skip}")
+def emit_phase_b(interior):
+    """t = SiLU(W1 x + b1) for this wave's blocks (wave, wave + 8, wave + 16 < 21) of stage B's patch, zero outside the image.
+    Two copies behind one branch: `interior` tiles (the whole 18 x 18 patch inside the image) need no zeroing at all."""
     P0 = V.names["P"][0]
     F0 = V.names["F"][0]
     A0 = V.names["ACC"][0]
-    # interior tile: the whole 18 x 18 patch lies inside the image (no zeroing)
-    E(f"s_sub_u32 {s('y0m1')}, {s('b_y0')}, 1")
-    E(f"s_sub_u32 {s('x0m1')}, {s('b_x0')}, 1")
-    E(f"s_add_u32 {s('tmp0')}, {s('b_y0')}, 17")
-    E(f"s_add_u32 {s('tmp1')}, {s('b_x0')}, 17")
-    E(f"s_cmp_le_u32 {s('tmp0')}, {s('H')}")
-    E(f"s_cselect_b32 {s('interior')}, 1, 0")
-    E(f"s_cmp_le_u32 {s('tmp1')}, {s('W')}")
-    E(f"s_cselect_b32 {s('tmp2')}, 1, 0")
-    E(f"s_and_b32 {s('interior')}, {s('interior')}, {s('tmp2')}")
-    E(f"s_cmp_gt_u32 {s('b_y0')}, 0")
-    E(f"s_cselect_b32 {s('tmp2')}, 1, 0")
-    E(f"s_and_b32 {s('interior')}, {s('interior')}, {s('tmp2')}")
-    E(f"s_cmp_gt_u32 {s('b_x0')}, 0")
-    E(f"s_cselect_b32 {s('tmp2')}, 1, 0")
-    E(f"s_and_b32 {s('interior')}, {s('interior')}, {s('tmp2')}")
+    if not interior:
+        E(f"s_sub_u32 {s('y0m1')}, {s('b_y0')}, 1")
+        E(f"s_sub_u32 {s('x0m1')}, {s('b_x0')}, 1")
     # the six W1 fragments: LDS -> P[0 : 24)
     for i in range(6):
         E(f"ds_read_b128 v[{P0 + 4 * i}:{P0 + 4 * i + 3}], {v('w1a')} offset:{1024 * i}")
+    temps = [F0 + 8 + i for i in range(8)] + [P0 + 24 + i for i in range(4)]
 
     def reads(i, aset):
         for ks in range(2):
@@ -283,77 +300,104 @@ def emit_phase_b():
 
     def silu_store(i, aset):
         """accumulator set aset = block i: SiLU, bf16, zero outside the image, into the t patch."""
-        Y = [F0 + 8, F0 + 12]
-        nozero = uid("nz")
-        # (px, pr, pc) of this lane's pixel and the "inside the image" mask -- border tiles only
-        E(f"s_cmp_eq_u32 {s('interior')}, 1")
-        E(f"s_cbranch_scc1 {nozero}")
-        t0, t1, t2 = P0 + 24, P0 + 25, P0 + 26
-        E(f"s_lshl_b32 {s('tmp0')}, {s('wave')}, 4")
-        E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {128 * i}")
-        E(f"v_add_u32 v{t0}, {s('tmp0')}, {v('l15')}", "patch pixel")
-        E(f"v_mul_u32_u24 v{t1}, 3641, v{t0}")
-        E(f"v_lshrrev_b32 v{t1}, 16, v{t1}", "patch row = pixel / 18")
-        E(f"v_mul_u32_u24 v{t2}, 18, v{t1}")
-        E(f"v_sub_u32 v{t2}, v{t0}, v{t2}", "patch column")
-        E(f"v_add_u32 v{t1}, {s('y0m1')}, v{t1}", "image row (wraps below zero)")
-        E(f"v_add_u32 v{t2}, {s('x0m1')}, v{t2}")
-        E(f"v_cmp_gt_u32 {s2('sa')}, {s('H')}, v{t1}")
-        E(f"v_cmp_gt_u32 vcc, {s('W')}, v{t2}")
-        E(f"s_and_b64 vcc, vcc, {s2('sa')}")
-        label(nozero)
+        regs = [A0 + 12 * aset + k for k in range(12)]
+        if not interior:
+            # (patch pixel, row, column) of this lane's pixel and the "inside the image" mask, before the temporaries are taken
+            t0, t1, t2 = temps[8], temps[9], temps[10]
+            E(f"s_lshl_b32 {s('tmp0')}, {s('wave')}, 4")
+            E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {128 * i}")
+            E(f"v_add_u32 v{t0}, {s('tmp0')}, {v('l15')}", "patch pixel")
+            E(f"v_mul_u32_u24 v{t1}, 3641, v{t0}")
+            E(f"v_lshrrev_b32 v{t1}, 16, v{t1}", "patch row = pixel / 18")
+            E(f"v_mul_u32_u24 v{t2}, 18, v{t1}")
+            E(f"v_sub_u32 v{t2}, v{t0}, v{t2}", "patch column")
+            E(f"v_add_u32 v{t1}, {s('y0m1')}, v{t1}", "image row (wraps below zero)")
+            E(f"v_add_u32 v{t2}, {s('x0m1')}, v{t2}")
+            E(f"v_cmp_gt_u32 {s2('sa')}, {s('H')}, v{t1}")
+            E(f"v_cmp_gt_u32 vcc, {s('W')}, v{t2}")
+            E(f"s_and_b64 vcc, vcc, {s2('sa')}")
+        emit_silu(regs, temps)
+        for k in range(0, 12, 2):
+            E(f"v_pk_mul_f32 v[{regs[k]}:{regs[k] + 1}], v[{regs[k]}:{regs[k] + 1}], v[{temps[k]}:{temps[k] + 1}]")
+        for k in range(6):
+            E(f"v_cvt_pk_bf16_f32 v{temps[k]}, v{regs[2 * k]}, v{regs[2 * k] + 1}")
+        if not interior:
+            for k in range(6):
+                E(f"v_cndmask_b32 v{temps[k]}, 0, v{temps[k]}, vcc")
         for m in range(3):
-            a = A0 + 12 * aset + 4 * m
-            y = Y[m % 2]
-            emit_silu4(a, y)
-            # (independent instructions between the rcp and its consumer: the next block's address arithmetic is elsewhere; pad)
-            E("s_nop 0", "hz: transcendental -> consumer")
-            E(f"v_pk_mul_f32 v[{a}:{a + 1}], v[{a}:{a + 1}], v[{y}:{y + 1}]")
-            E(f"v_pk_mul_f32 v[{a + 2}:{a + 3}], v[{a + 2}:{a + 3}], v[{y + 2}:{y + 3}]")
-            E(f"v_cvt_pk_bf16_f32 v{y}, v{a}, v{a + 1}")
-            E(f"v_cvt_pk_bf16_f32 v{y + 1}, v{a + 2}, v{a + 3}")
-            z = uid("z")
-            E(f"s_cmp_eq_u32 {s('interior')}, 1")
-            E(f"s_cbranch_scc1 {z}")
-            E(f"v_cndmask_b32 v{y}, 0, v{y}, vcc")
-            E(f"v_cndmask_b32 v{y + 1}, 0, v{y + 1}, vcc")
-            label(z)
-            E(f"ds_write_b64 {v('tw')}, v[{y}:{y + 1}] offset:{12288 * i + 32 * m}")
+            E(f"ds_write_b64 {v('tw')}, v[{temps[2 * m]}:{temps[2 * m] + 1}] offset:{12288 * i + 32 * m}")
 
-    # blocks 0 and 1 always exist for every wave (21 blocks, 8 waves); block 2 for waves 0-4
+    # blocks 0 and 1 exist for every wave (21 blocks, 8 waves); block 2 for waves 0-4.  The next block's fragment reads are in flight
+    # under the current block's SiLU (the block's own MFMAs have been issued, so its two fragment registers are free again).
     reads(0, 0)
     E("s_waitcnt lgkmcnt(0)")
     mfmas(0)
     reads(1, 1)
-    E("s_waitcnt lgkmcnt(0)")
-    mfmas(1)
-    E("s_nop 7", "hz: MFMA result -> VALU read (set 0: six MFMAs of set 1 and this pad behind it)")
+    E("s_nop 7", "hz: MFMA result -> VALU read")
     silu_store(0, 0)
+    E("s_waitcnt lgkmcnt(3)", "block 1's fragments and b1 (the three t writes behind them may still be on their way)")
+    mfmas(1)
     no2 = uid("nob2")
+    end = uid("pbe")
     E(f"s_cmp_eq_u32 {s('blk2')}, 0")
     E(f"s_cbranch_scc1 {no2}")
     reads(2, 0)
-    E("s_waitcnt lgkmcnt(0)")
-    mfmas(0)
-    label(no2)
-    E("s_nop 7", "hz: MFMA result -> VALU read (set 1)")
+    E("s_nop 7", "hz: MFMA result -> VALU read")
     silu_store(1, 1)
-    end = uid("pbe")
-    E(f"s_cmp_eq_u32 {s('blk2')}, 0")
-    E(f"s_cbranch_scc1 {end}")
-    E("s_nop 15", "hz: MFMA result -> VALU read (set 0, block 2)")
+    E("s_waitcnt lgkmcnt(3)")
+    mfmas(0)
+    E("s_nop 15", "hz: MFMA result -> VALU read")
     silu_store(2, 0)
+    E(f"s_branch {end}")
+    label(no2)
+    E("s_nop 15", "hz: MFMA result -> VALU read")
+    silu_store(1, 1)
     label(end)
+
+
+def emit_phase_b_dispatch():
+    skip = uid("pb")
+    border = uid("pbb")
+    E(f"s_cmp_eq_u32 {s('b_ok')}, 0")
+    E(f"s_cbranch_scc1 {skip}")
+    # interior tile: the whole 18 x 18 patch lies inside the image
+    E(f"s_add_u32 {s('tmp0')}, {s('b_y0')}, 17")
+    E(f"s_add_u32 {s('tmp1')}, {s('b_x0')}, 17")
+    E(f"s_cmp_le_u32 {s('tmp0')}, {s('H')}")
+    E(f"s_cselect_b32 {s('interior')}, 1, 0")
+    E(f"s_cmp_le_u32 {s('tmp1')}, {s('W')}")
+    E(f"s_cselect_b32 {s('tmp2')}, 1, 0")
+    E(f"s_and_b32 {s('interior')}, {s('interior')}, {s('tmp2')}")
+    E(f"s_min_u32 {s('tmp2')}, {s('b_y0')}, {s('b_x0')}")
+    E(f"s_min_u32 {s('tmp2')}, {s('tmp2')}, 1", "1 when both origins are > 0")
+    E(f"s_and_b32 {s('interior')}, {s('interior')}, {s('tmp2')}")
+    E(f"s_cmp_eq_u32 {s('interior')}, 0")
+    E(f"s_cbranch_scc1 {border}")
+    emit_phase_b(True)
+    E(f"s_branch {skip}")
+    label(border)
+    emit_phase_b(False)
     label(skip)
 
 
-def emit_phase_c(shortcut_flag_s):
-    """y = (x +) SiLU(W2 (*) t + b2) for the wave's two output rows of stage C's tile."""
+def emit_phase_c(dma_inside):
+    """y = (x +) SiLU(W2 (*) t + b2) for the wave's two output rows of stage C's tile.  dma_inside (waves 0-3, whose interval starts with
+    this phase): the next x patch's LDS-DMA is issued BEHIND the shortcut loads, so that the wait in front of the epilogue covers the
+    shortcut values only (vmcnt is in order) and the patch has the whole interval to arrive."""
     skip = uid("pc")
-    E(f"s_cmp_eq_u32 {s('c_ok')}, 0")
-    E(f"s_cbranch_scc1 {skip}")
+    if dma_inside:
+        have = uid("pch")
+        E(f"s_cmp_eq_u32 {s('c_ok')}, 1")
+        E(f"s_cbranch_scc1 {have}")
+        emit_dma()
+        E(f"s_branch {skip}")
+        label(have)
+    else:
+        E(f"s_cmp_eq_u32 {s('c_ok')}, 0")
+        E(f"s_cbranch_scc1 {skip}")
     P0 = V.names["P"][0]
     F0 = V.names["F"][0]
+    A0 = V.names["ACC"][0]
     # ---- scalar: row addresses and store masks ----
     E(f"s_lshl_b32 {s('tmp0')}, {s('wave')}, 1")
     E(f"s_add_u32 {s('tmp0')}, {s('tmp0')}, {s('c_y0')}", "image row of the wave's first output row")
@@ -382,7 +426,7 @@ def emit_phase_c(shortcut_flag_s):
     E(f"s_cselect_b64 {s2('mask1')}, {s2('colmask')}, 0")
     # ---- shortcut values (L2-hot: the x patch of this tile was fetched two intervals ago), accumulators from b2, first fragments ----
     nosc = uid("nosc")
-    E(f"s_cmp_eq_u32 {shortcut_flag_s}, 0")
+    E(f"s_cmp_eq_u32 {s('shortcut')}, 0")
     E(f"s_cbranch_scc1 {nosc}")
     for j in range(2):
         E(f"s_mov_b64 exec, {s2('mask' + str(j))}")
@@ -390,87 +434,110 @@ def emit_phase_c(shortcut_flag_s):
             E(f"global_load_dwordx2 v[{P0 + 2 * (3 * j + m)}:{P0 + 2 * (3 * j + m) + 1}], {v('vin')}, {s2('irow' + str(j))} offset:{32 * m}")
     E("s_mov_b64 exec, -1")
     label(nosc)
+    if dma_inside:
+        emit_dma(temps_base=P0 + 12)
     for j in range(2):
         for m in range(3):
             E(f"ds_read_b128 {acc(j, m)}, {v('bb')} offset:{192 + 64 * m}", "accumulators start from b2")
 
+    # B fragments: ring of eight (F and the sixteen temporaries of the epilogue, idle during the stream): read three k-steps ahead
+    ring = [F0 + 4 * i for i in range(4)] + [P0 + 12 + 4 * i for i in range(4)]
+    PD = 3
+
     def frag_reads(k):
         kind = KSTEPS[k]
         for j in range(2):
-            dst = F0 + 4 * ((2 * k + j) % 4)
-            if kind[0] == "A":
-                E(f"ds_read_b128 v[{dst}:{dst + 3}], {v('cA')} offset:{tap_off(kind[1]) + j * PW * PXB}")
-            else:
-                E(f"ds_read_b128 v[{dst}:{dst + 3}], {v('c' + kind[0])} offset:{tap_off(kind[1]) + j * PW * PXB}")
+            dst = ring[(2 * k + j) % 8]
+            areg = "cA" if kind[0] == "A" else "c" + kind[0]
+            E(f"ds_read_b128 v[{dst}:{dst + 3}], {v(areg)} offset:{tap_off(kind[1]) + j * PW * PXB}")
 
-    frag_reads(0)
-    stamp(PH_DMA)
+    for k in range(PD):
+        frag_reads(k)
+    if OPT["prio"]:
+        # the wave in its MFMA stream outranks its partner's SiLU stream (issue is arbitrated by priority, then age: without this the OLDER
+        # wave's dense VALU stream starves the younger wave's MFMAs -- stamped build: waves 4-7 spent 5.6 k cycles per tile in a stream that
+        # takes 1.5 k alone -- whereas a VALU stream loses little beside MFMAs: one transcendental or two plain instructions fit every gap)
+        E(f"s_setprio {OPT['prio']}")
     for k in range(KS2):
-        if k + 1 < KS2:
-            frag_reads(k + 1)
-            E("s_waitcnt lgkmcnt(2)")
-        else:
-            E("s_waitcnt lgkmcnt(0)")
+        if k + PD < KS2:
+            frag_reads(k + PD)
+        ahead = 2 * (min(KS2, k + PD + 1) - (k + 1))         # fragment reads issued after this k-step's
+        E(f"s_waitcnt lgkmcnt({ahead})")
         for m in range(3):
             for j in range(2):
-                f = F0 + 4 * ((2 * k + j) % 4)
+                f = ring[(2 * k + j) % 8]
                 E(f"v_mfma_f32_16x16x32_bf16 {acc(j, m)}, {w2(k, m)}, v[{f}:{f + 3}], {acc(j, m)}")
+    if OPT["prio"]:
+        E("s_setprio 0")
     stamp(PH_C_MFMA)
     E("s_nop 15", "hz: MFMA result -> VALU read")
-    E("s_waitcnt vmcnt(0)", "shortcut values (and, vmcnt being in order, this interval's LDS-DMA and the previous tile's stores)")
-    # ---- epilogue: SiLU, shortcut, bf16, store ----
-    Y = [P0 + 12, P0 + 16]
-    R = [P0 + 20, P0 + 24]
-    for j in range(2):
-        for m in range(3):
-            n = 3 * j + m
-            a = V.names["ACC"][0] + 4 * n
-            y, r = Y[n % 2], R[n % 2]
-            sc = P0 + 2 * n
-            emit_silu4(a, y)
-            plain = uid("pl")
-            done = uid("dn")
-            E(f"s_cmp_eq_u32 {shortcut_flag_s}, 0")
-            E(f"s_cbranch_scc1 {plain}")
-            E(f"v_lshlrev_b32 v{r}, 16, v{sc}")
-            E(f"v_and_b32 v{r + 1}, 0xffff0000, v{sc}")
-            E(f"v_lshlrev_b32 v{r + 2}, 16, v{sc + 1}")
-            E(f"v_and_b32 v{r + 3}, 0xffff0000, v{sc + 1}")
-            E(f"v_pk_mul_f32 v[{a}:{a + 1}], v[{a}:{a + 1}], v[{y}:{y + 1}]")
-            E(f"v_pk_mul_f32 v[{a + 2}:{a + 3}], v[{a + 2}:{a + 3}], v[{y + 2}:{y + 3}]")
-            E(f"v_pk_add_f32 v[{a}:{a + 1}], v[{a}:{a + 1}], v[{r}:{r + 1}]")
-            E(f"v_pk_add_f32 v[{a + 2}:{a + 3}], v[{a + 2}:{a + 3}], v[{r + 2}:{r + 3}]")
-            E(f"s_branch {done}")
+    if dma_inside:
+        w0, wd = uid("w0"), uid("wd")
+        E(f"s_cmp_eq_u32 {s('d_ok')}, 0")
+        E(f"s_cbranch_scc1 {w0}")
+        E("s_waitcnt vmcnt(4)", "shortcut values (the four LDS-DMA instructions behind them stay in flight)")
+        E(f"s_branch {wd}")
+        label(w0)
+        E("s_waitcnt vmcnt(0)")
+        label(wd)
+    else:
+        E("s_waitcnt vmcnt(0)", "shortcut values (and, vmcnt being in order, this interval's LDS-DMA and the previous tile's stores)")
+    stamp(PH_DMA)
+    # ---- epilogue, one output row (12 accumulator registers) at a time: SiLU, shortcut, bf16, store.  Two copies behind ONE branch. ----
+    temps = [P0 + 12 + i for i in range(12)]
+    plain, done = uid("pl"), uid("dn")
+    E(f"s_cmp_eq_u32 {s('shortcut')}, 0")
+    E(f"s_cbranch_scc1 {plain}")
+    for with_sc in (True, False):
+        if not with_sc:
             label(plain)
-            E("s_nop 0", "hz: transcendental -> consumer")
-            E(f"v_pk_mul_f32 v[{a}:{a + 1}], v[{a}:{a + 1}], v[{y}:{y + 1}]")
-            E(f"v_pk_mul_f32 v[{a + 2}:{a + 3}], v[{a + 2}:{a + 3}], v[{y + 2}:{y + 3}]")
-            label(done)
-            E(f"v_cvt_pk_bf16_f32 v{y}, v{a}, v{a + 1}")
-            E(f"v_cvt_pk_bf16_f32 v{y + 1}, v{a + 2}, v{a + 3}")
+        for j in range(2):
+            regs = [A0 + 12 * j + k for k in range(12)]
+            emit_silu(regs, temps)
+            for k in range(0, 12, 2):
+                E(f"v_pk_mul_f32 v[{regs[k]}:{regs[k] + 1}], v[{regs[k]}:{regs[k] + 1}], v[{temps[k]}:{temps[k] + 1}]")
+            if with_sc:
+                for m in range(3):
+                    sc = P0 + 2 * (3 * j + m)
+                    E(f"v_lshlrev_b32 v{temps[4 * m]}, 16, v{sc}")
+                    E(f"v_and_b32 v{temps[4 * m + 1]}, 0xffff0000, v{sc}")
+                    E(f"v_lshlrev_b32 v{temps[4 * m + 2]}, 16, v{sc + 1}")
+                    E(f"v_and_b32 v{temps[4 * m + 3]}, 0xffff0000, v{sc + 1}")
+                for k in range(0, 12, 2):
+                    E(f"v_pk_add_f32 v[{regs[k]}:{regs[k] + 1}], v[{regs[k]}:{regs[k] + 1}], v[{temps[k]}:{temps[k] + 1}]")
+            for k in range(6):
+                E(f"v_cvt_pk_bf16_f32 v{temps[k]}, v{regs[2 * k]}, v{regs[2 * k] + 1}")
             E(f"s_mov_b64 exec, {s2('mask' + str(j))}")
-            E(f"global_store_dwordx2 {v('vout')}, v[{y}:{y + 1}], {s2('orow' + str(j))} offset:{32 * m}")
+            for m in range(3):
+                E(f"global_store_dwordx2 {v('vout')}, v[{temps[2 * m]}:{temps[2 * m] + 1}], {s2('orow' + str(j))} offset:{32 * m}")
             E("s_mov_b64 exec, -1")
+        if with_sc:
+            E(f"s_branch {done}")
+    label(done)
     stamp(PH_C_EPI)
     label(skip)
 
 
-def gen_kernel(name, stamped=False):
+_kernel_no = [0]
+
+
+def gen_kernel(name, stamped=False, **opt):
     global out
     out = []
     STAMPED[0] = stamped
-    _uid[0] = 0 if not stamped else 100000
+    OPT.update(dict(stagger=True, nosilu=False, nomfma=False, nopk=False, nodma=False, nold=False, nost=False, prio=0))
+    OPT.update(opt)
+    _kernel_no[0] += 1
+    _uid[0] = 100000 * _kernel_no[0]
     E(f"; fused Bottleneck, C = 48, 8 waves: generated by gen_bottleneck_asm.py -- do not edit")
     label(name)
     a0 = S.names["inp"][0]
-    assert a0 % 4 == 0 and S.names["in_ld"][0] == a0 + 10
-    E(f"s_load_dwordx8 s[{a0}:{a0 + 7}], {s2('karg')}, 0x0", "inp, out, w, bias")
-    E(f"s_load_dwordx2 {s2('debug')}, {s2('karg')}, 0x20")
     b0 = S.names["in_ld"][0]
-    assert b0 % 2 == 0
-    E(f"s_load_dwordx8 s[{b0}:{b0 + 7}], {s2('karg')}, 0x28", "in_ld .. ntiles")
-    E(f"s_load_dwordx4 s[{b0 + 8}:{b0 + 11}], {s2('karg')}, 0x48", "shortcut, G, magic_tpi, magic_tx")
-    E(f"s_load_dwordx2 s[{b0 + 12}:{b0 + 13}], {s2('karg')}, 0x58", "in_bytes, pad")
+    assert a0 % 4 == 0 and b0 == a0 + 8 and S.names["debug"][0] == b0 + 14
+    E(f"s_load_dwordx8 s[{a0}:{a0 + 7}], {s2('karg')}, 0x0", "inp, out, w, bias")
+    E(f"s_load_dwordx8 s[{b0}:{b0 + 7}], {s2('karg')}, 0x20", "in_ld .. ntiles")
+    E(f"s_load_dwordx4 s[{b0 + 8}:{b0 + 11}], {s2('karg')}, 0x40", "shortcut, G, magic_tpi, magic_tx")
+    E(f"s_load_dwordx4 s[{b0 + 12}:{b0 + 15}], {s2('karg')}, 0x50", "in_bytes, pad, debug")
     T = [V.names["P"][0] + i for i in range(28)]
     E(f"v_and_b32 v{T[0]}, 63, {v('tid')}", "lane")
     E(f"v_lshrrev_b32 v{T[1]}, 6, {v('tid')}")
@@ -478,7 +545,10 @@ def gen_kernel(name, stamped=False):
     E(f"v_readfirstlane_b32 {s('wave')}, v{T[1]}")
     E(f"v_and_b32 {v('l15')}, 15, v{T[0]}")
     E(f"v_lshrrev_b32 v{T[2]}, 4, v{T[0]}", "g")
-    E(f"s_lshr_b32 {s('group')}, {s('wave')}, 2")
+    if OPT["stagger"]:
+        E(f"s_lshr_b32 {s('group')}, {s('wave')}, 2")
+    else:
+        E(f"s_mov_b32 {s('group')}, 0", "experiment: every wave runs phase C first (no stagger)")
     E(f"s_cmp_lt_u32 {s('wave')}, 5")
     E(f"s_cselect_b32 {s('blk2')}, 1, 0", "waves 0-4 own a third block of the patch (21 blocks)")
     E("s_waitcnt lgkmcnt(0)")
@@ -612,28 +682,39 @@ def gen_kernel(name, stamped=False):
     # ---- one barrier interval per tile: [DMA of tile k + 1] ; phase C of tile k - 1 and phase B of tile k, in the order of the wave's half ----
     loop = uid("loop")
     label(loop)
-    emit_dma()
     g1 = uid("g1")
     join = uid("join")
     E(f"s_cmp_eq_u32 {s('group')}, 1")
     E(f"s_cbranch_scc1 {g1}")
-    emit_phase_c(s("shortcut"))
+    emit_phase_c(True)
     stamp(PH_C_EPI)
-    emit_phase_b()
+    emit_phase_b_dispatch()
     stamp(PH_B)
+    # the x patch fetched in this interval must have landed before the barrier.  Its four instructions are older than the six output
+    # stores of a full tile, which may stay in flight; ragged tiles (stores with an empty EXEC) and intervals without a phase C: everything
+    full, w0 = uid("full"), uid("w0")
+    E(f"s_and_b32 {s('tmp0')}, {s('rowok0')}, {s('rowok1')}")
+    E(f"s_and_b32 {s('tmp0')}, {s('tmp0')}, {s('c_ok')}")
+    E(f"s_cmp_eq_u32 {s('tmp0')}, 1")
+    E(f"s_cbranch_scc1 {full}")
+    E("s_waitcnt vmcnt(0)")
+    E(f"s_branch {join}")
+    label(full)
+    E("s_waitcnt vmcnt(6)")
     E(f"s_branch {join}")
     label(g1)
-    emit_phase_b()
+    emit_dma()
+    emit_phase_b_dispatch()
     stamp(PH_B)
-    emit_phase_c(s("shortcut"))
+    emit_phase_c(False)
     stamp(PH_C_EPI)
-    label(join)
-    # the x patch fetched in this interval must have landed before the barrier: phase C's vmcnt(0) came after its issue; without a phase C, wait here
+    # (phase C's vmcnt(0) came after the DMA's issue; without a phase C, wait here)
     nowait = uid("nw")
     E(f"s_cmp_eq_u32 {s('c_ok')}, 1")
     E(f"s_cbranch_scc1 {nowait}")
     E("s_waitcnt vmcnt(0)")
     label(nowait)
+    label(join)
     E("s_waitcnt lgkmcnt(0)")
     E("s_barrier")
     stamp(PH_BARRIER)
@@ -723,9 +804,25 @@ def main():
     path = sys.argv[1] if len(sys.argv) > 1 else "bottleneck_asm.s"
     text = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.text"]
     entries = []
-    for name, stamped in (("bottleneck_asm_c48", False), ("bottleneck_asm_c48_stamped", True)):
+    # (name, stamped, options): the shipped kernel and its stamped diagnostic build; with AQ_GEN_EXPERIMENTAL=1 also the timing experiments of
+    # round 4 (selected at run time by AQ_BTL_ASM_KERNEL=<name>, tools/time_bottleneck.py; results in profiles/NOTES_r04.md): no stagger, the
+    # packed fp32 instructions as plain ones, and ablations that leave out the SiLU arithmetic, the MFMAs, the LDS-DMA, the shortcut loads or
+    # the output stores (wrong results: timing only)
+    import os
+    variants = [("bottleneck_asm_c48", False, {}), ("bottleneck_asm_c48_stamped", True, {})]
+    if os.environ.get("AQ_GEN_EXPERIMENTAL") == "1":
+        variants += [("bottleneck_asm_c48_nostagger", False, dict(stagger=False)), ("bottleneck_asm_c48_nostagger_stamped", True, dict(stagger=False)),
+                     ("bottleneck_asm_c48_prio", False, dict(prio=3)), ("bottleneck_asm_c48_prio_stamped", True, dict(prio=3)),
+                     ("bottleneck_asm_c48_nopk", False, dict(nopk=True)), ("bottleneck_asm_c48_nosilu", False, dict(nosilu=True)),
+                     ("bottleneck_asm_c48_nomfma", False, dict(nomfma=True)), ("bottleneck_asm_c48_skel", False, dict(nomfma=True, nosilu=True)),
+                     ("bottleneck_asm_c48_skel_nodma", False, dict(nomfma=True, nosilu=True, nodma=True)),
+                     ("bottleneck_asm_c48_skel_nold", False, dict(nomfma=True, nosilu=True, nold=True)),
+                     ("bottleneck_asm_c48_skel_nost", False, dict(nomfma=True, nosilu=True, nost=True)),
+                     ("bottleneck_asm_c48_skel_nomem", False, dict(nomfma=True, nosilu=True, nodma=True, nold=True, nost=True)),
+                     ("bottleneck_asm_c48_nomem", False, dict(nodma=True, nold=True, nost=True))]
+    for name, stamped, opt in variants:
         text += [f"\t.globl\t{name}", "\t.p2align\t8", f"\t.type\t{name},@function"]
-        text += gen_kernel(name, stamped)
+        text += gen_kernel(name, stamped, **opt)
         entries.append(metadata_entry(name))
         text += [f".Lfend_{name}:", f"\t.size\t{name}, .Lfend_{name}-{name}", descriptor(name)]
     text.append(f"""	.amdgpu_metadata

@@ -81,6 +81,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    if path == LIB_PATH and os.environ.get("AQ_ENGINE_LIB"):
+        path = os.environ["AQ_ENGINE_LIB"]             # A/B runs of two builds of the library in one session (tools/build_variant.py)
     if not os.path.exists(path):
         raise RuntimeError(f"{path} not found: build it with `python -m aquaculture_amd.build` "
                            "(there is no CPU/PyTorch fallback for the detect path)")
