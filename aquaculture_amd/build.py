@@ -31,6 +31,7 @@ SOURCES = [
     ("detect_nms.hip", ["-ffp-contract=off"]),   # bit-level parity with the oracle's fp32 op order
     ("head_decode.hip", ["-ffp-contract=off"]),  # the same decode arithmetic, fused behind the Detect head convs
     ("jpeg_idct.hip", []),                       # device half of the split JPEG decode (IDCT, chroma upsampling, colour conversion)
+    ("jpeg_huff.hip", []),                       # GPU entropy decode (round 4): the Huffman stage, one lane per restart segment
     ("engine.cpp", ["-x", "hip"]),
 ]
 # -packed-fp32-ops: no v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 in compiled kernels.  The SiLU epilogues run beside other waves' MFMAs (two

@@ -373,3 +373,179 @@ int aq_jpeg_scan(const uint8_t* data, size_t n, aq_jpeg_info* info) {
     const int rc = aq_jpeg_decode_coeffs(data, n, NULL, 0, info);
     return rc == AQJ_SPACE ? AQJ_OK : rc;
 }
+
+
+/* ---------------------------------------------------------------------------------------------------------------------------------------
+ * GPU entropy decode (round 4; VERDICT r03 item 8b, SURVEY.md 8f rank 2 "optional GPU Huffman later"): the host keeps only what is
+ * byte-serial and cheap -- header parsing and the removal of byte stuffing / restart markers while the file is copied into the upload
+ * buffer -- and the Huffman decoding itself runs on the device (csrc/jpeg_huff.hip: one lane per restart segment, i.e. per image for
+ * the files GDAL writes, which have no restart markers).  H2D then carries the 40-140 KB of a tile's entropy-coded data instead of its
+ * 3 MB coefficient image, and a tile costs the host tens of microseconds instead of 1.0-2.4 ms.
+ *
+ * aq_jpeg_prepare: parses the headers exactly as aq_jpeg_decode_coeffs does (same refusals: anything but baseline / extended sequential
+ * 8-bit YCbCr 4:2:0 is AQJ_UNSUPPORTED; colour signalling as libjpeg reads it), then writes to stream_out the scan's entropy-coded bytes
+ * with every stuffed 0x00 removed, cut at the restart markers: segment i (MCUs i * restart .. of the scan; one segment without DRI) starts at
+ * seg_off[i], a multiple of 16, and is followed by >= 8 zero bytes.  An unexpected marker inside the scan, a wrong RSTn sequence or a
+ * missing EOI is AQJ_CORRUPT (what the bit reader's overrun check catches in the host decoder is caught by the device the same way).
+ * tabs: the scan's six Huffman tables (DC / AC of the three components) in the device decoder's format. */
+typedef struct aq_jpeg_gpu_tab {
+    uint16_t look[1 << LOOK];     /* (length << 8) | symbol for codes of <= 9 bits, 0 = longer */
+    int32_t maxcode[18];
+    int32_t valoff[18];           /* (17 used) */
+    uint8_t vals[256];
+} aq_jpeg_gpu_tab;                /* 1024 + 72 + 72 + 256 = 1424 bytes */
+
+typedef struct aq_jpeg_stream_info {
+    int32_t width, height, mcu_cols, mcu_rows;
+    int32_t restart;              /* MCUs per restart interval, 0 = none */
+    int32_t nseg;                 /* segments written */
+    uint32_t stream_bytes;        /* bytes used in stream_out */
+    uint32_t pad;
+    uint64_t tab_hash;            /* FNV-1a of tabs: equal hashes = equal tables (callers share one device copy) */
+    uint16_t qt[3][64];
+    aq_jpeg_gpu_tab tabs[6];      /* [component][dc, ac] */
+} aq_jpeg_stream_info;
+
+int aq_jpeg_prepare(const uint8_t* data, size_t n, uint8_t* stream_out, size_t cap, uint32_t* seg_off, uint32_t* seg_len, int seg_cap,
+                    aq_jpeg_stream_info* si) {
+    if (!data || !si || n < 4 || data[0] != 0xFF || data[1] != 0xD8) return AQJ_CORRUPT;
+    memset(si, 0, sizeof *si);
+    uint16_t qt[4][64];
+    int qt_present[4] = {0, 0, 0, 0};
+    HuffTab hdc[4], hac[4];
+    for (int i = 0; i < 4; ++i) hdc[i].present = hac[i].present = 0;
+    int comp_id[3] = {0, 0, 0}, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0};
+    int restart = 0, have_sof = 0, ncomp = 0;
+    int saw_jfif = 0, saw_adobe = 0, adobe_transform = 0;
+    size_t pos = 2;
+    while (pos + 4 <= n) {
+        if (data[pos] != 0xFF) return AQJ_CORRUPT;
+        const unsigned m = data[pos + 1];
+        if (m == 0xFF) { ++pos; continue; }
+        pos += 2;
+        if (m == 0xD9) return AQJ_CORRUPT;
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (pos + 2 > n) return AQJ_CORRUPT;
+        const unsigned len = be16(data + pos);
+        if (len < 2 || pos + len > n) return AQJ_CORRUPT;
+        const uint8_t* seg = data + pos + 2;
+        const unsigned sl = len - 2;
+        if (m == 0xDB) {
+            unsigned o = 0;
+            while (o < sl) {
+                const int pq = seg[o] >> 4, tq = seg[o] & 15;
+                if (tq > 3 || pq > 1) return AQJ_CORRUPT;
+                ++o;
+                if (o + (pq ? 128u : 64u) > sl) return AQJ_CORRUPT;
+                for (int k = 0; k < 64; ++k) qt[tq][kZigzag[k]] = (uint16_t)(pq ? be16(seg + o + 2 * k) : seg[o + k]);
+                o += pq ? 128 : 64;
+                qt_present[tq] = 1;
+            }
+        } else if (m == 0xC4) {
+            unsigned o = 0;
+            while (o + 17 <= sl) {
+                const int tc = seg[o] >> 4, th = seg[o] & 15;
+                if (tc > 1 || th > 3) return AQJ_CORRUPT;
+                int cnt = 0;
+                for (int k = 0; k < 16; ++k) cnt += seg[o + 1 + k];
+                if (cnt > 256 || o + 17 + (unsigned)cnt > sl) return AQJ_CORRUPT;
+                const int rc = build(tc ? &hac[th] : &hdc[th], seg + o + 1, seg + o + 17, cnt);
+                if (rc) return rc;
+                o += 17 + (unsigned)cnt;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            if (sl < 6 || seg[0] != 8) return AQJ_UNSUPPORTED;
+            si->height = (int32_t)be16(seg + 1);
+            si->width = (int32_t)be16(seg + 3);
+            ncomp = seg[5];
+            if (ncomp != 3 || sl < 6u + 9u || si->width <= 0 || si->height <= 0) return AQJ_UNSUPPORTED;
+            for (int c = 0; c < 3; ++c) {
+                comp_id[c] = seg[6 + 3 * c];
+                comp_h[c] = seg[7 + 3 * c] >> 4;
+                comp_v[c] = seg[7 + 3 * c] & 15;
+                comp_q[c] = seg[8 + 3 * c];
+                if (comp_q[c] > 3) return AQJ_CORRUPT;
+            }
+            if (!(comp_h[0] == 2 && comp_v[0] == 2 && comp_h[1] == 1 && comp_v[1] == 1 && comp_h[2] == 1 && comp_v[2] == 1)) return AQJ_UNSUPPORTED;
+            have_sof = 1;
+        } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            return AQJ_UNSUPPORTED;
+        } else if (m == 0xE0) {
+            if (sl >= 5 && !memcmp(seg, "JFIF", 5)) saw_jfif = 1;
+        } else if (m == 0xEE) {
+            if (sl >= 12 && !memcmp(seg, "Adobe", 5)) { saw_adobe = 1; adobe_transform = seg[11]; }
+        } else if (m == 0xDD) {
+            if (sl < 2) return AQJ_CORRUPT;
+            restart = (int)be16(seg);
+        } else if (m == 0xDA) {
+            if (!have_sof || sl < 1 || seg[0] != 3 || sl < 1u + 6u + 3u) return AQJ_UNSUPPORTED;
+            if (!saw_jfif && (saw_adobe ? adobe_transform == 0 : (comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B'))) return AQJ_UNSUPPORTED;
+            for (int c = 0; c < 3; ++c) {
+                if (seg[1 + 2 * c] != comp_id[c]) return AQJ_UNSUPPORTED;
+                const int td = seg[2 + 2 * c] >> 4, ta = seg[2 + 2 * c] & 15;
+                if (td > 3 || ta > 3 || !hdc[td].present || !hac[ta].present || !qt_present[comp_q[c]]) return AQJ_CORRUPT;
+                memcpy(si->qt[c], qt[comp_q[c]], sizeof si->qt[c]);
+                const HuffTab* src[2] = {&hdc[td], &hac[ta]};
+                for (int k = 0; k < 2; ++k) {
+                    aq_jpeg_gpu_tab* t = &si->tabs[2 * c + k];
+                    memcpy(t->look, src[k]->look, sizeof t->look);
+                    memcpy(t->maxcode, src[k]->maxcode, sizeof t->maxcode);
+                    memcpy(t->valoff, src[k]->valoff, 17 * sizeof(int32_t));
+                    t->valoff[0] = 0; t->valoff[17] = 0;
+                    t->maxcode[0] = -1;
+                    memcpy(t->vals, src[k]->vals, 256);
+                }
+            }
+            uint64_t h = 1469598103934665603ull;
+            for (size_t i = 0; i < sizeof si->tabs; ++i) { h ^= ((const uint8_t*)si->tabs)[i]; h *= 1099511628211ull; }
+            si->tab_hash = h;
+            si->mcu_cols = (si->width + 15) / 16;
+            si->mcu_rows = (si->height + 15) / 16;
+            si->restart = restart;
+            const long long total_mcu = (long long)si->mcu_cols * si->mcu_rows;
+            const long long want_seg = restart ? (total_mcu + restart - 1) / restart : 1;
+            if (!stream_out || !seg_off || !seg_len || want_seg > seg_cap) { si->nseg = (int32_t)want_seg; return AQJ_SPACE; }
+            /* the scan: copy, dropping stuffed zeros; cut at RSTn (which must count 0..7 in order); stop at EOI */
+            const uint8_t* p = data + pos + len;
+            const uint8_t* end = data + n;
+            size_t o = 0;
+            int nseg = 0, next_rst = 0, saw_eoi = 0;
+            seg_off[0] = 0;
+            while (p < end) {
+                const uint8_t* ff = (const uint8_t*)memchr(p, 0xFF, (size_t)(end - p));
+                const size_t run = (size_t)((ff ? ff : end) - p);
+                if (o + run + 48 > cap) return AQJ_SPACE;
+                memcpy(stream_out + o, p, run);
+                o += run;
+                if (!ff) { p = end; break; }
+                if (ff + 1 >= end) return AQJ_CORRUPT;
+                const unsigned mk = ff[1];
+                if (mk == 0x00) { stream_out[o++] = 0xFF; p = ff + 2; continue; }          /* stuffed: a data byte 0xFF */
+                if (mk == 0xFF) { p = ff + 1; continue; }                                  /* fill byte */
+                if (mk >= 0xD0 && mk <= 0xD7) {
+                    if (!restart || mk != (unsigned)(0xD0 + next_rst) || nseg + 1 >= want_seg) return AQJ_CORRUPT;
+                    next_rst = (next_rst + 1) & 7;
+                    seg_len[nseg] = (uint32_t)(o - seg_off[nseg]);
+                    if (o + 40 > cap) return AQJ_SPACE;
+                    memset(stream_out + o, 0, 24);
+                    o = (o + 8 + 15) & ~(size_t)15;                                        /* >= 8 zero bytes, next segment 16-byte aligned */
+                    seg_off[++nseg] = (uint32_t)o;
+                    p = ff + 2;
+                    continue;
+                }
+                if (mk == 0xD9) { saw_eoi = 1; break; }
+                return AQJ_CORRUPT;                                                        /* any other marker inside the scan */
+            }
+            if (!saw_eoi || nseg + 1 != want_seg) return AQJ_CORRUPT;
+            seg_len[nseg] = (uint32_t)(o - seg_off[nseg]);
+            if (o + 40 > cap) return AQJ_SPACE;
+            memset(stream_out + o, 0, 24);
+            o = (o + 8 + 15) & ~(size_t)15;
+            si->nseg = nseg + 1;
+            si->stream_bytes = (uint32_t)o;
+            return AQJ_OK;
+        }
+        pos += len;
+    }
+    return AQJ_CORRUPT;
+}

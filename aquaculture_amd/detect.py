@@ -91,10 +91,12 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
     p.add_argument("--autotune", choices=("auto", "on", "off"), default="auto",
                    help="time the conv kernels' tile configurations on the first full batch and keep the fastest per layer "
                         "(cached in $AQ_TUNE_CACHE or ~/.cache/aquaculture_amd/); auto = only for sweeps of >= 8 batches per GPU")
-    p.add_argument("--jpeg-decode", choices=("auto", "host", "split"), default="auto",
+    p.add_argument("--jpeg-decode", choices=("auto", "host", "split", "gpu"), default="auto",
                    help="split: the decode workers undo only the Huffman coding, the GPU does the inverse DCT, chroma upsampling and colour "
                         "conversion (byte-identical to libjpeg-turbo; baseline 4:2:0 JPEGs, which is what the reference's tiler writes); "
-                        "host: full software decode in the workers; auto: split when every image of the sweep qualifies")
+                        "host: full software decode in the workers; auto: split when every image of the sweep qualifies; "
+                        "gpu: the Huffman stage on the GPU as well (one lane per image, super-batches of AQ_JPEG_GPU_SUPERBATCH = 1024 tiles in "
+                        "flight): the host only reads the files and strips byte stuffing, H2D carries the files' entropy-coded bytes")
     p.add_argument("--resume", action="store_true",
                    help="continue an interrupted sweep in project/name (implies --exist-ok): tiles recorded in the run directory's "
                         "done.rank*.txt manifests are skipped, also those that produced no label file")
@@ -111,7 +113,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         project="runs/detect", name="exp", exist_ok=False, half=False, batch_size=64, precision=None,
         workers=8, decode_threads=False, quiet=False, geocode_bboxes=None, geocode_out=None, tile_scenes=0, autotune="auto", resume=False,
         jpeg_decode="auto", log=print, **unsupported):
-    from .engine import Engine, format_label_rows, jpeg_slots_to_rgb, letterbox_device, letterbox_scene_tiles   # raises if the HIP library or the GPU is missing: there is no fallback
+    from .engine import Engine, format_label_rows, jpeg_idct_rgb, jpeg_slots_to_rgb, letterbox_device, letterbox_scene_tiles   # raises if the HIP library or the GPU is missing: there is no fallback
 
     for k in UNSUPPORTED:
         if unsupported.get(k):
@@ -290,6 +292,98 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
             names = [os.path.join(os.path.dirname(path), st_ + ".tif") for st_ in stems]     # label file = <tile stem>.txt
             yield names, ("scene", path, arr, origins, hw), [hw] * len(stems), None, gids
 
+    gpu_superbatch = max(batch_size, int(os.environ.get("AQ_JPEG_GPU_SUPERBATCH", 1024)) // batch_size * batch_size)
+
+    def gpu_jpeg_source(sub):
+        """--jpeg-decode gpu: (paths, ("gpu_coef", coef int16 CUDA [b * nco], qt int16 CUDA [b, 192], decode-done event, done-hook), shapes,
+        None) per batch.  Three super-batches rotate: while the engine consumes the batches of super-batch k, the Huffman kernel of k + 1
+        runs (one launch; its latency is one image's serial decode, 50-200 ms) and reader threads prepare k + 2."""
+        from concurrent.futures import ThreadPoolExecutor
+        from . import jpeg as aqjpeg
+        from .engine import jpeg_huffman_decode
+        wh = aqjpeg.scan_file(sub.files[0])
+        W0, H0 = wh
+        nco = aqjpeg.coef_count(H0, W0)
+        SB, NB = gpu_superbatch, 3
+        per = aqjpeg.stream_capacity(H0, W0)
+        host = [torch.zeros(SB * per + 256, dtype=torch.uint8).pin_memory() for _ in range(NB)]
+        batches_h = [aqjpeg.GpuDecodeBatch(SB, H0, W0, stream_buf=h.numpy(), bytes_per_image=per) for h in host]
+        dev_streams = [torch.empty(SB * per + 256, dtype=torch.uint8, device=dev) for _ in range(NB)]
+        dev_coef = [torch.empty(SB * nco, dtype=torch.int16, device=dev) for _ in range(NB)]
+        status_h = [torch.zeros(SB * 64, dtype=torch.int32).pin_memory() for _ in range(NB)]
+        dstreams = [torch.cuda.Stream() for _ in range(NB)]
+        consumed = [[] for _ in range(NB)]                 # events of the batches that read buffer i: its next decode waits for them
+        chunks = [sub.files[s_:s_ + SB] for s_ in range(0, len(sub.files), SB)]
+        pool = ThreadPoolExecutor(max(2, min(sub.workers, 16)))
+
+        def prepare(k):
+            b = batches_h[k % NB]
+            paths = chunks[k]
+
+            def one(j):
+                with open(paths[j], "rb") as f:
+                    data = f.read()
+                rc = b.add(j, data)
+                if rc != 0:
+                    raise ValueError(f"{paths[j]}: GPU JPEG decode preparation status {rc} (-1 unsupported coding, -2 corrupt data, -3 more than "
+                                     f"{per * 8 / (H0 * W0):.1f} bits per pixel: raise AQ_JPEG_GPU_BPP or use --jpeg-decode split)")
+            list(pool.map(one, range(len(paths))))
+            return b.finish(len(paths))
+
+        def launch(k, prepared):
+            i = k % NB
+            segs, sets, first = prepared
+            n = len(chunks[k])
+            ds = dstreams[i]
+            for ev_ in consumed[i]:
+                ds.wait_event(ev_)
+            consumed[i] = []
+            with torch.cuda.stream(ds):
+                used = int(segs["stream_off"][-1]) + int(segs["stream_len"][-1]) + 256
+                dev_streams[i][:used].copy_(host[i][:used], non_blocking=True)
+                segs_d = torch.from_numpy(segs.view(np.uint8).reshape(-1, 32)).pin_memory().to(dev, non_blocking=True)
+                sets_d = torch.from_numpy(np.ascontiguousarray(sets)).pin_memory().to(dev, non_blocking=True)
+                qt_d = torch.from_numpy(batches_h[i].qt[:n].view(np.int16).reshape(n, 192).copy()).pin_memory().to(dev, non_blocking=True)
+                dev_coef[i][:n * nco].zero_()
+                st_d = torch.empty(segs.shape[0], dtype=torch.int32, device=dev)
+                jpeg_huffman_decode(dev_streams[i], segs_d, sets_d, dev_coef[i], st_d)
+                if segs.shape[0] > status_h[i].numel():
+                    raise ValueError("GPU JPEG decode: too many restart segments per super-batch (lower AQ_JPEG_GPU_SUPERBATCH)")
+                status_h[i][:segs.shape[0]].copy_(st_d, non_blocking=True)
+                ev_ = torch.cuda.Event()
+                ev_.record(ds)
+            return ev_, qt_d, first, segs.shape[0], (segs_d, sets_d, st_d)
+
+        try:
+            prepared = {}
+            launched = {}
+            for k in range(min(2, len(chunks))):
+                prepared[k] = prepare(k)
+            if chunks:
+                launched[0] = launch(0, prepared.pop(0))
+            for k in range(len(chunks)):
+                if k + 1 < len(chunks) and k + 1 not in launched:
+                    launched[k + 1] = launch(k + 1, prepared.pop(k + 1))          # decode of the NEXT super-batch runs while this one is consumed
+                if k + 2 < len(chunks):
+                    prepared[k + 2] = prepare(k + 2)
+                ev_, qt_d, first, nseg, keep = launched.pop(k)
+                ev_.synchronize()                                                  # this super-batch's coefficients are in HBM; its statuses on the host
+                st = status_h[k % NB][:nseg].numpy()
+                if st.any():
+                    bad_seg = int(np.nonzero(st)[0][0])
+                    bad_img = int(np.searchsorted(first, bad_seg, side="right") - 1)
+                    raise ValueError(f"{chunks[k][bad_img]}: corrupt JPEG scan (GPU entropy decode status {int(st[bad_seg])}; libjpeg / Pillow refuse "
+                                     "the file as truncated)")
+                i = k % NB
+                paths_k = chunks[k]
+                for s_ in range(0, len(paths_k), batch_size):
+                    b_ = min(batch_size, len(paths_k) - s_)
+                    hook = (lambda e, i=i: consumed[i].append(e))
+                    yield (paths_k[s_:s_ + b_], ("gpu_coef", dev_coef[i][s_ * nco:(s_ + b_) * nco], qt_d[s_:s_ + b_], ev_, hook, (H0, W0), nco),
+                           [(H0, W0)] * b_, None)
+        finally:
+            pool.shutdown(wait=False)
+
     def image_source():
         """Every header is read once (no decode): the images of the most common size take the zero-copy pinned path, any others
         (the reference's tiler cuts smaller edge tiles for scenes that are not a multiple of 1024, src/load_data/tile_tifs.py:35-36)
@@ -326,12 +420,20 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                         bad = [sub.files[i] for i, r in enumerate(scan) if r is None]
                         raise ValueError(f"--jpeg-decode split: {len(bad)} of {len(scan)} images are not baseline 4:2:0 JPEGs the split decoder reads "
                                          f"(use auto or host): {', '.join(bad[:3])}{' ...' if len(bad) > 3 else ''}")
+                if jpeg_decode == "gpu" and not split:
+                    raise ValueError("--jpeg-decode gpu needs baseline 4:2:0 JPEGs throughout (use auto or host)")
                 if split and not split_note[0]:
                     split_note[0] = True
-                    log(f"jpeg decode: split (entropy decoding in {sub.workers} worker processes, IDCT / upsampling / colour conversion on the GPU)")
-                gen = sub.pinned_batches(batch_size, depth + 2, processes=0 if decode_threads else None, coef=split)     # one buffer more than the batches in flight: the workers decode one batch ahead
-                release_of[0] = lambda i, sub=sub: sub.release(i)
-                it = gen
+                    log(f"jpeg decode: split (entropy decoding in {sub.workers} worker processes, IDCT / upsampling / colour conversion on the GPU)"
+                        if jpeg_decode != "gpu" else
+                        f"jpeg decode: gpu (entropy decoding on the GPU, one lane per image, super-batches of {gpu_superbatch} tiles; "
+                        f"{sub.workers} reader threads strip byte stuffing; IDCT / upsampling / colour conversion on the GPU)")
+                if jpeg_decode == "gpu":
+                    it = gpu_jpeg_source(sub)
+                else:
+                    gen = sub.pinned_batches(batch_size, depth + 2, processes=0 if decode_threads else None, coef=split)     # one buffer more than the batches in flight: the workers decode one batch ahead
+                    release_of[0] = lambda i, sub=sub: sub.release(i)
+                    it = gen
             else:
                 it = ((p_, torch.from_numpy(b_).pin_memory(), s_, None) for p_, b_, s_ in sub.batches(batch_size))
             n_ = 0
@@ -362,7 +464,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
             slot_free[slot].acquire()
             st = streams[slot]
             with torch.cuda.stream(st):
-                if isinstance(host, tuple):                # scene mode: one upload per scene, tiles cut by the letterbox kernel
+                if isinstance(host, tuple) and host[0] == "scene":      # scene mode: one upload per scene, tiles cut by the letterbox kernel
                     _, spath, sarr, origins, thw = host
                     if spath != scene_path:                # page-locked source: async copy, its buffer goes back once the copy is done
                         scene_dev, scene_path = torch.from_numpy(sarr).to(dev, non_blocking=True), spath
@@ -373,6 +475,17 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                         st.wait_event(scene_ev)            # another stream uploaded this scene
                     scene_dev.record_stream(st)
                     tiles = letterbox_scene_tiles(scene_dev, origins, thw, tuple(imgsz), int(max(ck.stride)), True)
+                elif isinstance(host, tuple) and host[0] == "gpu_coef":   # --jpeg-decode gpu: the coefficient blocks are in HBM already
+                    _, coef_v, qt_v, dec_ev, hook, (h0_, w0_), nco_ = host
+                    st.wait_event(dec_ev)
+                    if jpeg_scratch[slot] is None:
+                        jpeg_scratch[slot] = torch.empty(eng.lib.aq_jpeg_scratch_bytes(batch_size, h0_, w0_), dtype=torch.uint8, device=dev)
+                    off_ = torch.arange(qt_v.shape[0], dtype=torch.int64, device=dev) * nco_
+                    tiles = jpeg_idct_rgb(coef_v, off_, qt_v, h0_, w0_, scratch=jpeg_scratch[slot])
+                    used_ev = torch.cuda.Event()
+                    used_ev.record(st)
+                    hook(used_ev)                          # the super-batch's buffer is free for its next decode once this batch has read it
+                    tiles = letterbox_device(tiles, tuple(imgsz), int(max(ck.stride)), True)
                 else:
                     tiles = host.to(dev, non_blocking=True)
                     if buf_i is not None:                  # hand the pinned buffer back once its H2D copy has completed

@@ -103,6 +103,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_engine_autotune.argtypes = [vp, vp, i32, i32, i32, vp, sz, i32, vp]
     lib.aq_engine_get_conv_config.argtypes = [vp, i32]
     lib.aq_engine_last_launch.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.aq_jpeg_huffman_decode.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     lib.aq_engine_set_tuned_table.argtypes = [vp, i32, i32, i32, C.POINTER(i32), i32]
     lib.aq_engine_calibrate_amax.argtypes = [vp, vp, i32, i32, i32, vp, sz, C.POINTER(f32), i32, vp]
     lib.aq_engine_set_fp8_scales.argtypes = [vp, C.POINTER(f32), i32]
@@ -865,6 +866,21 @@ def jpeg_idct_rgb(coef: torch.Tensor, coef_off: torch.Tensor, qt: torch.Tensor, 
         scratch = torch.empty(n, dtype=torch.uint8, device=coef.device)
     _check(lib.aq_jpeg_idct_rgb(coef.data_ptr(), coef_off.data_ptr(), qt.data_ptr(), B, H, W, scratch.data_ptr(), out.data_ptr(), _stream_ptr()))
     return out
+
+
+def jpeg_huffman_decode(streams: torch.Tensor, segs: torch.Tensor, tabsets: torch.Tensor, coef: torch.Tensor, status: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GPU entropy decode (aq_jpeg_huffman_decode): ``streams`` uint8 CUDA = the upload buffer jpeg.GpuDecodeBatch filled, ``segs`` uint8
+    CUDA [nseg, 32] = its segment descriptors, ``tabsets`` uint8 CUDA [n_sets, jpeg.TABSET_BYTES]; ``coef`` int16 CUDA, ZEROED by the caller,
+    receives the quantised coefficient blocks in the host decoder's layout.  Returns the per-segment status tensor (int32; 0 = ok)."""
+    _require_gpu()
+    lib = load_library()
+    assert streams.is_cuda and streams.dtype == torch.uint8 and segs.is_cuda and segs.dtype == torch.uint8 and segs.dim() == 2 and segs.shape[1] == 32
+    assert tabsets.is_cuda and tabsets.dtype == torch.uint8 and coef.is_cuda and coef.dtype == torch.int16
+    nseg = int(segs.shape[0])
+    if status is None:
+        status = torch.empty(nseg, dtype=torch.int32, device=streams.device)
+    _check(lib.aq_jpeg_huffman_decode(streams.data_ptr(), segs.data_ptr(), nseg, tabsets.data_ptr(), coef.data_ptr(), status.data_ptr(), _stream_ptr()))
+    return status
 
 
 def jpeg_slots_to_rgb(slots: torch.Tensor, H: int, W: int, scratch: Optional[torch.Tensor] = None) -> torch.Tensor:

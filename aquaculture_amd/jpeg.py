@@ -32,8 +32,25 @@ def load_lib():
         lib = C.CDLL(lib_path())
         lib.aq_jpeg_decode_coeffs.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(JpegInfo)]
         lib.aq_jpeg_scan.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(JpegInfo)]
+        lib.aq_jpeg_prepare.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(StreamInfo)]
         _LIB = lib
     return _LIB
+
+
+class GpuTab(C.Structure):
+    _fields_ = [("look", C.c_uint16 * 512), ("maxcode", C.c_int32 * 18), ("valoff", C.c_int32 * 18), ("vals", C.c_uint8 * 256)]
+
+
+class StreamInfo(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("mcu_cols", C.c_int32), ("mcu_rows", C.c_int32), ("restart", C.c_int32),
+                ("nseg", C.c_int32), ("stream_bytes", C.c_uint32), ("pad", C.c_uint32), ("tab_hash", C.c_uint64), ("qt", (C.c_uint16 * 64) * 3),
+                ("tabs", GpuTab * 6)]
+
+
+SEG_DTYPE = np.dtype([("stream_off", "<u4"), ("stream_len", "<u4"), ("coef_off", "<u8"), ("mcu0", "<u4"), ("n_mcu", "<u4"),
+                      ("mcu_cols", "<u2"), ("mcu_rows", "<u2"), ("tabset", "<u4")])
+assert SEG_DTYPE.itemsize == 32
+TABSET_BYTES = 6 * C.sizeof(GpuTab)
 
 
 def coef_count(H: int, W: int) -> int:
@@ -103,6 +120,77 @@ def decode_coeffs(data: bytes, coef_out: np.ndarray, qt_out: np.ndarray) -> Tupl
             return AQJ_UNSUPPORTED, info
         qt_out[...] = np.ctypeslib.as_array(info.qt).reshape(3, 64)
     return rc, info
+
+
+class GpuDecodeBatch:
+    """Host side of the GPU entropy decode for a batch of same-size JPEG files: every file's scan -- byte stuffing removed, cut at restart
+    markers -- back to back in one (page-locked, if the caller passes such a buffer) upload buffer, the 32-byte segment descriptors the
+    device kernel reads (aq_jpeg_huffman_decode, include/aq_engine.h), the quantisation tables, and the distinct Huffman table sets.
+    ``add`` is thread-safe per slot: callers prepare different slots from different threads (the C call releases the GIL)."""
+
+    MAX_SEG = 4096                     # restart segments per image (a DRI of one MCU row on a 1024-px tile gives 64)
+
+    def __init__(self, n_images: int, H: int, W: int, stream_buf: Optional[np.ndarray] = None, bytes_per_image: Optional[int] = None):
+        self.n, self.H, self.W = n_images, H, W
+        self.per = bytes_per_image or stream_capacity(H, W)
+        self.streams = stream_buf if stream_buf is not None else np.zeros(n_images * self.per + 256, np.uint8)      # (+ 256: the device reads whole 64-byte chunks, two ahead)
+        assert self.streams.dtype == np.uint8 and self.streams.size >= n_images * self.per + 256
+        self.qt = np.zeros((n_images, 3, 64), np.uint16)
+        self.nco = coef_count(H, W)
+        self._segs = [None] * n_images
+        self._hash = [0] * n_images
+        self._tabs = [None] * n_images
+
+    def add(self, slot: int, data: bytes) -> int:
+        """Prepare image `slot` from the file's bytes.  Returns AQJ_OK or the status that makes the caller fall back / fail."""
+        info = StreamInfo()
+        off = np.zeros(self.MAX_SEG, np.uint32)
+        ln = np.zeros(self.MAX_SEG, np.uint32)
+        base = slot * self.per
+        rc = load_lib().aq_jpeg_prepare(data, len(data), self.streams[base:].ctypes.data, self.per, off.ctypes.data, ln.ctypes.data, self.MAX_SEG, C.byref(info))
+        if rc != AQJ_OK:
+            return rc
+        if (info.width, info.height) != (self.W, self.H):
+            raise ValueError(f"{info.height}x{info.width} differs from the batch's {self.H}x{self.W}; mixed sizes need batches()")
+        n = info.nseg
+        segs = np.zeros(n, SEG_DTYPE)
+        segs["stream_off"] = off[:n] + base
+        segs["stream_len"] = ln[:n]
+        segs["coef_off"] = slot * self.nco
+        per_seg = info.restart if info.restart else info.mcu_cols * info.mcu_rows
+        segs["mcu0"] = np.arange(n, dtype=np.uint32) * per_seg
+        segs["n_mcu"] = np.minimum(per_seg, info.mcu_cols * info.mcu_rows - segs["mcu0"])
+        segs["mcu_cols"], segs["mcu_rows"] = info.mcu_cols, info.mcu_rows
+        self.qt[slot] = np.ctypeslib.as_array(info.qt).reshape(3, 64)
+        self._segs[slot], self._hash[slot] = segs, int(info.tab_hash)
+        self._tabs[slot] = bytes(info.tabs)
+        return AQJ_OK
+
+    def finish(self, count: Optional[int] = None):
+        """(segment descriptors [nseg] of SEG_DTYPE, table sets uint8 [n_sets][TABSET_BYTES], first segment of every image [count + 1]) for
+        images 0 .. count - 1, table sets de-duplicated by hash."""
+        count = self.n if count is None else count
+        sets, index = [], {}
+        parts, first = [], [0]
+        for i in range(count):
+            h = self._hash[i]
+            if h not in index:
+                index[h] = len(sets)
+                sets.append(np.frombuffer(self._tabs[i], np.uint8))
+            sg = self._segs[i]
+            sg["tabset"] = index[h]
+            parts.append(sg)
+            first.append(first[-1] + sg.shape[0])
+        return np.concatenate(parts), np.stack(sets), np.asarray(first, np.int64)
+
+
+def stream_capacity(H: int, W: int, bits_per_pixel: Optional[float] = None) -> int:
+    """Upload-buffer bytes reserved per image (a multiple of 128).  Default 2 bits per pixel + slack (AQ_JPEG_GPU_BPP overrides): GDAL's
+    q = 75 tiles take 0.3 (smooth water) to 1.1 (detailed imagery) bits per pixel; a file that needs more makes GpuDecodeBatch.add return
+    AQJ_SPACE and the caller decodes the sweep with the host decoder instead (tests pass bits_per_pixel = 12: q = 100 noise)."""
+    bpp = bits_per_pixel if bits_per_pixel is not None else float(os.environ.get("AQ_JPEG_GPU_BPP", 2.0))
+    px = (H + 15) // 16 * 16 * ((W + 15) // 16 * 16)
+    return (int(px * bpp / 8) + 8192 + 127) // 128 * 128
 
 
 if __name__ == "__main__":                      # header scanner process (scan_files_in_processes)

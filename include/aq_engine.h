@@ -317,6 +317,16 @@ int aq_letterbox_tiles_u8(const uint8_t* scene_dev, long long scene_bytes, long 
 size_t aq_jpeg_scratch_bytes(int B, int H, int W);
 int aq_jpeg_idct_rgb(const int16_t* coef_dev, const long long* coef_off_dev, const uint16_t* qt_dev, int B, int H, int W,
                      void* scratch_dev, uint8_t* out_dev, void* stream);
+/* GPU entropy decode (round 4): the Huffman stage of the same decode on the device, one lane per restart segment (= per image for files
+ * without restart markers).  Replaces the host half's aq_jpeg_decode_coeffs ([UPSTREAM LoadImages -> cv2.imread]'s entropy stage;
+ * producer of the files: reference src/load_data/tile_tifs.py:66-74).  streams_dev: the bytes aq_jpeg_prepare (include/aq_jpeg.h) wrote,
+ * uploaded as they are; segs_dev: nseg descriptors of 32 bytes {u32 stream_off, u32 stream_len, u64 coef_off (int16 index of the image's
+ * first coefficient in coef_dev), u32 mcu0, u32 n_mcu, u16 mcu_cols, u16 mcu_rows, u32 tabset}; tabsets_dev: table sets of six
+ * aq_jpeg_gpu_tab each; coef_dev: ZEROED coefficient buffers in aq_jpeg_decode_coeffs's layout; status_dev: int32 per segment (0 ok, 2 corrupt).
+ * The kernel reads the stream in 64-byte chunks from each segment's start and runs up to two chunks ahead: streams_dev needs 256 readable
+ * bytes behind the last segment.  The caller validates every offset; the kernel trusts them. */
+int aq_jpeg_huffman_decode(const void* streams_dev, const void* segs_dev, int nseg, const void* tabsets_dev, void* coef_dev,
+                           void* status_dev, void* stream);
 /* SPPF pools: y1 = mp5(x), y2 = mp5(y1), y3 = mp5(y2) written to channel slices c, 2c, 3c of the same buffer. */
 int aq_sppf_pool(void* buf_dev, int ld, int ch_off, int c, int B, int H, int W, int precision, void* stream);
 /* nearest 2x upsample of a channel slice into a channel slice. */

@@ -31,6 +31,33 @@ int aq_jpeg_decode_coeffs(const uint8_t* data, size_t n, int16_t* coef_out, size
 /* Headers only: fills info (sizes, tables). */
 int aq_jpeg_scan(const uint8_t* data, size_t n, aq_jpeg_info* info);
 
+
+/* ---- GPU entropy decode (round 4): the host parses the headers and strips byte stuffing / restart markers while copying the scan into
+ * the upload buffer; the Huffman decoding runs on the device (aq_jpeg_huffman_decode, include/aq_engine.h), one lane per restart segment.
+ * Same refusals as aq_jpeg_decode_coeffs (AQJ_UNSUPPORTED: use the software decoder; AQJ_CORRUPT: truncated scan, stray marker, missing EOI). */
+typedef struct aq_jpeg_gpu_tab {
+    uint16_t look[512];                   /* (length << 8) | symbol for codes of <= 9 bits, 0 = longer */
+    int32_t maxcode[18];                  /* largest code of each length 1..16 (-1: none), [17] = sentinel */
+    int32_t valoff[18];                   /* vals index of the first code of a length minus that code */
+    uint8_t vals[256];
+} aq_jpeg_gpu_tab;
+
+typedef struct aq_jpeg_stream_info {
+    int32_t width, height, mcu_cols, mcu_rows;
+    int32_t restart;                      /* MCUs per restart interval (0: none) = MCUs per segment */
+    int32_t nseg;                         /* segments written (AQJ_SPACE: segments needed) */
+    uint32_t stream_bytes;                /* bytes used in stream_out */
+    uint32_t pad;
+    uint64_t tab_hash;                    /* equal hashes = equal Huffman tables: callers keep one device copy per distinct hash */
+    uint16_t qt[3][64];                   /* quantisation tables per component, natural order */
+    aq_jpeg_gpu_tab tabs[6];              /* [component][dc, ac] */
+} aq_jpeg_stream_info;
+
+/* stream_out (capacity cap): the scan's bytes without stuffed zeros, segment i at seg_off[i] (a multiple of 16), seg_len[i] bytes long,
+ * followed by >= 8 zero bytes.  seg_cap: capacity of seg_off / seg_len. */
+int aq_jpeg_prepare(const uint8_t* data, size_t n, uint8_t* stream_out, size_t cap, uint32_t* seg_off, uint32_t* seg_len, int seg_cap,
+                    aq_jpeg_stream_info* si);
+
 #ifdef __cplusplus
 }
 #endif

@@ -415,3 +415,26 @@ def test_cli_refuses_a_truncated_tile_in_both_decode_modes(workdir, lib, tmp_pat
         assert r.returncode != 0 and victim in r.stderr, (mode, r.stderr[-1500:])
         done = tmp_path / "runs" / ("trunc_" + mode) / "done.rank0.txt"
         assert not done.exists() or victim[:-5] not in open(done).read().split()
+
+
+def test_gpu_jpeg_decode_gives_identical_labels(workdir, lib, tmp_path):
+    """--jpeg-decode gpu (round 4: the Huffman stage on the GPU too, one lane per image, super-batches) against --jpeg-decode host: the
+    coefficient blocks equal the host decoder's (tests/test_jpeg.py), so the label files are byte-identical; with a super-batch smaller
+    than the directory the rotation of the three buffers is exercised; a tile cut short is refused with its name."""
+    import shutil
+    out_h, lab_h = _run(workdir, "gjpeg_host", extra=("--quiet", "--half", "--jpeg-decode", "host"))
+    out_g, lab_g = _run(workdir, "gjpeg_gpu", extra=("--quiet", "--half", "--jpeg-decode", "gpu"), env={"AQ_JPEG_GPU_SUPERBATCH": "4"})
+    assert "jpeg decode: gpu" in out_g
+    names = sorted(os.listdir(lab_h))
+    assert names and names == sorted(os.listdir(lab_g))
+    for n in names:
+        assert open(lab_g / n, "rb").read() == open(lab_h / n, "rb").read(), n
+    src = tmp_path / "jpegs"
+    shutil.copytree(workdir / "jpegs", src)
+    victim = sorted(os.listdir(src))[5]
+    data = (src / victim).read_bytes()
+    (src / victim).write_bytes(data[: len(data) * 2 // 3])
+    cmd = [sys.executable, os.path.join(ROOT, "yolov5", "detect.py"), "--weights", str(workdir / "multilabel_farms_synth.pt"), "--source", str(src),
+           "--nosave", "--save-txt", "--save-conf", "--project", str(tmp_path / "runs"), "--name", "gjpeg_trunc", "--batch-size", "4", "--half", "--jpeg-decode", "gpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+    assert r.returncode != 0 and victim in r.stderr, r.stderr[-1500:]

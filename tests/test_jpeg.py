@@ -52,7 +52,7 @@ def test_libaqjpeg_exports_what_its_header_declares(jpeg_lib):
     import re
     hdr = open(os.path.join(ROOT, "include", "aq_jpeg.h")).read()
     names = set(re.findall(r"\b(aq_jpeg_\w+)\s*\(", hdr))
-    assert names == {"aq_jpeg_decode_coeffs", "aq_jpeg_scan"}
+    assert names == {"aq_jpeg_decode_coeffs", "aq_jpeg_scan", "aq_jpeg_prepare"}
     lib = jpeg_lib.load_lib()
     for n in names:
         assert hasattr(lib, n), n
@@ -235,3 +235,141 @@ def test_header_scan_in_processes_equals_the_in_process_one(jpeg_lib, tmp_path):
     assert want[:3] == [(64, 64), (80, 80), (96, 96)] and want[-2:] == [None, None]
     assert jpeg_lib.scan_files_in_processes(paths, 3) == want
     assert jpeg_lib.scan_files_in_processes(paths[:1], 8) == want[:1]
+
+
+def _scan_bytes(data):
+    """The entropy-coded bytes of a baseline file, from behind the SOS header up to (not including) EOI."""
+    sos = data.index(b"\xff\xda")
+    start = sos + 2 + int.from_bytes(data[sos + 2:sos + 4], "big")
+    end = data.rindex(b"\xff\xd9")
+    return data[start:end]
+
+
+@pytest.mark.parametrize("idx", range(11))
+def test_gpu_decode_preparation_is_the_scan_minus_stuffing_and_restart_markers(jpeg_lib, idx):
+    """aq_jpeg_prepare (host side of the GPU entropy decode): putting the stuffed zeros and the RSTn markers back into what it wrote gives the
+    file's scan bytes exactly; segments are 4-byte aligned, zero-padded, one per restart interval; tables and sizes equal the header scan's."""
+    name, data = _cases()[idx]
+    ref = _pil(data)
+    H, W = ref.shape[:2]
+    b = jpeg_lib.GpuDecodeBatch(2, H, W, bytes_per_image=jpeg_lib.stream_capacity(H, W, 12))
+    assert b.add(1, data) == 0, name
+    sg = b._segs[1]
+    rebuilt = bytearray()
+    for i, s in enumerate(sg):
+        off, ln = int(s["stream_off"]), int(s["stream_len"])
+        assert off % 16 == 0 and off >= b.per and not b.streams[off + ln:off + ln + 8].any(), name
+        rebuilt += bytes(b.streams[off:off + ln]).replace(b"\xff", b"\xff\x00")
+        if i + 1 < len(sg):
+            rebuilt += bytes([0xFF, 0xD0 + (i & 7)])
+    assert bytes(rebuilt) == _scan_bytes(data), name
+    info = jpeg_lib.scan(data)
+    assert np.array_equal(b.qt[1], np.ctypeslib.as_array(info.qt).reshape(3, 64))
+    total = info.mcu_cols * info.mcu_rows
+    assert int(sg["n_mcu"].sum()) == total and int(sg["mcu0"][0]) == 0 and (np.diff(sg["mcu0"].astype(np.int64)) == sg["n_mcu"][:-1]).all()
+    assert (sg["coef_off"] == b.nco).all()
+
+
+def test_gpu_decode_preparation_refuses_what_the_host_decoder_refuses(jpeg_lib):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 255, (32, 48, 3), dtype=np.uint8)
+    b = jpeg_lib.GpuDecodeBatch(1, 32, 48, bytes_per_image=jpeg_lib.stream_capacity(32, 48, 12))
+    for kw in (dict(subsampling=0), dict(progressive=True)):
+        assert b.add(0, _jpeg(img, **kw)) == -1, kw
+    assert b.add(0, _jpeg(img[..., 0])) == -1
+    good = _jpeg(img, quality=90, restart_marker_blocks=2)
+    assert b.add(0, good) == 0
+    for cut in (len(good) // 2, len(good) - 2, 40):
+        assert b.add(0, good[:cut]) == -2, cut                     # truncated: no EOI
+    sos = good.index(b"\xff\xda")
+    mid = sos + (len(good) - sos) // 2
+    assert b.add(0, good[:mid] + b"\xff\xc4" + good[mid + 2:]) == -2      # a stray marker inside the scan
+    rst = good.index(b"\xff\xd0", sos)
+    assert b.add(0, good[:rst] + b"\xff\xd3" + good[rst + 2:]) == -2      # restart markers out of sequence
+    with pytest.raises(ValueError):
+        b.add(0, _jpeg(rng.integers(0, 255, (48, 48, 3), dtype=np.uint8)))  # another size than the batch's
+
+
+@pytest.mark.gpu
+def test_gpu_entropy_decode_equals_the_host_decoder(jpeg_lib, lib):
+    """aq_jpeg_huffman_decode (one lane per restart segment) on batches of same-size files: the coefficient buffers equal
+    aq_jpeg_decode_coeffs's, value for value -- and therefore, through aq_jpeg_idct_rgb, Pillow's pixels byte for byte."""
+    import torch
+    from aquaculture_amd import engine, tiles
+    rng = np.random.default_rng(11)
+    noise = lambda h, w: rng.integers(0, 255, (h, w, 3), dtype=np.uint8)
+    groups = {
+        (640, 640): [_jpeg(tiles.synthetic_tile(i, 640), quality=75) for i in (0, 3, 19, 40)] + [_jpeg(noise(640, 640), quality=q) for q in (50, 95)],
+        (1024, 1024): [_jpeg(tiles.synthetic_tile(i, 1024), quality=75) for i in (1, 19)] + [_jpeg(noise(1024, 1024), quality=75, optimize=True)],
+        (100, 150): [_jpeg(noise(100, 150), quality=q) for q in (30, 75, 98)] + [_jpeg(noise(100, 150), quality=60, restart_marker_blocks=3)],
+        (33, 17): [_jpeg(noise(33, 17), quality=80)],
+        (64, 64): [_jpeg(noise(64, 64), quality=75, restart_marker_blocks=3), _jpeg(noise(64, 64), quality=85, restart_marker_rows=1),
+                   _jpeg(np.tile(np.array([[[255, 0, 0], [0, 255, 0]], [[0, 0, 255], [255, 255, 255]]], np.uint8).repeat(8, 0).repeat(8, 1), (4, 4, 1)), quality=100)],
+    }
+    for (H, W), files in groups.items():
+        # 70 images: more than one wave of segments, files repeated
+        files = (files * 70)[:70]
+        n = jpeg_lib.coef_count(H, W)
+        want = np.zeros((len(files), n), np.int16)
+        qt = np.zeros((len(files), 3, 64), np.uint16)
+        for i, data in enumerate(files):
+            rc, _ = jpeg_lib.decode_coeffs(data, want[i], qt[i])
+            assert rc == 0
+        b = jpeg_lib.GpuDecodeBatch(len(files), H, W, bytes_per_image=jpeg_lib.stream_capacity(H, W, 12))
+        for i, data in enumerate(files):
+            assert b.add(i, data) == 0
+        segs, sets, first = b.finish()
+        coef = torch.zeros((len(files), n), dtype=torch.int16, device="cuda")
+        st = engine.jpeg_huffman_decode(torch.from_numpy(b.streams).cuda(), torch.from_numpy(segs.view(np.uint8).reshape(-1, 32)).cuda(),
+                                        torch.from_numpy(sets).cuda(), coef.view(-1))
+        assert int(st.abs().max()) == 0, (H, W, st.cpu().tolist())
+        got = coef.cpu().numpy()
+        assert np.array_equal(b.qt, qt)
+        bad = [i for i in range(len(files)) if not np.array_equal(got[i], want[i])]
+        assert not bad, f"{H}x{W}: images {bad[:5]} differ ({int((got != want).sum())} values)"
+        off = torch.arange(len(files), dtype=torch.int64) * n
+        rgb = engine.jpeg_idct_rgb(coef.view(-1), off.cuda(), torch.from_numpy(b.qt.view(np.int16)).cuda(), H, W).cpu().numpy()
+        for i in (0, len(files) - 1):
+            assert np.array_equal(rgb[i], _pil(files[i]))
+
+
+@pytest.mark.gpu
+def test_gpu_entropy_decode_flags_damaged_scans(jpeg_lib, lib):
+    """Bits flipped inside the entropy-coded data (markers intact, so the host preparation accepts the file): every segment either decodes to
+    SOME coefficients or reports status 2 -- the kernel terminates, stays inside its buffers (a canary behind them is intact), and a scan cut
+    short inside its data (the EOI kept) is reported as consumed-past-the-end."""
+    import torch
+    from aquaculture_amd import engine
+    rng = np.random.default_rng(5)
+    H, W = 96, 128
+    good = _jpeg(rng.integers(0, 255, (H, W, 3), dtype=np.uint8), quality=80)
+    sos = good.index(b"\xff\xda")
+    start = sos + 2 + int.from_bytes(good[sos + 2:sos + 4], "big")
+    files = [good]
+    for k in range(40):
+        d = bytearray(good)
+        for _ in range(1 + k % 5):
+            pos = int(rng.integers(start, len(good) - 2))
+            d[pos] = (d[pos] ^ (1 << int(rng.integers(0, 8)))) & 0xFE or 0x01          # never create 0xFF (a marker) by accident
+        files.append(bytes(d))
+    files.append(good[:start + (len(good) - start) // 3] + b"\xff\xd9")                # a third of the scan, then EOI
+    b = jpeg_lib.GpuDecodeBatch(len(files), H, W, bytes_per_image=jpeg_lib.stream_capacity(H, W, 12))
+    keep = [i for i, d in enumerate(files) if b.add(i, d) == 0]
+    assert 0 in keep and len(files) - 1 in keep and len(keep) > 30
+    # compact the accepted files into slots 0.. (finish() wants a prefix)
+    b2 = jpeg_lib.GpuDecodeBatch(len(keep), H, W, bytes_per_image=jpeg_lib.stream_capacity(H, W, 12))
+    for j, i in enumerate(keep):
+        assert b2.add(j, files[i]) == 0
+    segs, sets, first = b2.finish()
+    n = jpeg_lib.coef_count(H, W)
+    coef = torch.zeros(len(keep) * n + 4096, dtype=torch.int16, device="cuda")
+    coef[len(keep) * n:] = 12345
+    st = engine.jpeg_huffman_decode(torch.from_numpy(b2.streams).cuda(), torch.from_numpy(segs.view(np.uint8).reshape(-1, 32)).cuda(),
+                                    torch.from_numpy(sets).cuda(), coef).cpu().numpy()
+    assert set(st.tolist()) <= {0, 2} and st[0] == 0 and st[-1] == 2
+    assert bool((coef[len(keep) * n:] == 12345).all())
+    host_ok = []
+    tmp, qt = np.zeros(n, np.int16), np.zeros((3, 64), np.uint16)
+    for j, i in enumerate(keep):
+        host_ok.append(jpeg_lib.decode_coeffs(files[i], tmp, qt)[0] == 0)
+    assert [s == 0 for s in st.tolist()] == host_ok                                     # the same files are refused as by the host decoder
