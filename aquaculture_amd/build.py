@@ -104,7 +104,7 @@ def build_jpeg_lib() -> str:
     cc = shutil.which("gcc") or shutil.which("cc") or shutil.which("clang")
     if not cc:
         raise RuntimeError("no C compiler for libaqjpeg.so")
-    r = subprocess.run([cc, "-O3", "-shared", "-fPIC", "-Wall", "-o", JPEG_LIB + ".tmp", os.path.join(CSRC, "jpeg_coef.c")], capture_output=True, text=True)
+    r = subprocess.run([cc, "-O3", "-shared", "-fPIC", "-Wall", "-pthread", "-o", JPEG_LIB + ".tmp", os.path.join(CSRC, "jpeg_coef.c")], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"{cc} failed on jpeg_coef.c:\n{r.stdout}\n{r.stderr}")
     os.replace(JPEG_LIB + ".tmp", JPEG_LIB)

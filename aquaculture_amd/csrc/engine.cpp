@@ -2,6 +2,8 @@
 // The engine allocates device memory only in aq_engine_create (packed weights, zero page, events);
 // every launch-path function only enqueues work on the caller's stream.
 #include "aq_common.h"
+#include <unistd.h>
+#include <string>
 
 #include <cstdarg>
 #include <cstdio>
@@ -1037,6 +1039,41 @@ extern "C" int aq_engine_op_times(aq_engine* e, float* ms_out, int n_ops, int* c
     if (calls > 0) for (int i = 0; i < n_ops; ++i) ms_out[i] /= calls;
     if (calls_recorded) *calls_recorded = calls;
     return AQ_OK;
+}
+
+// Host helper of the label writer, a whole batch per call (round 4): tile t's rows are rows[offsets[t] .. offsets[t + 1]) (cls xc yc w h conf,
+// fp32, already in file order); every tile with at least one row gets <dir>/<stem>.txt with exactly the bytes aq_format_label_rows produces,
+// truncating what was there (a tile processed again after a crash leaves the same bytes); tiles without rows get no file (the consumer,
+// reference src/process_yolo/geocode_results.py:123, relies on it).  One call per batch from a writer thread: the interpreter lock is
+// released for the formatting (~2,000 %g conversions per tile with the synthetic checkpoint) AND the file system calls -- with a Python
+// `open / write / close` per tile the four writer threads serialised on the lock at ~5 k tiles/s.  do_fsync: fsync every file before
+// closing it (the fallback where syncfs is unavailable).  Returns the number of files written, or -1 - t when tile t could not be written.
+extern "C" long aq_format_label_rows(const float* rows, int n, int save_conf, char* buf, size_t buflen);
+extern "C" long aq_write_label_files(const char* dir, const char* const* stems, const float* rows, const long long* offsets, int n_tiles,
+                                     int save_conf, int do_fsync) {
+    if (!dir || !stems || !rows || !offsets || n_tiles < 0) return -1;
+    std::vector<char> buf(1 << 16);
+    std::string path;
+    long written = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+        const long long n = offsets[t + 1] - offsets[t];
+        if (n <= 0) continue;
+        long k = aq_format_label_rows(rows + (size_t)offsets[t] * 6, (int)n, save_conf, buf.data(), buf.size());
+        if (k < 0) {
+            buf.resize((size_t)(-k) + 64);
+            k = aq_format_label_rows(rows + (size_t)offsets[t] * 6, (int)n, save_conf, buf.data(), buf.size());
+        }
+        path.assign(dir);
+        path += '/';
+        path += stems[t];
+        path += ".txt";
+        FILE* f = fopen(path.c_str(), "wb");
+        if (!f) return -1 - t;
+        const bool ok = fwrite(buf.data(), 1, (size_t)k, f) == (size_t)k && fflush(f) == 0 && (!do_fsync || fsync(fileno(f)) == 0);
+        if (fclose(f) != 0 || !ok) return -1 - t;
+        ++written;
+    }
+    return written;
 }
 
 // Host helper of the label writer: n rows (cls xc yc w h conf, fp32) -> text exactly as `detect.py --save-txt --save-conf`

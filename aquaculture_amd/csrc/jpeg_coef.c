@@ -88,6 +88,7 @@ static void fill(Bits* b) {
 static int build(HuffTab* t, const uint8_t* counts, const uint8_t* vals, int nvals) {
     int code = 0, k = 0;
     memset(t->look, 0, sizeof t->look);
+    memset(t->vals, 0, sizeof t->vals);                         /* (the GPU path hashes and uploads whole tables: no stack bytes in them) */
     memcpy(t->vals, vals, (size_t)nvals);
     for (int len = 1; len <= 16; ++len) {
         t->valoff[len] = k - code;
@@ -548,4 +549,102 @@ int aq_jpeg_prepare(const uint8_t* data, size_t n, uint8_t* stream_out, size_t c
         pos += len;
     }
     return AQJ_CORRUPT;
+}
+
+
+/* A whole super-batch at once, without the interpreter in the loop: reads `n` files and prepares each into its slot of the upload buffer
+ * (slot i = per_image bytes at streams + i * per_image), on `nthreads` POSIX threads (files i = t, t + nthreads, ...).  Per image: status[i]
+ * (AQJ_*; a file of another size than W x H is AQJ_UNSUPPORTED with nseg[i] = -1), nseg[i] segments in segs[i * seg_cap ..] (stream_off
+ * relative to `streams`, coef_off = i * coef_per_image, tabset left 0 for the caller), qt[i], hash[i] and tabs[i] (the caller keeps one copy
+ * per distinct hash).  Returns the number of files whose status is not AQJ_OK. */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef struct aq_jpeg_seg {
+    uint32_t stream_off, stream_len;
+    uint64_t coef_off;
+    uint32_t mcu0, n_mcu;
+    uint16_t mcu_cols, mcu_rows;
+    uint32_t tabset;
+} aq_jpeg_seg;
+
+typedef struct {
+    const char* const* paths; int n, H, W; uint8_t* streams; size_t per_image; aq_jpeg_seg* segs; int seg_cap; uint64_t coef_per_image;
+    int32_t* status; int32_t* nseg; uint16_t* qt; uint64_t* hash; aq_jpeg_gpu_tab* tabs; int t, nthreads;
+} PrepJob;
+
+static void* prep_thread(void* arg) {
+    PrepJob* j = (PrepJob*)arg;
+    uint8_t* buf = NULL;
+    size_t cap = 0;
+    uint32_t* off = (uint32_t*)malloc(sizeof(uint32_t) * 2 * (size_t)j->seg_cap);
+    uint32_t* len = off ? off + j->seg_cap : NULL;
+    aq_jpeg_stream_info* si = (aq_jpeg_stream_info*)malloc(sizeof *si);
+    for (int i = j->t; i < j->n; i += j->nthreads) {
+        j->status[i] = AQJ_CORRUPT; j->nseg[i] = 0;
+        if (!off || !si) continue;
+        FILE* f = fopen(j->paths[i], "rb");
+        if (!f) continue;
+        size_t got = 0;
+        for (;;) {
+            if (got + 65536 > cap) {
+                const size_t ncap = cap ? cap * 2 : (size_t)1 << 18;
+                uint8_t* nb = (uint8_t*)realloc(buf, ncap);
+                if (!nb) { got = 0; break; }
+                buf = nb; cap = ncap;
+            }
+            const size_t r = fread(buf + got, 1, cap - got, f);
+            got += r;
+            if (r == 0) break;
+        }
+        fclose(f);
+        if (!got) continue;
+        const size_t base = (size_t)i * j->per_image;
+        const int rc = aq_jpeg_prepare(buf, got, j->streams + base, j->per_image, off, len, j->seg_cap, si);
+        j->status[i] = rc;
+        if (rc != AQJ_OK) continue;
+        if (si->width != j->W || si->height != j->H) { j->status[i] = AQJ_UNSUPPORTED; j->nseg[i] = -1; continue; }
+        j->nseg[i] = si->nseg;
+        const uint32_t per_seg = si->restart ? (uint32_t)si->restart : (uint32_t)(si->mcu_cols * si->mcu_rows);
+        const uint32_t total = (uint32_t)(si->mcu_cols * si->mcu_rows);
+        for (int k = 0; k < si->nseg; ++k) {
+            aq_jpeg_seg* sg = &j->segs[(size_t)i * j->seg_cap + k];
+            sg->stream_off = (uint32_t)(base + off[k]);
+            sg->stream_len = len[k];
+            sg->coef_off = (uint64_t)i * j->coef_per_image;
+            sg->mcu0 = (uint32_t)k * per_seg;
+            sg->n_mcu = sg->mcu0 + per_seg <= total ? per_seg : total - sg->mcu0;
+            sg->mcu_cols = (uint16_t)si->mcu_cols; sg->mcu_rows = (uint16_t)si->mcu_rows;
+            sg->tabset = 0;
+        }
+        memcpy(j->qt + (size_t)i * 192, si->qt, 384);
+        j->hash[i] = si->tab_hash;
+        memcpy(&j->tabs[(size_t)i * 6], si->tabs, sizeof si->tabs);
+    }
+    free(buf); free(off); free(si);
+    return NULL;
+}
+
+int aq_jpeg_prepare_files(const char* const* paths, int n, int H, int W, uint8_t* streams, size_t per_image, void* segs, int seg_cap,
+                          uint64_t coef_per_image, int32_t* status, int32_t* nseg, uint16_t* qt, uint64_t* hash, void* tabs, int nthreads) {
+    if (!paths || n <= 0 || !streams || !segs || seg_cap <= 0 || !status || !nseg || !qt || !hash || !tabs || (uint64_t)n * per_image >= ((uint64_t)1 << 32))
+        return -1;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    if (nthreads > n) nthreads = n;
+    PrepJob jobs[64];
+    pthread_t th[64];
+    int started[64];
+    for (int t = 0; t < nthreads; ++t) {
+        PrepJob jb = {paths, n, H, W, streams, per_image, (aq_jpeg_seg*)segs, seg_cap, coef_per_image, status, nseg, qt, hash, (aq_jpeg_gpu_tab*)tabs, t, nthreads};
+        jobs[t] = jb;
+        started[t] = pthread_create(&th[t], NULL, prep_thread, &jobs[t]) == 0;
+        if (!started[t]) prep_thread(&jobs[t]);             /* no thread: do its share here */
+    }
+    for (int t = 0; t < nthreads; ++t)
+        if (started[t]) pthread_join(th[t], NULL);
+    int bad = 0;
+    for (int i = 0; i < n; ++i) bad += status[i] != AQJ_OK;
+    return bad;
 }

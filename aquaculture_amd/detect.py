@@ -113,7 +113,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         project="runs/detect", name="exp", exist_ok=False, half=False, batch_size=64, precision=None,
         workers=8, decode_threads=False, quiet=False, geocode_bboxes=None, geocode_out=None, tile_scenes=0, autotune="auto", resume=False,
         jpeg_decode="auto", log=print, **unsupported):
-    from .engine import Engine, format_label_rows, jpeg_idct_rgb, jpeg_slots_to_rgb, letterbox_device, letterbox_scene_tiles   # raises if the HIP library or the GPU is missing: there is no fallback
+    from .engine import Engine, format_label_rows, write_label_files, jpeg_idct_rgb, jpeg_slots_to_rgb, letterbox_device, letterbox_scene_tiles   # raises if the HIP library or the GPU is missing: there is no fallback
 
     for k in UNSUPPORTED:
         if unsupported.get(k):
@@ -228,7 +228,27 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                 same = all(sh == shapes0[0] for sh in shapes0)       # the pinned path: one original size per batch -> one numpy pass for all tiles
                 if same:
                     rows_all, offs = postprocess.batch_rows(det_all, cnt[:len(paths)], (H, W), shapes0[0])
-                for b, p in enumerate(paths):
+                bulk = same and quiet and save_txt                  # a whole batch of label files in ONE C call (no interpreter lock held; round 4)
+                if bulk:
+                    ndet = int(offs[-1])
+                    if multi and ndet:                              # the batch's rows for the detection gather, in one piece
+                        cnt_b = cnt[:len(paths)].astype(np.int64)
+                        keep_ = np.arange(det_all.shape[1])[None, :] < cnt_b[:, None]
+                        with gather_lock:
+                            gather.add(torch.from_numpy(np.repeat(np.asarray(gidx, np.int32), cnt_b)), aqdist.pack_rows(torch.from_numpy(det_all[:len(paths)][keep_].copy())))
+                    fs_fallback = durable and not can_syncfs[0]
+                    nlab = write_label_files(labels_dir, [os.path.splitext(os.path.basename(p))[0] for p in paths], rows_all, offs, save_conf, fsync=fs_fallback)
+                    if durable and nlab and can_syncfs[0] and not sync_filesystem_of(labels_dir):
+                        can_syncfs[0] = False               # (no syncfs here: this batch's files are synced one by one now, later batches inside the C call)
+                        for p in paths:
+                            fp_ = os.path.join(labels_dir, os.path.splitext(os.path.basename(p))[0] + ".txt")
+                            if os.path.exists(fp_):
+                                fd_ = os.open(fp_, os.O_RDONLY)
+                                os.fsync(fd_)
+                                os.close(fd_)
+                    if durable and nlab and not can_syncfs[0]:
+                        fsync_dir(labels_dir)
+                for b, p in enumerate(paths if not bulk else ()):
                     det = det_all[b, : cnt[b]]
                     ndet += det.shape[0]
                     rows = rows_all[offs[b]:offs[b + 1]] if same else postprocess.detections_to_rows(det, (H, W), shapes0[b])
@@ -276,6 +296,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
 
     lock = threading.Lock()
     manifest_lock = threading.Lock()
+    can_syncfs = [True]
     n_writers = 4 if quiet else 1          # per-image log lines stay in order with a single writer
     depth_q = depth
     wts = [threading.Thread(target=writer, daemon=True) for _ in range(n_writers)]
@@ -292,43 +313,35 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
             names = [os.path.join(os.path.dirname(path), st_ + ".tif") for st_ in stems]     # label file = <tile stem>.txt
             yield names, ("scene", path, arr, origins, hw), [hw] * len(stems), None, gids
 
-    gpu_superbatch = max(batch_size, int(os.environ.get("AQ_JPEG_GPU_SUPERBATCH", 1024)) // batch_size * batch_size)
+    gpu_superbatch = max(batch_size, int(os.environ.get("AQ_JPEG_GPU_SUPERBATCH", 2048)) // batch_size * batch_size)
 
     def gpu_jpeg_source(sub):
-        """--jpeg-decode gpu: (paths, ("gpu_coef", coef int16 CUDA [b * nco], qt int16 CUDA [b, 192], decode-done event, done-hook), shapes,
-        None) per batch.  Three super-batches rotate: while the engine consumes the batches of super-batch k, the Huffman kernel of k + 1
-        runs (one launch; its latency is one image's serial decode, 50-200 ms) and reader threads prepare k + 2."""
+        """--jpeg-decode gpu: (paths, ("gpu_coef", coef int16 CUDA [b * nco], qt int16 CUDA [b, 192], decode-done event, done-hook, ...), shapes,
+        None) per batch.  Four super-batch buffers rotate: while the engine consumes the batches of super-batch k, the Huffman kernels of
+        k + 1 and k + 2 run (one launch each: a launch takes as long as its slowest image's serial decode, 50-200 ms for 1024-px tiles,
+        whatever the number of tiles in it) and C threads read and prepare the files of k + 3 (aq_jpeg_prepare_files)."""
         from concurrent.futures import ThreadPoolExecutor
         from . import jpeg as aqjpeg
         from .engine import jpeg_huffman_decode
-        wh = aqjpeg.scan_file(sub.files[0])
-        W0, H0 = wh
+        W0, H0 = aqjpeg.scan_file(sub.files[0])
         nco = aqjpeg.coef_count(H0, W0)
-        SB, NB = gpu_superbatch, 3
+        D = 2                                              # decode launches in flight ahead of the one being consumed
+        NB = D + 2
+        SB = min(gpu_superbatch, (len(sub.files) + batch_size - 1) // batch_size * batch_size)
         per = aqjpeg.stream_capacity(H0, W0)
+        if SB * per + 256 >= 1 << 32:
+            raise ValueError("--jpeg-decode gpu: AQ_JPEG_GPU_SUPERBATCH x bytes per image exceeds 4 GiB; lower it")
+        chunks = [sub.files[s_:s_ + SB] for s_ in range(0, len(sub.files), SB)]
+        NB = min(NB, len(chunks))
         host = [torch.zeros(SB * per + 256, dtype=torch.uint8).pin_memory() for _ in range(NB)]
         batches_h = [aqjpeg.GpuDecodeBatch(SB, H0, W0, stream_buf=h.numpy(), bytes_per_image=per) for h in host]
         dev_streams = [torch.empty(SB * per + 256, dtype=torch.uint8, device=dev) for _ in range(NB)]
         dev_coef = [torch.empty(SB * nco, dtype=torch.int16, device=dev) for _ in range(NB)]
-        status_h = [torch.zeros(SB * 64, dtype=torch.int32).pin_memory() for _ in range(NB)]
+        status_h = [torch.zeros(SB * aqjpeg.GpuDecodeBatch.SEG_CAP, dtype=torch.int32).pin_memory() for _ in range(NB)]
         dstreams = [torch.cuda.Stream() for _ in range(NB)]
         consumed = [[] for _ in range(NB)]                 # events of the batches that read buffer i: its next decode waits for them
-        chunks = [sub.files[s_:s_ + SB] for s_ in range(0, len(sub.files), SB)]
-        pool = ThreadPoolExecutor(max(2, min(sub.workers, 16)))
-
-        def prepare(k):
-            b = batches_h[k % NB]
-            paths = chunks[k]
-
-            def one(j):
-                with open(paths[j], "rb") as f:
-                    data = f.read()
-                rc = b.add(j, data)
-                if rc != 0:
-                    raise ValueError(f"{paths[j]}: GPU JPEG decode preparation status {rc} (-1 unsupported coding, -2 corrupt data, -3 more than "
-                                     f"{per * 8 / (H0 * W0):.1f} bits per pixel: raise AQ_JPEG_GPU_BPP or use --jpeg-decode split)")
-            list(pool.map(one, range(len(paths))))
-            return b.finish(len(paths))
+        nthreads = max(2, min(sub.workers, 16))
+        pool = ThreadPoolExecutor(1)                       # one orchestrating thread; the parallelism is inside the C call
 
         def launch(k, prepared):
             i = k % NB
@@ -339,7 +352,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                 ds.wait_event(ev_)
             consumed[i] = []
             with torch.cuda.stream(ds):
-                used = int(segs["stream_off"][-1]) + int(segs["stream_len"][-1]) + 256
+                used = (int(segs["stream_off"][-1]) + int(segs["stream_len"][-1]) + 256 + 127) // 128 * 128
                 dev_streams[i][:used].copy_(host[i][:used], non_blocking=True)
                 segs_d = torch.from_numpy(segs.view(np.uint8).reshape(-1, 32)).pin_memory().to(dev, non_blocking=True)
                 sets_d = torch.from_numpy(np.ascontiguousarray(sets)).pin_memory().to(dev, non_blocking=True)
@@ -347,27 +360,23 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                 dev_coef[i][:n * nco].zero_()
                 st_d = torch.empty(segs.shape[0], dtype=torch.int32, device=dev)
                 jpeg_huffman_decode(dev_streams[i], segs_d, sets_d, dev_coef[i], st_d)
-                if segs.shape[0] > status_h[i].numel():
-                    raise ValueError("GPU JPEG decode: too many restart segments per super-batch (lower AQ_JPEG_GPU_SUPERBATCH)")
                 status_h[i][:segs.shape[0]].copy_(st_d, non_blocking=True)
                 ev_ = torch.cuda.Event()
                 ev_.record(ds)
             return ev_, qt_d, first, segs.shape[0], (segs_d, sets_d, st_d)
 
         try:
-            prepared = {}
-            launched = {}
-            for k in range(min(2, len(chunks))):
-                prepared[k] = prepare(k)
-            if chunks:
-                launched[0] = launch(0, prepared.pop(0))
+            futures, launched = {}, {}
+            next_prep = next_launch = 0
             for k in range(len(chunks)):
-                if k + 1 < len(chunks) and k + 1 not in launched:
-                    launched[k + 1] = launch(k + 1, prepared.pop(k + 1))          # decode of the NEXT super-batch runs while this one is consumed
-                if k + 2 < len(chunks):
-                    prepared[k + 2] = prepare(k + 2)
+                while next_prep < len(chunks) and next_prep < k + NB:          # (buffer next_prep % NB was last used by super-batch next_prep - NB < k)
+                    futures[next_prep] = pool.submit(batches_h[next_prep % NB].prepare_files, chunks[next_prep], nthreads)
+                    next_prep += 1
+                while next_launch < len(chunks) and next_launch <= k + D:
+                    launched[next_launch] = launch(next_launch, futures.pop(next_launch).result())
+                    next_launch += 1
                 ev_, qt_d, first, nseg, keep = launched.pop(k)
-                ev_.synchronize()                                                  # this super-batch's coefficients are in HBM; its statuses on the host
+                ev_.synchronize()                                              # this super-batch's coefficients are in HBM; its statuses on the host
                 st = status_h[k % NB][:nseg].numpy()
                 if st.any():
                     bad_seg = int(np.nonzero(st)[0][0])

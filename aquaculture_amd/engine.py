@@ -70,7 +70,7 @@ EXPORTS = (
     "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_pack_conv_weights_x3", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_stemdown_supported", "aq_stemdown", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
     "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct",
     "aq_conv3x3_pl_supported", "aq_conv3x3_pl_asm_family", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_s2_supported", "aq_pack_conv3x3_pl_s2", "aq_conv3x3_pl_s2", "aq_jpeg_scratch_bytes", "aq_jpeg_idct_rgb", "aq_f32_to_e4m3", "aq_conv1x1_direct_f8out", "aq_absmax_bf16", "aq_engine_calibrate_amax", "aq_engine_set_fp8_scales", "aq_engine_last_launch", "aq_conv3x3_pl_f8_supported", "aq_pack_conv3x3_pl_f8", "aq_conv3x3_pl_f8", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
-    "aq_upsample2x", "aq_letterbox_u8", "aq_letterbox_tiles_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms",
+    "aq_upsample2x", "aq_letterbox_u8", "aq_letterbox_tiles_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms", "aq_jpeg_huffman_decode", "aq_write_label_files",
 )
 
 _lib = None
@@ -104,6 +104,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_engine_get_conv_config.argtypes = [vp, i32]
     lib.aq_engine_last_launch.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     lib.aq_jpeg_huffman_decode.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    lib.aq_write_label_files.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(f32), C.POINTER(C.c_longlong), i32, i32, i32]
+    lib.aq_write_label_files.restype = C.c_long
     lib.aq_engine_set_tuned_table.argtypes = [vp, i32, i32, i32, C.POINTER(i32), i32]
     lib.aq_engine_calibrate_amax.argtypes = [vp, vp, i32, i32, i32, vp, sz, C.POINTER(f32), i32, vp]
     lib.aq_engine_set_fp8_scales.argtypes = [vp, C.POINTER(f32), i32]
@@ -624,6 +626,22 @@ def format_label_rows(rows: np.ndarray, save_conf: bool = True) -> bytes:
         buf = C.create_string_buffer(-k + 1)
         k = lib.aq_format_label_rows(rows.ctypes.data_as(C.POINTER(C.c_float)), n, int(save_conf), buf, len(buf))
     return buf.raw[:k]
+
+
+def write_label_files(labels_dir: str, stems, rows: np.ndarray, offsets: np.ndarray, save_conf: bool = True, fsync: bool = False) -> int:
+    """One C call per batch (aq_write_label_files; releases the GIL for formatting and file system calls): tile t's rows are
+    rows[offsets[t]:offsets[t + 1]] (float32 [N, 6], file order); returns the number of label files written (tiles without rows get none)."""
+    lib = load_library()
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = len(stems)
+    assert offsets.shape[0] == n + 1 and (rows.shape[0] == 0 or rows.shape[1] == 6)
+    arr = (C.c_char_p * n)(*[os.fsencode(s_) for s_ in stems])
+    k = lib.aq_write_label_files(os.fsencode(labels_dir), arr, rows.ctypes.data_as(C.POINTER(C.c_float)), offsets.ctypes.data_as(C.POINTER(C.c_longlong)), n,
+                                 int(save_conf), int(fsync))
+    if k < 0:
+        raise OSError(f"could not write the label file of {stems[-1 - k]} in {labels_dir}")
+    return int(k)
 
 
 def stem_conv_nhwc(tiles_u8: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, act: bool = True, precision: str = "bf16") -> torch.Tensor:

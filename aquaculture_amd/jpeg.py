@@ -32,6 +32,8 @@ def load_lib():
         lib = C.CDLL(lib_path())
         lib.aq_jpeg_decode_coeffs.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(JpegInfo)]
         lib.aq_jpeg_scan.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(JpegInfo)]
+        lib.aq_jpeg_prepare_files.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_uint64,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         lib.aq_jpeg_prepare.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(StreamInfo)]
         _LIB = lib
     return _LIB
@@ -165,6 +167,39 @@ class GpuDecodeBatch:
         self._segs[slot], self._hash[slot] = segs, int(info.tab_hash)
         self._tabs[slot] = bytes(info.tabs)
         return AQJ_OK
+
+    SEG_CAP = 64                       # restart segments per image in the bulk path (prepare_files)
+
+    def prepare_files(self, paths, nthreads: int = 8):
+        """Slots 0 .. len(paths) - 1 from files, in C threads (aq_jpeg_prepare_files: file reads, header parsing, byte-stuffing removal -- no
+        interpreter per image).  Returns (segs, table sets, first segment per image) like ``finish``; raises ValueError naming the first file
+        the decoder does not take."""
+        n = len(paths)
+        assert 0 < n <= self.n
+        if not hasattr(self, "_bulk"):
+            self._bulk = (np.zeros((self.n, self.SEG_CAP), SEG_DTYPE), np.zeros(self.n, np.int32), np.zeros(self.n, np.int32),
+                          np.zeros(self.n, np.uint64), np.zeros((self.n, TABSET_BYTES), np.uint8))
+        segs, status, nseg, hashes, tabs = self._bulk
+        arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        bad = load_lib().aq_jpeg_prepare_files(arr, n, self.H, self.W, self.streams.ctypes.data, self.per, segs.ctypes.data, self.SEG_CAP, self.nco,
+                                               status.ctypes.data, nseg.ctypes.data, self.qt.ctypes.data, hashes.ctypes.data, tabs.ctypes.data, nthreads)
+        if bad:
+            i = int(np.nonzero(status[:n])[0][0]) if bad > 0 else 0
+            why = {AQJ_UNSUPPORTED: "not a baseline 8-bit 4:2:0 JPEG of the batch's size", AQJ_CORRUPT: "corrupt or truncated (libjpeg / Pillow refuse the file too)",
+                   AQJ_SPACE: f"more than {self.per * 8 / (self.H * self.W):.1f} bits per pixel or more than {self.SEG_CAP} restart segments: raise "
+                              "AQ_JPEG_GPU_BPP or use --jpeg-decode split"}.get(int(status[i]), f"status {int(status[i])}")
+            raise ValueError(f"{paths[i]}: GPU JPEG decode preparation failed: {why}")
+        uniq, first_idx, inverse = np.unique(hashes[:n], return_index=True, return_inverse=True)
+        counts = nseg[:n]
+        if (counts == 1).all():
+            out = segs[:n, 0].copy()
+            out["tabset"] = inverse
+        else:
+            keep = np.arange(self.SEG_CAP)[None, :] < counts[:, None]
+            out = segs[:n][keep]
+            out["tabset"] = np.repeat(inverse, counts)
+        first = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
+        return out, tabs[first_idx].copy(), first
 
     def finish(self, count: Optional[int] = None):
         """(segment descriptors [nseg] of SEG_DTYPE, table sets uint8 [n_sets][TABSET_BYTES], first segment of every image [count + 1]) for

@@ -366,6 +366,10 @@ int aq_nms(const float* rows_dev, int rows_per_tile, int B, int N, int nc, float
 /* Host helper: n label rows (cls xc yc w h conf, fp32, stride 6) -> the text detect.py --save-txt [--save-conf] writes
  * ("%g" per value, one line per row).  Returns bytes written or -(bytes needed). */
 long aq_format_label_rows(const float* rows, int n, int save_conf, char* buf, size_t buflen);
+/* A batch of label files per call (no interpreter lock held): tile t's rows are rows[offsets[t] .. offsets[t + 1]); tiles with rows get
+ * <dir>/<stems[t]>.txt with aq_format_label_rows's bytes (truncating), tiles without get no file.  Returns files written, or -1 - t. */
+long aq_write_label_files(const char* dir, const char* const* stems, const float* rows, const long long* offsets, int n_tiles,
+                          int save_conf, int do_fsync);
 
 #ifdef __cplusplus
 }

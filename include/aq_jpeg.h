@@ -58,6 +58,13 @@ typedef struct aq_jpeg_stream_info {
 int aq_jpeg_prepare(const uint8_t* data, size_t n, uint8_t* stream_out, size_t cap, uint32_t* seg_off, uint32_t* seg_len, int seg_cap,
                     aq_jpeg_stream_info* si);
 
+/* A super-batch without the interpreter in the loop: reads n files and prepares each into slot i of the upload buffer (per_image bytes at
+ * streams + i * per_image) on nthreads POSIX threads.  segs: 32-byte descriptors as aq_jpeg_huffman_decode reads them, seg_cap per image
+ * (nseg[i] used; tabset left 0); status[i] = AQJ_* (another size than W x H: AQJ_UNSUPPORTED with nseg[i] = -1); qt uint16 [n][3][64];
+ * hash[i], tabs [n][6] aq_jpeg_gpu_tab (keep one per distinct hash).  Returns how many files are not AQJ_OK (-1: bad argument). */
+int aq_jpeg_prepare_files(const char* const* paths, int n, int H, int W, uint8_t* streams, size_t per_image, void* segs, int seg_cap,
+                          uint64_t coef_per_image, int32_t* status, int32_t* nseg, uint16_t* qt, uint64_t* hash, void* tabs, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,3 +191,33 @@ def test_batch_postprocess_equals_the_per_tile_one_bit_for_bit():
             assert want.shape == got.shape and np.array_equal(want.view(np.uint32), got.view(np.uint32)), (shp, b)
     rows, offs = P.batch_rows(det, np.zeros(B, np.int64), (640, 640), (640, 640))
     assert rows.shape == (0, 6) and not offs.any()
+
+
+def test_batch_label_writer_writes_the_bytes_of_the_per_tile_formatter(tmp_path):
+    """aq_write_label_files (one C call per batch, round 4) against the per-tile path it replaces: the same files with the same bytes, no
+    file for a tile without rows, an existing file truncated; an unwritable directory is an error that names the tile."""
+    import numpy as np
+    import pytest
+    from aquaculture_amd import engine, postprocess
+    rng = np.random.default_rng(3)
+    counts = np.array([5, 0, 1, 340, 0, 17])
+    offs = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
+    rows = np.empty((int(offs[-1]), 6), np.float32)
+    rows[:, 0] = rng.integers(0, 5, rows.shape[0])
+    rows[:, 1:5] = rng.integers(0, 1025, (rows.shape[0], 4)) / np.float32(1024)
+    rows[:, 5] = rng.uniform(0.25, 1, rows.shape[0])
+    rows[3, 1:5] = [0, 1e-5, 1, 0.5]                                  # exponent form, integers
+    stems = [f"ORTHOIMAGERY.ORTHOPHOTOS2015_{i}_0_1024" for i in range(len(counts))]
+    (tmp_path / f"{stems[2]}.txt").write_bytes(b"stale content that is longer than the new file\n" * 20)
+    for save_conf in (True, False):
+        n = engine.write_label_files(str(tmp_path), stems, rows, offs, save_conf)
+        assert n == int((counts > 0).sum())
+        for t, stem in enumerate(stems):
+            f = tmp_path / f"{stem}.txt"
+            if counts[t] == 0:
+                assert not f.exists()
+                continue
+            want = engine.format_label_rows(rows[offs[t]:offs[t + 1]], save_conf)
+            assert f.read_bytes() == want == postprocess.format_rows(rows[offs[t]:offs[t + 1]], save_conf).encode()
+    with pytest.raises(OSError, match=stems[0]):
+        engine.write_label_files(str(tmp_path / "missing_dir"), stems, rows, offs, True)

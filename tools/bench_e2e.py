@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--decode-threads", action="store_true", help="in-process decode threads instead of worker processes (A/B)")
     ap.add_argument("--scenes", type=int, default=0, help="scene mode: write this many 6144x6144 scene rasters (36 tiles each) and sweep them "
                                                           "with --tile-scenes instead of a jpeg directory")
-    ap.add_argument("--jpeg-decode", default="auto", choices=("auto", "host", "split"))
+    ap.add_argument("--jpeg-decode", default="auto", choices=("auto", "host", "split", "gpu"))
     ap.add_argument("--noise", type=float, default=0.0, help="Gaussian sensor noise (sigma, 8-bit levels) added before the JPEG encoder: the synthetic tiles are smooth "
                                                              "(0.3 bit per pixel at q75); sigma 10 gives 1.1 bpp, about what detailed aerial imagery compresses to")
     ap.add_argument("--json", default="", help="append this run's numbers to a JSON file (profiles/e2e_latest.json: bench.py quotes it as `e2e`)")
