@@ -201,7 +201,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     # Up to `depth` batches are in flight, each with its own workspace slot, pinned result buffers and stream.
     import queue
     import threading
-    depth = 3
+    depth = max(2, int(os.environ.get("AQ_PIPELINE_DEPTH", 3)))
     streams = [torch.cuda.Stream() for _ in range(depth)]
     slot_free = [threading.Semaphore(1) for _ in range(depth)]   # a slot's pinned result buffers are reused only after its writer is done
     stats = {"seen": 0, "labels": 0, "dets": 0, "t_post": 0.0}
@@ -221,6 +221,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                 ev.synchronize()
                 t0 = time.perf_counter()
                 nlab = ndet = 0
+                released = False
                 H, W = hw
                 cnt = counts_h.numpy()
                 det_all = dets_h.numpy()
@@ -236,6 +237,11 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                         keep_ = np.arange(det_all.shape[1])[None, :] < cnt_b[:, None]
                         with gather_lock:
                             gather.add(torch.from_numpy(np.repeat(np.asarray(gidx, np.int32), cnt_b)), aqdist.pack_rows(torch.from_numpy(det_all[:len(paths)][keep_].copy())))
+                    # the slot's pinned result buffers have been read (batch_rows copied what it needs): hand the slot back BEFORE formatting and
+                    # writing -- ~20 ms of C per batch with the synthetic checkpoint's 340 detections per tile; held across it, three slots capped the
+                    # sweep at ~5.5 k tiles/s whatever the decode path (round 4)
+                    slot_free[slot_id].release()
+                    released = True
                     fs_fallback = durable and not can_syncfs[0]
                     nlab = write_label_files(labels_dir, [os.path.splitext(os.path.basename(p))[0] for p in paths], rows_all, offs, save_conf, fsync=fs_fallback)
                     if durable and nlab and can_syncfs[0] and not sync_filesystem_of(labels_dir):
@@ -265,7 +271,8 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                     if multi and det.shape[0]:
                         with gather_lock:
                             gather.add(torch.full((det.shape[0],), gidx[b], dtype=torch.int32), aqdist.pack_rows(torch.from_numpy(det.copy())))
-                slot_free[slot_id].release()
+                if not released:
+                    slot_free[slot_id].release()
                 # the manifest line below vouches for these bytes: on disk first (files and their directory entries), then the record -- a
                 # node crash must not leave a recorded tile without its label file (it would look like "no detections" for good).
                 # One syncfs per batch; per-file fsync + directory fsync where that is unavailable.
@@ -297,7 +304,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     lock = threading.Lock()
     manifest_lock = threading.Lock()
     can_syncfs = [True]
-    n_writers = 4 if quiet else 1          # per-image log lines stay in order with a single writer
+    n_writers = max(4, min(8, workers // 2)) if quiet else 1          # (per-image log lines stay in order with a single writer; the quiet path's work is C without the interpreter lock)
     depth_q = depth
     wts = [threading.Thread(target=writer, daemon=True) for _ in range(n_writers)]
     for w_ in wts:
@@ -317,21 +324,27 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
 
     def gpu_jpeg_source(sub):
         """--jpeg-decode gpu: (paths, ("gpu_coef", coef int16 CUDA [b * nco], qt int16 CUDA [b, 192], decode-done event, done-hook, ...), shapes,
-        None) per batch.  Four super-batch buffers rotate: while the engine consumes the batches of super-batch k, the Huffman kernels of
-        k + 1 and k + 2 run (one launch each: a launch takes as long as its slowest image's serial decode, 50-200 ms for 1024-px tiles,
+        None) per batch.  D + 2 super-batch buffers rotate: while the engine consumes the batches of super-batch k, the Huffman kernels of
+        k + 1 .. k + D run (one launch each: a launch takes as long as its slowest image's serial decode, 50-200 ms for 1024-px tiles,
         whatever the number of tiles in it) and C threads read and prepare the files of k + 3 (aq_jpeg_prepare_files)."""
         from concurrent.futures import ThreadPoolExecutor
         from . import jpeg as aqjpeg
         from .engine import jpeg_huffman_decode
         W0, H0 = aqjpeg.scan_file(sub.files[0])
         nco = aqjpeg.coef_count(H0, W0)
-        D = 2                                              # decode launches in flight ahead of the one being consumed
+        D = max(1, int(os.environ.get("AQ_JPEG_GPU_INFLIGHT", 3)))     # decode launches in flight ahead of the one being consumed
         NB = D + 2
         SB = min(gpu_superbatch, (len(sub.files) + batch_size - 1) // batch_size * batch_size)
         per = aqjpeg.stream_capacity(H0, W0)
         if SB * per + 256 >= 1 << 32:
             raise ValueError("--jpeg-decode gpu: AQ_JPEG_GPU_SUPERBATCH x bytes per image exceeds 4 GiB; lower it")
-        chunks = [sub.files[s_:s_ + SB] for s_ in range(0, len(sub.files), SB)]
+        # super-batches ramp up (4 x batch, 8 x batch, ... SB): the first tiles reach the engine after one small decode launch instead of a
+        # full one -- a launch takes as long as its slowest image whatever its size, so small launches only cost throughput at the start
+        chunks, s_, size = [], 0, min(SB, 4 * batch_size)
+        while s_ < len(sub.files):
+            chunks.append(sub.files[s_:s_ + size])
+            s_ += size
+            size = min(SB, size * 2)
         NB = min(NB, len(chunks))
         host = [torch.zeros(SB * per + 256, dtype=torch.uint8).pin_memory() for _ in range(NB)]
         batches_h = [aqjpeg.GpuDecodeBatch(SB, H0, W0, stream_buf=h.numpy(), bytes_per_image=per) for h in host]
@@ -464,13 +477,19 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         tune = False                                   # some rank may have no batch to meet the broadcast with
     tune_cache = os.environ.get("AQ_TUNE_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "aquaculture_amd", "tune.json")
     copy_done = []
+    diag = {"source": 0.0, "slot_wait": 0.0, "put": 0.0, "writer_busy": 0.0} if os.environ.get("AQ_E2E_DIAG") == "1" else None
+    t_src = time.perf_counter()
     try:
         for paths, host, shapes0, buf_i, gidx in source_iter:
             if err:
                 break
             t0 = time.perf_counter()
+            if diag is not None:
+                diag["source"] += t0 - t_src
             slot = k % depth
             slot_free[slot].acquire()
+            if diag is not None:
+                diag["slot_wait"] += time.perf_counter() - t0
             st = streams[slot]
             with torch.cuda.stream(st):
                 if isinstance(host, tuple) and host[0] == "scene":      # scene mode: one upload per scene, tiles cut by the letterbox kernel
@@ -534,6 +553,8 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
             shape_str = f"(1, 3, {H}, {W})"
             t2 = time.perf_counter()
             q.put((ev, counts_h, dets_h, paths, shapes0, (H, W), list(gidx), t2 - t1, slot))
+            if diag is not None:
+                diag["put"] += time.perf_counter() - t2
             n_fed[0] += len(paths)
             while copy_done and (copy_done[0][0].query() or len(copy_done) > depth):
                 ev_, bi_ = copy_done.pop(0)
@@ -547,6 +568,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
             if multi and k % flush_every == 0:         # bounded gather: rows leave the host lists every few batches (collective)
                 with gather_lock:
                     gather.flush(more=True, failed=bool(err))
+            t_src = time.perf_counter()
     except BaseException as e:   # anything the main loop raises (engine, autotune, a decode error, another rank's RankFailed) ends the sweep
         err.append(e)            # HERE, but only after the writers are joined and the other ranks have been told (the collective tail below)
     for _ in wts:
@@ -576,6 +598,9 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
         log(f"Speed: {per(t_pre):.1f}ms pre-process, {per(t_inf):.1f}ms inference, {per(t_post):.1f}ms NMS-out/post-process "
             f"per image at shape {shape_str} (host time per stage; stages overlap)")
         log(f"{seen_all} images, {dets_all} detections, {seen_all / max(elapsed, 1e-9):.1f} images/s on {world} GPU(s) [{precision}]")
+        if diag is not None:
+            log(f"diag (main thread, seconds of {elapsed:.2f}): waiting for the source {diag['source']:.2f}, for a free slot {diag['slot_wait']:.2f}, "
+                f"in q.put {diag['put']:.2f}, pre {t_pre:.2f}, enqueue {t_inf:.2f}; writers' post time summed over threads {t_post:.2f}")
         if t_steady[0] is not None and seen > 4 * batch_size:
             # this rank's rate once the sweep is under way (everything up to the second batch -- header scan, decode worker start-up,
             # tile-configuration timing, pipeline fill -- excluded): what a long sweep converges to

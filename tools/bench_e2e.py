@@ -69,8 +69,8 @@ def main():
     t0 = time.perf_counter()
     r = subprocess.run(cmd, capture_output=True, text=True)
     dt = time.perf_counter() - t0
-    tail = [l for l in r.stdout.splitlines() if l.startswith(("Speed", "Results", "steady", "jpeg decode")) or "images/s" in l or "labels saved" in l]
-    print("\n".join(tail[-5:]))
+    tail = [l for l in r.stdout.splitlines() if l.startswith(("Speed", "Results", "steady", "jpeg decode", "diag")) or "images/s" in l or "labels saved" in l]
+    print("\n".join(tail[-6:]))
     if r.returncode != 0:
         print(r.stderr[-2000:])
     what = f"{a.scenes} scenes ({a.n} 1024px tiles)" if a.scenes else f"{a.n} {a.size}px jpegs"
