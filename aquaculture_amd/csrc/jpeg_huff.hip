@@ -123,7 +123,12 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const unsigned char* __re
             const int comp = blk < 4 ? 0 : blk - 3;
             const int ti = 2 * comp + (k ? 1 : 0);
             const unsigned idx = (unsigned)(acc >> (nbits - 9)) & 511u;
-            const unsigned e = lds_tabs ? s_look[ti][idx] : my[ti].look[idx];
+            // (ALWAYS the LDS read, then the rare override: written as `lds_tabs ? s_look[..] : my[..].look[..]` the compiler selects between the two
+            //  ADDRESSES and emits one flat load with s_waitcnt vmcnt(0) -- a vector-memory round trip per symbol that also drains every
+            //  coefficient store issued so far: 1.9 k cycles per symbol in the first builds)
+            unsigned e = s_look[ti][idx];
+            asm volatile("" : "+v"(e));                          // (opaque: keeps the two loads two instructions)
+            if (!lds_tabs) e = my[ti].look[idx];
             int len, sym;
             if (e) {
                 len = (int)(e >> 8);

@@ -80,6 +80,21 @@ int main(int argc, char** argv) {
             if (rc == AQJ_OK) ++ok; else ++bad;
             const int rs = aq_jpeg_scan(exact, m, &inf2);
             (void)rs;
+            {   /* the GPU path's host preparation on the same bytes: exactly-sized output buffers of varying capacity */
+                static aq_jpeg_stream_info si;
+                const size_t scap = 64 + rnd() % (m + 64);
+                uint8_t* sbuf = (uint8_t*)malloc(scap);
+                const int segcap = 1 + (int)(rnd() % 40);
+                uint32_t* so = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)segcap);
+                uint32_t* sl = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)segcap);
+                const int rp = aq_jpeg_prepare(exact, m, sbuf, scap, so, sl, segcap, &si);
+                if (rp == AQJ_OK) {
+                    if (si.nseg < 1 || si.nseg > segcap || si.stream_bytes > scap) abort();
+                    for (int k = 0; k < si.nseg; ++k)
+                        if ((so[k] & 15) || (size_t)so[k] + sl[k] + 8 > scap) abort();
+                }
+                free(sbuf); free(so); free(sl);
+            }
             free(coef); free(exact); free(buf);
         }
         free(orig);
