@@ -156,7 +156,7 @@ def acc(j, m):
 out = []
 _uid = [0]
 STAMPED = [False]
-OPT = dict(stagger=True, nosilu=False, nomfma=False, nopk=False, nodma=False, nold=False, nost=False, prio=0)      # experiment switches of a kernel variant (main() sets them per kernel)
+OPT = dict(stagger=True, nosilu=False, nomfma=False, nopk=False, nodma=False, nold=False, nost=False, prio=0, ntst=False, ntld=False)      # experiment switches of a kernel variant (main() sets them per kernel)
 PH_PROLOGUE, PH_DMA, PH_B, PH_C_MFMA, PH_C_EPI, PH_BARRIER = range(6)      # (PH_DMA: the vmcnt wait in front of the epilogue)
 
 
@@ -183,6 +183,8 @@ def E(line="", comment=None):
                 b_ = f"s{int(r3.group(1)) + h}"
             out.append(f"\t{op}_e64 v{d + h}, v{a + h}, {b_}")
         return
+    if (OPT["ntst"] and line.startswith("global_store_dwordx2")) or (OPT["ntld"] and line.startswith("global_load_dwordx2")):
+        line += " nt"                      # experiment: streaming hint on the output stores / the shortcut loads (neither is read again by this kernel)
     out.append(("\t" + line if line and not line.endswith(":") else line) + (f"\t; {comment}" if comment else ""))
 
 
@@ -525,7 +527,7 @@ def gen_kernel(name, stamped=False, **opt):
     global out
     out = []
     STAMPED[0] = stamped
-    OPT.update(dict(stagger=True, nosilu=False, nomfma=False, nopk=False, nodma=False, nold=False, nost=False, prio=0))
+    OPT.update(dict(stagger=True, nosilu=False, nomfma=False, nopk=False, nodma=False, nold=False, nost=False, prio=0, ntst=False, ntld=False))
     OPT.update(opt)
     _kernel_no[0] += 1
     _uid[0] = 100000 * _kernel_no[0]
@@ -819,7 +821,9 @@ def main():
                      ("bottleneck_asm_c48_skel_nold", False, dict(nomfma=True, nosilu=True, nold=True)),
                      ("bottleneck_asm_c48_skel_nost", False, dict(nomfma=True, nosilu=True, nost=True)),
                      ("bottleneck_asm_c48_skel_nomem", False, dict(nomfma=True, nosilu=True, nodma=True, nold=True, nost=True)),
-                     ("bottleneck_asm_c48_nomem", False, dict(nodma=True, nold=True, nost=True))]
+                     ("bottleneck_asm_c48_nomem", False, dict(nodma=True, nold=True, nost=True)),
+                     ("bottleneck_asm_c48_ntst", False, dict(ntst=True)), ("bottleneck_asm_c48_ntld", False, dict(ntld=True)),
+                     ("bottleneck_asm_c48_nt", False, dict(ntst=True, ntld=True))]
     for name, stamped, opt in variants:
         text += [f"\t.globl\t{name}", "\t.p2align\t8", f"\t.type\t{name},@function"]
         text += gen_kernel(name, stamped, **opt)

@@ -122,12 +122,12 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const unsigned char* __re
             }
             const int comp = blk < 4 ? 0 : blk - 3;
             const int ti = 2 * comp + (k ? 1 : 0);
-            const unsigned idx = (unsigned)(acc >> (nbits - 9)) & 511u;
-            // (ALWAYS the LDS read, then the rare override: written as `lds_tabs ? s_look[..] : my[..].look[..]` the compiler selects between the two
-            //  ADDRESSES and emits one flat load with s_waitcnt vmcnt(0) -- a vector-memory round trip per symbol that also drains every
-            //  coefficient store issued so far: 1.9 k cycles per symbol in the first builds)
+            // ONE 64-bit shift per symbol: the next 32 bits of the stream, left-aligned; the 9-bit table index, the long codes and the value
+            // bits all come out of this word with 32-bit shifts (a symbol <= 16 bits and its <= 15 value bits fit: nbits >= 33 here)
+            const unsigned top = (unsigned)(acc >> (nbits - 32));
+            const unsigned idx = top >> 23;
             unsigned e = s_look[ti][idx];
-            asm volatile("" : "+v"(e));                          // (opaque: keeps the two loads two instructions)
+            asm volatile("" : "+v"(e));                          // (opaque: keeps the two loads two instructions, see the header)
             if (!lds_tabs) e = my[ti].look[idx];
             int len, sym;
             if (e) {
@@ -136,15 +136,15 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const unsigned char* __re
             } else {                                             // code longer than 9 bits (rare): the canonical-code search of the host decoder
                 const JpegGpuTab* t = my + ti;
                 len = 10;
-                int code = (int)((acc >> (nbits - 10)) & 1023u);
-                while (len <= 16 && code > t->maxcode[len]) { ++len; code = (int)((acc >> (nbits - len)) & ((1u << len) - 1u)); }
+                int code = (int)(top >> 22);
+                while (len <= 16 && code > t->maxcode[len]) { ++len; code = (int)(top >> (32 - len)); }
                 if (len > 16) { st = 2; active = false; continue; }
                 sym = t->vals[(code + t->valoff[len]) & 0xff];
             }
-            nbits -= len;
             const int r = k ? sym >> 4 : 0;
             const int s = k ? sym & 15 : sym;
             if (k == 0 && s > 11) { st = 2; active = false; continue; }
+            nbits -= len + s;                                    // (s = 0 for EOB / ZRL / a zero DC difference)
             if (k != 0 && s == 0) {
                 if (r == 15) k += 16;                            // ZRL
                 else k = 64;                                     // EOB
@@ -152,9 +152,8 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const unsigned char* __re
                 k += r;
                 if (k > 63) { st = 2; active = false; continue; }
                 int v = 0;
-                if (s) {                                         // (a symbol <= 16 bits and its <= 15 value bits fit the >= 33 bits a refill leaves)
-                    v = (int)((acc >> (nbits - s)) & ((1u << s) - 1u));
-                    nbits -= s;
+                if (s) {
+                    v = (int)((top << len) >> (32 - s));
                     if (v < (1 << (s - 1))) v += 1 - (1 << s);
                 }
                 if (k == 0) {

@@ -11,13 +11,13 @@ timeout -k 10 1000 python tools/profile_pmc.py --out "$OUT/pmc" > "$OUT/pmc.log"
 cp "$OUT/pmc/hbm_traffic.json" profiles/hbm_traffic_latest.json 2>/dev/null      # so that the bench lines below carry `traffic`
 rm -f "$OUT/e2e_latest.json"
 for sz in 640 1024; do
-    for jd in split host; do
-        n=$([ "$sz" = 640 ] && echo 24576 || echo 8192)
+    for jd in split gpu host; do
+        n=$([ "$sz" = 640 ] && echo 24576 || echo 16384)
         timeout -k 10 300 python tools/bench_e2e.py --size "$sz" --n "$n" --workers 14 --precision bf16 --jpeg-decode "$jd" --json "$OUT/e2e_latest.json" 2>&1 | grep -E "steady"
     done
 done
-for jd in split host; do
-    timeout -k 10 300 python tools/bench_e2e.py --size 1024 --n 8192 --workers 14 --precision bf16 --jpeg-decode "$jd" --noise 10 --json "$OUT/e2e_latest.json" 2>&1 | grep -E "steady"
+for jd in split gpu host; do
+    timeout -k 10 300 python tools/bench_e2e.py --size 1024 --n 16384 --workers 14 --precision bf16 --jpeg-decode "$jd" --noise 10 --json "$OUT/e2e_latest.json" 2>&1 | grep -E "steady"
 done
 timeout -k 10 300 python tools/bench_e2e.py --scenes 200 --workers 14 --precision bf16 --json "$OUT/e2e_latest.json" 2>&1 | grep -E "steady"
 cp "$OUT/e2e_latest.json" profiles/e2e_latest.json 2>/dev/null                   # ... and `e2e`

@@ -90,7 +90,7 @@ def op_patterns(o, spec):
     if o.kind == spec.OP_DOWNBLOCK:
         return ("downblock_kernel",)
     if o.kind == spec.OP_BOTTLENECK:
-        return ("bottleneck_kernel",)
+        return ("bottleneck_kernel", "bottleneck_asm")
     if o.kind == spec.OP_SPPF_POOL:
         return ("sppf_pool",)
     if o.kind == spec.OP_UPSAMPLE2X:
