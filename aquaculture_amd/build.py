@@ -26,6 +26,7 @@ SOURCES = [
     ("bottleneck.hip", []),
     ("downblock.hip", []),
     ("conv1x1_direct.hip", []),
+    ("conv1x1_asm.hip", []),                     # host side of the generated-assembly wide 1x1 (gen_conv1x1_asm.py; round 4)
     ("conv3x3_pl.hip", []),
     ("pointwise.hip", []),
     ("detect_nms.hip", ["-ffp-contract=off"]),   # bit-level parity with the oracle's fp32 op order
@@ -77,10 +78,10 @@ def llvm_bin(cc: str) -> str:
 
 def _assemble_planar(verbose: bool, cc: str) -> None:
     """The hand-scheduled assembly kernels: generate each .s (gen_conv3x3_pl_asm.py: the planar 3x3 families; gen_bottleneck_asm.py: the fused
-    C = 48 Bottleneck), assemble and link it into a gfx950 code object with the ROCm clang / lld, and write it as a byte list that the
+    C = 48 Bottleneck; gen_conv1x1_asm.py: the wide 1x1), assemble and link it into a gfx950 code object with the ROCm clang / lld, and write it as a byte list that the
     .hip file of the same family embeds (hipModuleLoadData)."""
     llvm = llvm_bin(cc)
-    for gen, stem in (("gen_conv3x3_pl_asm.py", "conv3x3_pl_asm"), ("gen_bottleneck_asm.py", "bottleneck_asm")):
+    for gen, stem in (("gen_conv3x3_pl_asm.py", "conv3x3_pl_asm"), ("gen_bottleneck_asm.py", "bottleneck_asm"), ("gen_conv1x1_asm.py", "conv1x1_asm")):
         src, obj, co = (os.path.join(CSRC, stem + ext) for ext in (".s", ".o", ".hsaco"))
         cmds = [[sys.executable, os.path.join(CSRC, gen), src],
                 [os.path.join(llvm, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-c", src, "-o", obj],

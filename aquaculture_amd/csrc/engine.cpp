@@ -65,7 +65,7 @@ struct PackedW {
     int kgroups = 0, kgroups_pad = 0, G = 0, cout_rows = 0;
     bool x3 = false;            // AQ_F16X3 engine: this conv runs in split mode (weights as fp16 hi / lo halves; bias = [bias 2^s | 2^-s])
     void* w_direct = nullptr;   // layers a direct kernel supports: its A-fragment image (csrc/conv1x1_direct.hip, csrc/downblock.hip)
-    int direct_cfg = -1;        // AQ_CONV_CFG_DIRECT1X1 / AQ_CONV_CFG_DIRECT3X3S2 / AQ_CONV_CFG_PL3X3 / AQ_CONV_CFG_PL3X3S2
+    int direct_cfg = -1;        // AQ_CONV_CFG_DIRECT1X1 / AQ_CONV_CFG_DIRECT3X3S2 / AQ_CONV_CFG_PL3X3 / AQ_CONV_CFG_PL3X3S2 / AQ_CONV_CFG_ASM1X1
     void* w_head = nullptr;     // bf16 engines, Detect head convs with a small head: aq_pack_head_weights image (csrc/head_decode.hip)
     void* w_pl8 = nullptr;      // AQ_BF16_W8 engines, planar 3x3 layers: the e4m3 code stream and its float[2048] bias x 2^-e | 2^e
     float* sb_pl8 = nullptr;
@@ -336,6 +336,13 @@ int run_conv(aq_engine* e, int oi, void* ws, const uint8_t* tiles, int B, hipStr
         return aq_conv1x1_direct(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
                                  tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
                                  op.src.channels, op.dst.channels, pw.w_direct, pw.bias, (long long)B * pd.h * pd.w, op.act, stream);
+    }
+    if (cfg == AQ_CONV_CFG_ASM1X1) {
+        if (pw.direct_cfg != cfg) { aq_set_error("conv op %d has no assembly 1x1 form", oi); return AQ_ERR_INVALID; }
+        note_launch(e, oi, AQ_FAM_ASM1X1, cfg);
+        return aq_conv1x1_asm(tptr(e, ws, tiles, op.src.tensor), e->tensors[op.src.tensor].channels, op.src.ch_off,
+                              tptr(e, ws, tiles, op.dst.tensor), e->tensors[op.dst.tensor].channels, op.dst.ch_off,
+                              op.src.channels, op.dst.channels, pw.w_direct, pw.bias, (long long)B * pd.h * pd.w, op.act, stream);
     }
     if (cfg < 0) cfg = aq_conv_pick_config(p.cout, p.npix, prec);
     if (pw.x3) p.x3_off = pw.cout_rows;
@@ -714,6 +721,18 @@ extern "C" int aq_engine_create(const aq_model_desc* d, int device, aq_engine** 
                 return fail(AQ_ERR_HIP);
             }
             pw.direct_cfg = AQ_CONV_CFG_DIRECT1X1;
+        }
+        if (d->precision == AQ_BF16 && op.k == 1 && op.stride == 1 && op.res.tensor < 0 && op.act == 1 && e->tensors[op.dst.tensor].dtype == AQ_T_ACT &&
+            pw.direct_cfg < 0 && op.src.ch_off % 8 == 0 && e->tensors[op.src.tensor].channels % 8 == 0 && op.dst.ch_off % 4 == 0 &&
+            e->tensors[op.dst.tensor].channels % 4 == 0 && aq_conv1x1_asm_supported(op.src.channels, op.dst.channels)) {
+            size_t nb = 0;
+            if (aq_pack_conv1x1_asm(op.weight, op.src.channels, op.dst.channels, nullptr, &nb, nullptr) != AQ_OK ||
+                hipMalloc(&pw.w_direct, nb) != hipSuccess ||
+                aq_pack_conv1x1_asm(op.weight, op.src.channels, op.dst.channels, pw.w_direct, &nb, nullptr) != AQ_OK) {
+                aq_set_error("engine_create: assembly 1x1 weight upload failed (op %zu)", oi);
+                return fail(AQ_ERR_HIP);
+            }
+            pw.direct_cfg = AQ_CONV_CFG_ASM1X1;
         }
         if (d->precision == AQ_BF16 && op.k == 3 && op.stride == 2 && op.pad == 1 && op.res.tensor < 0 && e->tensors[op.dst.tensor].dtype == AQ_T_ACT &&
             aq_conv3x3s2_direct_supported(op.src.channels, op.dst.channels)) {

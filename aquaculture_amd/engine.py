@@ -67,7 +67,7 @@ EXPORTS = (
     "aq_engine_infer", "aq_engine_forward_raw", "aq_engine_tensor_ptr", "aq_engine_profile",
     "aq_engine_op_times", "aq_engine_num_ops", "aq_engine_set_conv_config", "aq_engine_autotune", "aq_engine_set_tuned_table",
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
-    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_pack_conv_weights_x3", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_stemdown_supported", "aq_stemdown", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct",
+    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_pack_conv_weights_x3", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_stemdown_supported", "aq_stemdown", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct", "aq_conv1x1_asm_supported", "aq_pack_conv1x1_asm", "aq_conv1x1_asm",
     "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct",
     "aq_conv3x3_pl_supported", "aq_conv3x3_pl_asm_family", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_s2_supported", "aq_pack_conv3x3_pl_s2", "aq_conv3x3_pl_s2", "aq_jpeg_scratch_bytes", "aq_jpeg_idct_rgb", "aq_f32_to_e4m3", "aq_conv1x1_direct_f8out", "aq_absmax_bf16", "aq_engine_calibrate_amax", "aq_engine_set_fp8_scales", "aq_engine_last_launch", "aq_conv3x3_pl_f8_supported", "aq_pack_conv3x3_pl_f8", "aq_conv3x3_pl_f8", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_letterbox_tiles_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms", "aq_jpeg_huffman_decode", "aq_write_label_files",
@@ -127,6 +127,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_conv1x1_direct_supported.argtypes = [i32, i32]
     lib.aq_pack_conv1x1_direct.argtypes = [C.POINTER(f32), i32, i32, vp, C.POINTER(sz), vp]
     lib.aq_conv1x1_direct.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, C.c_longlong, i32, vp]
+    lib.aq_conv1x1_asm_supported.argtypes = [i32, i32]
+    lib.aq_pack_conv1x1_asm.argtypes = [C.POINTER(f32), i32, i32, vp, C.POINTER(sz), vp]
+    lib.aq_conv1x1_asm.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, C.c_longlong, i32, vp]
     lib.aq_conv3x3s2_direct_supported.argtypes = [i32, i32]
     lib.aq_pack_conv3x3s2_direct.argtypes = [C.POINTER(f32), i32, i32, vp, C.POINTER(sz), vp]
     lib.aq_conv3x3s2_direct.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp]
@@ -445,7 +448,7 @@ class Engine:
         return cfgs
 
     FAMILIES = {0: "none", 1: "igemm_or_halo", 2: "pl3x3", 3: "pl3x3_w8", 4: "pl3x3s2", 5: "pl3x3_f8", 6: "direct1x1", 7: "direct1x1_f8out",
-                8: "direct3x3s2", 9: "bottleneck", 10: "downblock", 11: "stem", 12: "head_decode"}
+                8: "direct3x3s2", 9: "bottleneck", 10: "downblock", 11: "stem", 12: "head_decode", 13: "asm1x1"}
 
     def last_launches(self) -> List[Tuple[str, int]]:
         """(kernel family, tile-configuration id) of every op's most recent launch (aq_engine_last_launch) -- what actually ran, as opposed
@@ -719,6 +722,7 @@ def downblock_nhwc(x: torch.Tensor, wa_oihw: torch.Tensor, ba: torch.Tensor, wb_
 
 
 CONV_CFG_DIRECT1X1 = 1000   # AQ_CONV_CFG_DIRECT1X1
+CONV_CFG_ASM1X1 = 1004      # AQ_CONV_CFG_ASM1X1
 CONV_CFG_DIRECT3X3S2 = 1001  # AQ_CONV_CFG_DIRECT3X3S2
 CONV_CFG_PL3X3 = 1002       # AQ_CONV_CFG_PL3X3
 CONV_CFG_PL3X3S2 = 1003     # AQ_CONV_CFG_PL3X3S2
@@ -783,6 +787,29 @@ def conv1x1_direct_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tenso
         out = torch.empty(x.shape[:-1] + (cout,), dtype=torch.bfloat16, device=x.device)
     _check(lib.aq_conv1x1_direct(x.data_ptr(), ld, 0, out.data_ptr(), out.stride(-2), 0, cin, cout, wbuf.data_ptr(), bbuf.data_ptr(), npix, int(act),
                                  _stream_ptr()))
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
+def conv1x1_asm_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 [..., cin] pixels (may be a channel slice of a wider dense tensor) -> SiLU(W x + b) through aq_conv1x1_asm, the generated-assembly
+    wide 1x1 (tests, tools/time_conv1x1_asm.py)."""
+    _require_gpu()
+    lib = load_library()
+    assert x.dtype == torch.bfloat16 and x.stride(-1) == 1
+    cin, cout = x.shape[-1], w_oihw.shape[0]
+    ld = x.stride(-2)
+    npix = x.numel() // cin
+    w = np.ascontiguousarray(w_oihw.reshape(cout, cin).float().cpu().numpy())
+    n = C.c_size_t()
+    wp = w.ctypes.data_as(C.POINTER(C.c_float))
+    _check(lib.aq_pack_conv1x1_asm(wp, cin, cout, None, C.byref(n), None))
+    wbuf = torch.empty(n.value, dtype=torch.uint8, device=x.device)
+    _check(lib.aq_pack_conv1x1_asm(wp, cin, cout, wbuf.data_ptr(), C.byref(n), _stream_ptr()))
+    bbuf = bias.float().to(x.device).contiguous()
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (cout,), dtype=torch.bfloat16, device=x.device)
+    _check(lib.aq_conv1x1_asm(x.data_ptr(), ld, 0, out.data_ptr(), out.stride(-2), 0, cin, cout, wbuf.data_ptr(), bbuf.data_ptr(), npix, 1, _stream_ptr()))
     torch.cuda.current_stream().synchronize()
     return out
 

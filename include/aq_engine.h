@@ -153,7 +153,8 @@ enum {
     AQ_FAM_BOTTLENECK = 9,
     AQ_FAM_DOWNBLOCK = 10,
     AQ_FAM_STEM = 11,
-    AQ_FAM_HEAD_DECODE = 12
+    AQ_FAM_HEAD_DECODE = 12,
+    AQ_FAM_ASM1X1 = 13             /* wide 1x1 in generated assembly (conv1x1_asm_nb13) */
 };
 int aq_engine_last_launch(aq_engine* e, int op, int* family, int* cfg);
 /* Install a table that aq_engine_autotune produced earlier (or on another rank) for the SAME engine and (B,H,W): cfgs[n_ops], one id per
@@ -232,6 +233,16 @@ int aq_conv1x1_direct_supported(int cin, int cout);
 int aq_pack_conv1x1_direct(const float* w_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream);
 int aq_conv1x1_direct(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff, int cin, int cout,
                       const void* packed_w_dev, const float* bias_dev, long long npix, int act, void* stream);
+
+/* Wide 1x1 convolution in generated gfx950 assembly (bf16, SiLU; Cin a multiple of 96, Cout in {384, 768, 1536}: yolov5m's K >= 768 1x1 layers --
+ * C3 cv1|cv2 / cv3 at 20x20, SPPF cv1 / cv2, model.10, model.13 cv1|cv2).  208-pixel x 384-channel tiles, eight waves, weights streamed from L2
+ * to registers, pixels by buffer-descriptor LDS-DMA in 96-channel chunks (csrc/gen_conv1x1_asm.py).  Same operation as aq_conv2d with k = 1,
+ * act = 1; autotuner candidate AQ_CONV_CFG_ASM1X1.  npix: pixels (B x H x W); in / out may be channel slices of wider tensors. */
+#define AQ_CONV_CFG_ASM1X1 1004
+int aq_conv1x1_asm_supported(int cin, int cout);
+int aq_pack_conv1x1_asm(const float* w_host, int cin, int cout, void* packed_dev, size_t* bytes, void* stream);
+int aq_conv1x1_asm(const void* in_dev, int in_ld, int in_choff, void* out_dev, int out_ld, int out_choff, int cin, int cout,
+                   const void* packed_w_dev, const float* bias_dev, long long npix, int act, void* stream);
 
 /* Direct 3x3 / stride 2 / pad 1 convolution (bf16; 96 -> 192 channels: yolov5m's model.3), the plain form of the down-block kernel:
  * input patches by LDS-DMA, weights in registers (last k-steps in LDS), each input-row fragment loaded once for the output rows it

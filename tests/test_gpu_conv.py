@@ -296,6 +296,27 @@ def test_direct_conv1x1_matches_reference(lib, cin, cout, npix_shape):
         torch.testing.assert_close(got, ref.bfloat16().float(), rtol=2 ** -7, atol=2e-3)
 
 
+@pytest.mark.parametrize("cin,cout", [(768, 768), (768, 384), (1536, 768), (96, 384), (384, 1536)])
+@pytest.mark.parametrize("npix_shape", [(1, 5, 7), (1, 13, 16), (2, 37, 41), (16, 40, 40)])
+def test_asm_conv1x1_matches_reference(lib, cin, cout, npix_shape):
+    """aq_conv1x1_asm (generated assembly, 208-pixel x 384-channel tiles) vs F.conv2d on bf16-rounded operands: K = 96 (one chunk) .. 1536,
+    one / two / four channel tiles; input and output are channel slices of wider tensors; pixel counts: less than one tile, exactly one
+    tile, ragged multi-tile, more tiles than CUs (several tiles per workgroup: the loads run ahead across tile boundaries)."""
+    from aquaculture_amd import engine
+    B, H, W = npix_shape
+    g = torch.Generator().manual_seed(cin + H)
+    xw = (torch.randn(B, H, W, cin + 16, generator=g) * 0.8).bfloat16().cuda()
+    x = xw[..., 8:8 + cin]
+    w = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.2
+    outw = torch.full((B, H, W, cout + 8), 7.0, dtype=torch.bfloat16, device="cuda")
+    engine.conv1x1_asm_nhwc(x, w, b, out=outw[..., 4:4 + cout])
+    ref = F.silu(F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.bfloat16().float(), b)).permute(0, 2, 3, 1)
+    got = outw[..., 4:4 + cout].float().cpu()
+    assert (outw[..., :4] == 7.0).all() and (outw[..., 4 + cout:] == 7.0).all()
+    torch.testing.assert_close(got, ref.bfloat16().float(), rtol=2 ** -7, atol=2e-3)
+
+
 def test_direct_conv1x1_in_engine(lib, synth_ck):
     """Forcing the direct kernel on every 1x1 layer it supports leaves the head outputs within bf16 noise of the default engine."""
     from aquaculture_amd import engine, tiles
