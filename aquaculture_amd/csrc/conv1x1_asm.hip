@@ -8,7 +8,8 @@ using namespace aqdev;
 
 namespace {
 
-constexpr int kTPX = 208, kNT = 384, kKC = 96;          // pixels / output channels per tile, input channels per chunk (gen_conv1x1_asm.py TPX, NT, 32 KS)
+constexpr int kNT = 384, kKC = 96;                      // output channels per tile, input channels per chunk (gen_conv1x1_asm.py NT, 32 KS)
+constexpr int kTPX[2] = {208, 112};                     // pixels per tile of the two families (nb13, nb7)
 constexpr int kStepB = 3 * 1024;                        // weight bytes per (wave, k-step): three 1 KB A fragments
 constexpr int kMaxCout = 1536;
 
@@ -26,15 +27,17 @@ const unsigned char kC1AsmCode[] = {
 #include "conv1x1_asm_hsaco.inc"
 };
 hipModule_t g_c1a_mod[64];
-hipFunction_t g_c1a_fn[64][2];               // plain, stamped
+hipFunction_t g_c1a_fn[64][2][2];            // [family nb13 / nb7][plain, stamped]
 int g_c1a_cus = 0;
 
 int c1a_load(int dev) {
     if (g_c1a_mod[dev]) return AQ_OK;
     hipModule_t mod = nullptr;
     AQ_CHECK_HIP(hipModuleLoadData(&mod, kC1AsmCode));
-    AQ_CHECK_HIP(hipModuleGetFunction(&g_c1a_fn[dev][0], mod, "conv1x1_asm_nb13"));
-    AQ_CHECK_HIP(hipModuleGetFunction(&g_c1a_fn[dev][1], mod, "conv1x1_asm_nb13_stamped"));
+    AQ_CHECK_HIP(hipModuleGetFunction(&g_c1a_fn[dev][0][0], mod, "conv1x1_asm_nb13"));
+    AQ_CHECK_HIP(hipModuleGetFunction(&g_c1a_fn[dev][0][1], mod, "conv1x1_asm_nb13_stamped"));
+    AQ_CHECK_HIP(hipModuleGetFunction(&g_c1a_fn[dev][1][0], mod, "conv1x1_asm_nb7"));
+    AQ_CHECK_HIP(hipModuleGetFunction(&g_c1a_fn[dev][1][1], mod, "conv1x1_asm_nb7_stamped"));
     g_c1a_mod[dev] = mod;
     return AQ_OK;
 }
@@ -115,7 +118,19 @@ extern "C" int aq_conv1x1_asm(const void* in_dev, int in_ld, int in_choff, void*
     a.nchunks = cin / kKC;
     const int nct = cout / kNT;
     a.nct_log2 = nct == 1 ? 0 : nct == 2 ? 1 : 2;
-    const long long ptiles = (npix + kTPX - 1) / kTPX;
+    // Family: 208-pixel tiles unless their grid leaves the CUs half idle and the 112-pixel tiles (twice the weight bytes per MFMA: about 15 % more
+    // time per pixel) finish in fewer tile-heights: 768 -> 384 at 20x20, batch 64 = 124 tiles of 208 pixels, 229 of 112.  AQ_C1_ASM_NB=13 / 7 forces one.
+    int fam = 0;
+    {
+        const long long t13 = (npix + kTPX[0] - 1) / kTPX[0] * nct, t7 = (npix + kTPX[1] - 1) / kTPX[1] * nct;
+        const double c13 = (double)((t13 + g_c1a_cus - 1) / g_c1a_cus) * 13.0, c7 = (double)((t7 + g_c1a_cus - 1) / g_c1a_cus) * 7.0 * 1.15;
+        if (c7 < c13) fam = 1;
+        const char* fe = getenv("AQ_C1_ASM_NB");          // (read per call: tests and tools/time_conv1x1_asm.py switch it)
+        const int forced = fe ? atoi(fe) : 0;
+        if (forced == 13) fam = 0;
+        if (forced == 7) fam = 1;
+    }
+    const long long ptiles = (npix + kTPX[fam] - 1) / kTPX[fam];
     a.ntiles = (int)(ptiles * nct);
     long long grid = g_c1a_cus;
     if (grid > a.ntiles) grid = a.ntiles;
@@ -129,7 +144,7 @@ extern "C" int aq_conv1x1_asm(const void* in_dev, int in_ld, int in_choff, void*
     size_t sbytes = 0;
     unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
     if (sbuf && (size_t)grid * 8 * 64 <= sbytes) { a.debug = sbuf; which = 1; }
-    hipFunction_t fn = g_c1a_fn[dev][which];
+    hipFunction_t fn = g_c1a_fn[dev][fam][which];
     const char* exp_kernel = getenv("AQ_C1_ASM_KERNEL");       // timing experiments: another kernel of the code object, by name (tools/time_conv1x1.py)
     if (exp_kernel && *exp_kernel) {
         char name[96];

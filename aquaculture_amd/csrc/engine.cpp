@@ -26,7 +26,7 @@ void aq_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* aq_last_error(void) { return g_err; }
-extern "C" int aq_version(void) { return 6; }   // 6: planar 3x3/s2 and fp8 families, AQ_F16X3, fp8 pairs; 5: AQ_BF16_W8, aq_conv3x3_pl_w8; 2: fused stem / Bottleneck / down-block ops, direct 1x1 and 3x3/s2 candidates; 3: one-tile-per-workgroup grids
+extern "C" int aq_version(void) { return 7; }   // 7: generated-assembly wide 1x1 (AQ_CONV_CFG_ASM1X1), assembly C = 48 Bottleneck; 6: planar 3x3/s2 and fp8 families, AQ_F16X3, fp8 pairs; 5: AQ_BF16_W8, aq_conv3x3_pl_w8; 2: fused stem / Bottleneck / down-block ops, direct 1x1 and 3x3/s2 candidates; 3: one-tile-per-workgroup grids
 
 namespace {
 

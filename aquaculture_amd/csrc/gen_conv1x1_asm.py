@@ -34,32 +34,50 @@ Usage: python gen_conv1x1_asm.py OUT.s   (aquaculture_amd/build.py assembles it 
 import os
 import sys
 
-NB = 13                      # pixel blocks per tile
-TPX = 16 * NB
 NW = 8                       # waves
 MB = 3                       # M blocks per wave
 NT = 16 * MB * NW            # output channels per tile (384)
 KS = 3                       # k-steps (32 channels) per chunk
-HP = NB * 1024               # one k-step's plane of a chunk
-CH = KS * HP                 # one chunk buffer
 RING = 3
 MAX_COUT = 1536
 BIAS_OFF = 0                 # the layer's biases (floats), then the ring (DS instruction offsets are 16 bits: the biases go first)
 RB0 = 4 * MAX_COUT
-LDS_BYTES = RB0 + RING * CH
-NE = KS * NB                 # (k-step, pixel block) elements per chunk
 PD = 4                       # B fragments read ahead
-BAR_AT = NE - PD - 1
-NDMA = 5                     # LDS-DMA instructions per wave and chunk (39 = 8 x 5 - 1: wave 7 repeats its fourth)
 STEP_B = MB * 1024           # weight bytes per (wave, k-step)
-assert NE == 39 and NW * NDMA >= NE and PD == 4
-
-# B-fragment ring.  The body repeats every NE = 39 elements and a fragment is live for PD + 1 = 5 of them, so the slot of element e must be
-# periodic in 39 with any five consecutive elements in different slots: 39 is not a multiple of 5, six slots in runs of 6, 6, 6, 6, 5, 5, 5 do it
-# (a window of five spans at most two runs: the tail t of one -- slots len - t .. len - 1 -- and the first 5 - t slots of the next; len >= 5).
-SLOT = [k for run in (6, 6, 6, 6, 5, 5, 5) for k in range(run)]
 NSLOT = 6
-assert len(SLOT) == 39 and all(len({SLOT[(e + d) % 39] for d in range(5)}) == 5 for e in range(39))
+MAX_NDMA = 5
+# Tile heights.  nb13: 208 pixels -- 25,600 pixels x 768 channels = 248 tiles, one round of 256 CUs.  nb7: 112 pixels, for the layers whose nb13
+# grid would leave half the CUs idle (768 -> 384 at 20x20: 124 tiles of 208 pixels, 229 of 112); twice the weight bytes per MFMA.
+# B-fragment ring: the body repeats every NE elements and a fragment is live for PD + 1 = 5 of them, so the slot of element e must be periodic
+# in NE with any five consecutive elements in different slots: NE = 39 / 21 are not multiples of 5; six slots in runs of 6 and 5 do it (a window
+# of five spans at most two runs: the tail t of one -- slots len - t .. len - 1 -- and the first 5 - t slots of the next; len >= 5).
+RUNS = {13: (6, 6, 6, 6, 5, 5, 5), 7: (6, 5, 5, 5)}
+
+
+def configure(nb):
+    """Sets the tile constants of one family and allocates its vector registers."""
+    g = globals()
+    g["NB"] = nb
+    g["TPX"] = 16 * nb
+    g["HP"] = nb * 1024               # one k-step's plane of a chunk
+    g["CH"] = KS * HP                 # one chunk buffer
+    g["LDS_BYTES"] = RB0 + RING * CH
+    g["NE"] = KS * nb                 # (k-step, pixel block) elements per chunk
+    g["BAR_AT"] = NE - PD - 1
+    g["NDMA"] = (NE + NW - 1) // NW   # LDS-DMA instructions per wave and chunk (a wave whose last index is past NE repeats its previous one)
+    g["SLOT"] = [k for run in RUNS[nb] for k in range(run)]
+    assert PD == 4 and NDMA <= MAX_NDMA and NW * (NDMA - 1) < NE <= NW * NDMA
+    assert len(SLOT) == NE and all(len({SLOT[(e + d) % NE] for d in range(PD + 1)}) == PD + 1 for e in range(NE))
+    V = Regs("v", 256)
+    g["V"] = V
+    V.alloc("tid")
+    V.alloc("ACC", 4 * MB * nb, 4)
+    V.alloc("A", 4 * MB * 3, 4)
+    V.alloc("BR", 4 * NSLOT, 4)
+    V.alloc("T", 12, 4)
+    for nm in ("vlrd", "vrd", "vrdn", "vwl", "vdl", "vol1", "vol2", "vbl1", "vbl2", "va0", "va1"):
+        V.alloc(nm)
+    V.alloc("vdt", MAX_NDMA)
 
 
 ARG = dict(inp=0, out=8, w=16, bias=24, in_ld=32, out_ld=36, npix=40, nchunks=44, ntiles=48, nct_log2=52, G=56, in_bytes=60,
@@ -82,7 +100,6 @@ class Regs:
         return base
 
 
-V = Regs("v", 256)
 S = Regs("s", 100)
 
 S.alloc("karg", 2)
@@ -102,22 +119,14 @@ for nm in ("wave", "tmp0", "tmp1", "tmp2", "tmp3", "tmp4", "tmp5", "wstream",
            "c_wb", "c_px0", "c_ct", "c_ok", "c_last",                              # stage C: the chunk the MFMAs run on
            "dbuf", "rbufn", "orow", "boff", "oguard", "after_epi"):
     S.alloc(nm)
-S.alloc("dsrc", NDMA)
-S.alloc("dlds", NDMA)
+S.alloc("dsrc", MAX_NDMA)
+S.alloc("dlds", MAX_NDMA)
 S.alloc("klog2e2", 2, 2)
 S.alloc("kone2", 2, 2)
 S.alloc("t64", 2, 2)
 S.alloc("st_last", 2, 2)
 S.alloc("st_acc", 2 * NPH, 2)
 
-V.alloc("tid")
-V.alloc("ACC", 4 * MB * NB, 4)
-V.alloc("A", 4 * MB * 3, 4)
-V.alloc("BR", 4 * NSLOT, 4)
-V.alloc("T", 12, 4)
-for nm in ("vlrd", "vrd", "vrdn", "vwl", "vdl", "vol1", "vol2", "vbl1", "vbl2", "va0", "va1"):
-    V.alloc(nm)
-V.alloc("vdt", NDMA)
 
 
 def s(name, i=0):
@@ -273,13 +282,13 @@ def emit_body():
         ks, j = divmod(e, NB)
         if j == 0:
             # weights two k-steps ahead; then this k-step's set must have landed.  Vector-memory operations return in order; issued behind the
-            # awaited loads: k-step 0: 3 + 3; k-step 1: 3 + 5 (LDS-DMA) + 3; k-step 2: 5 + 3 + 3.  After an epilogue its 2 NB stores sit in
+            # awaited loads: k-step 0: 3 + 3; k-step 1: 3 + NDMA (LDS-DMA) + 3; k-step 2: NDMA + 3 + 3.  After an epilogue its 2 NB stores sit in
             # between: the same waits with + 2 NB, or they would wait for the stores to be written
             if ks == 0:
                 emit_wloads(2, "c_wb", 2 * STEP_B)
             else:
                 emit_wloads(ks - 1, "n_wb", (ks - 1) * STEP_B)
-            n = 6 if ks == 0 else 11
+            n = 6 if ks == 0 else 6 + NDMA
             if ks < 2:
                 late, join = uid("late"), uid("join")
                 E(f"s_cmp_eq_u32 {s('after_epi')}, 1")
@@ -298,15 +307,15 @@ def emit_body():
         for m in range(MB):
             E(f"v_mfma_f32_16x16x32_bf16 {acc(m, j)}, {afrag(ks, m)}, {bfrag(e)}, {acc(m, j)}")
         if e == BAR_AT:
-            # stage N's pixels: this wave's part was issued one body ago; behind it 3 + 3, then this body's 3 + 5 + 3 + 3 (+ the stores)
+            # stage N's pixels: this wave's part was issued one body ago; behind it 3 + 3, then this body's 3 + NDMA + 3 + 3 (+ the stores)
             stamp(PH_STREAM)
             late, join = uid("late"), uid("join")
             E(f"s_cmp_eq_u32 {s('after_epi')}, 1")
             E(f"s_cbranch_scc1 {late}")
-            E("s_waitcnt vmcnt(20)")
+            E(f"s_waitcnt vmcnt({15 + NDMA})")
             E(f"s_branch {join}")
             label(late)
-            E(f"s_waitcnt vmcnt({20 + 2 * NB})")
+            E(f"s_waitcnt vmcnt({15 + NDMA + 2 * NB})")
             label(join)
             E("s_barrier")
             stamp(PH_BARRIER)
@@ -377,16 +386,17 @@ def emit_acc_init(ct):
 _kernel_no = [0]
 
 
-def gen_kernel(name, stamped=False, **opt):
+def gen_kernel(name, nb, stamped=False, **opt):
     global out
     out = []
+    configure(nb)
     STAMPED[0] = stamped
     for k in OPT:
         OPT[k] = False
     OPT.update(opt)
     _kernel_no[0] += 1
     _uid[0] = 100000 * _kernel_no[0]
-    E("; wide 1x1 convolution, 208 pixels x 384 channels per tile, 8 waves: generated by gen_conv1x1_asm.py -- do not edit")
+    E(f"; wide 1x1 convolution, {TPX} pixels x {NT} channels per tile, 8 waves: generated by gen_conv1x1_asm.py -- do not edit")
     label(name)
     a0 = S.names["inp"][0]
     b0 = S.names["in_ld"][0]
@@ -449,10 +459,10 @@ def gen_kernel(name, stamped=False, **opt):
     E(f"v_lshlrev_b32 {v('vbl1')}, 5, v{g}")
     E(f"v_lshlrev_b32 {v('vbl2')}, 4, v{g}")
     E(f"v_add_u32 {v('vbl2')}, 128, {v('vbl2')}")
-    # this wave's LDS-DMA instructions: i = wave + 8 n (39 -> 31); k-step i / 13, pixel block i % 13
+    # this wave's LDS-DMA instructions: i = wave + 8 n (past the chunk's NE: the wave's previous one again); k-step i / NB, pixel block i % NB
     for n in range(NDMA):
         E(f"s_add_u32 {s('tmp0')}, {s('wave')}, {8 * n}")
-        if 8 * n + 7 >= NE:
+        if NW * n + NW - 1 >= NE:
             E(f"s_cmp_ge_u32 {s('tmp0')}, {NE}")
             E(f"s_cselect_b32 {s('tmp1')}, 8, 0")
             E(f"s_sub_u32 {s('tmp0')}, {s('tmp0')}, {s('tmp1')}")
@@ -470,18 +480,6 @@ def gen_kernel(name, stamped=False, **opt):
         E(f"s_mul_i32 {s('tmp3')}, {s('tmp3')}, {s('in_ld')}")
         E(f"s_lshl_b32 {s('tmp4')}, {s('tmp1')}, 6")
         E(f"s_add_u32 {s('dsrc', n)}, {s('tmp3')}, {s('tmp4')}")
-    # ---- the biases -> LDS (all `cout` floats; 64 lanes x 16 bytes per instruction) ----
-    E(f"v_lshlrev_b32 v{T[3]}, 4, {v('tid')}")
-    E(f"s_lshl_b32 {s('tmp0')}, {s('cout')}, 2")
-    E(f"v_cmp_gt_u32 vcc, {s('tmp0')}, v{T[3]}")
-    nb = uid("nobias")
-    E(f"s_and_saveexec_b64 {s2('t64')}, vcc")
-    E(f"s_cbranch_execz {nb}")
-    E(f"global_load_dwordx4 v[{T[4]}:{T[7]}], v{T[3]}, {s2('bias')}")
-    E("s_waitcnt vmcnt(0)")
-    E(f"ds_write_b128 v{T[3]}, v[{T[4]}:{T[7]}] offset:{BIAS_OFF}")
-    label(nb)
-    E(f"s_mov_b64 exec, {s2('t64')}")
     # ---- first tile: XCD-aware bijective map (workgroups sharing an XCD get consecutive tiles: the channel tiles of a pixel tile share its pixels in L2) ----
     E(f"s_lshr_b32 {s('tmp0')}, {s('G')}, 3", "q")
     E(f"s_and_b32 {s('tmp1')}, {s('G')}, 7", "r")
@@ -511,7 +509,15 @@ def gen_kernel(name, stamped=False, **opt):
     emit_advance_d()
     E(f"s_mov_b32 {s('dbuf')}, {RB0 + 2 * CH}")
     E(f"s_mov_b32 {s('rbufn')}, {RB0 + CH}")
+    # ---- the biases -> LDS (all `cout` floats, 16 bytes per thread), fetched behind the first chunks' loads: one memory latency for all ----
+    E(f"v_lshlrev_b32 v{T[3]}, 4, {v('tid')}")
+    E(f"s_lshl_b32 {s('tmp0')}, {s('cout')}, 2")
+    E(f"v_cmp_gt_u32 vcc, {s('tmp0')}, v{T[3]}")
+    E(f"s_and_saveexec_b64 {s2('t64')}, vcc")
+    E(f"global_load_dwordx4 v[{T[4]}:{T[7]}], v{T[3]}, {s2('bias')}")
     E("s_waitcnt vmcnt(0)")
+    E(f"ds_write_b128 v{T[3]}, v[{T[4]}:{T[7]}] offset:{BIAS_OFF}")
+    E(f"s_mov_b64 exec, {s2('t64')}")
     E("s_waitcnt lgkmcnt(0)")
     E("s_barrier")
     emit_acc_init("c_ct")
@@ -526,7 +532,11 @@ def gen_kernel(name, stamped=False, **opt):
     E(f"s_cbranch_scc1 {noepi}")
     stamp(PH_STREAM)
     emit_epilogue()
+    noinit = uid("noinit")
+    E(f"s_cmp_eq_u32 {s('n_ok')}, 0", "no tile follows: nothing to initialise")
+    E(f"s_cbranch_scc1 {noinit}")
     emit_acc_init("n_ct")
+    label(noinit)
     stamp(PH_EPILOGUE)
     label(noepi)
     # rotate the stages and the ring
@@ -644,17 +654,20 @@ def main():
     text = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.text"]
     entries = []
     # the shipped kernel and its stamped build; with AQ_GEN_EXPERIMENTAL=1 also timing-only ablations (AQ_C1_ASM_KERNEL=<name>; wrong results)
-    variants = [("conv1x1_asm_nb13", False, {}), ("conv1x1_asm_nb13_stamped", True, {})]
+    variants = [(f"conv1x1_asm_nb{nb}{'_stamped' if st else ''}", nb, st, {}) for nb in (13, 7) for st in (False, True)]
     if os.environ.get("AQ_GEN_EXPERIMENTAL") == "1":
-        variants += [("conv1x1_asm_nb13_nosilu", False, dict(nosilu=True)), ("conv1x1_asm_nb13_nomfma", False, dict(nomfma=True)),
-                     ("conv1x1_asm_nb13_nodma", False, dict(nodma=True)), ("conv1x1_asm_nb13_nowl", False, dict(nowl=True)),
-                     ("conv1x1_asm_nb13_nost", False, dict(nost=True)), ("conv1x1_asm_nb13_nords", False, dict(nords=True)),
-                     ("conv1x1_asm_nb13_mfmaonly", False, dict(nosilu=True, nodma=True, nowl=True, nost=True, nords=True))]
-    for name, stamped, opt in variants:
+        variants += [("conv1x1_asm_nb13_nosilu", 13, False, dict(nosilu=True)), ("conv1x1_asm_nb13_nomfma", 13, False, dict(nomfma=True)),
+                     ("conv1x1_asm_nb13_nodma", 13, False, dict(nodma=True)), ("conv1x1_asm_nb13_nowl", 13, False, dict(nowl=True)),
+                     ("conv1x1_asm_nb13_nost", 13, False, dict(nost=True)), ("conv1x1_asm_nb13_nords", 13, False, dict(nords=True)),
+                     ("conv1x1_asm_nb13_mfmaonly", 13, False, dict(nosilu=True, nodma=True, nowl=True, nost=True, nords=True))]
+    report = []
+    for name, nb, stamped, opt in variants:
         text += [f"\t.globl\t{name}", "\t.p2align\t8", f"\t.type\t{name},@function"]
-        text += gen_kernel(name, stamped, **opt)
+        text += gen_kernel(name, nb, stamped, **opt)
         entries.append(metadata_entry(name))
         text += [f".Lfend_{name}:", f"\t.size\t{name}, .Lfend_{name}-{name}", descriptor(name)]
+        if not stamped and not opt:
+            report.append(f"{name}: {V.next} VGPRs, {LDS_BYTES} B LDS")
     text.append(f"""	.amdgpu_metadata
 ---
 amdhsa.kernels:
@@ -667,7 +680,7 @@ amdhsa.version:
 """)
     with open(path, "w") as f:
         f.write("\n".join(text) + "\n")
-    print(f"conv1x1_asm_nb13: {V.next} VGPRs, {S.next} SGPRs, {LDS_BYTES} B LDS; wrote {path}: {sum(1 for l in text if 'v_mfma' in l)} MFMA instructions")
+    print("; ".join(report) + f"; {S.next} SGPRs; wrote {path}: {sum(1 for l in text if 'v_mfma' in l)} MFMA instructions")
 
 
 if __name__ == "__main__":

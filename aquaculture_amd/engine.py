@@ -397,7 +397,7 @@ class Engine:
         tables), and the environment switches that remove kernels from the candidate set (such a run has a table of its own)."""
         key = (f"{self.ck.variant}:nc{self.ck.nc}:p{self.precision_name}:{B}x{H}x{W}:n{self.lib.aq_conv_num_configs()}"
                f":v{self.lib.aq_version()}:ops{len(self.plan.ops)}")
-        off = ",".join(sorted(f"{k}={v}" for k, v in os.environ.items() if k.startswith("AQ_DISABLE_") or k in ("AQ_PL_W8", "AQ_PL_ASM", "AQ_PL_NB")))
+        off = ",".join(sorted(f"{k}={v}" for k, v in os.environ.items() if k.startswith("AQ_DISABLE_") or k in ("AQ_PL_W8", "AQ_PL_ASM", "AQ_PL_NB", "AQ_C1_ASM", "AQ_C1_ASM_NB")))
         return key + (":" + off if off else "")
 
     def autotune(self, tiles: torch.Tensor, reps: int = 3, cache: Optional[str] = None, shipped: bool = True) -> List[int]:

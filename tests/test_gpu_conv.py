@@ -298,11 +298,14 @@ def test_direct_conv1x1_matches_reference(lib, cin, cout, npix_shape):
 
 @pytest.mark.parametrize("cin,cout", [(768, 768), (768, 384), (1536, 768), (96, 384), (384, 1536)])
 @pytest.mark.parametrize("npix_shape", [(1, 5, 7), (1, 13, 16), (2, 37, 41), (16, 40, 40)])
-def test_asm_conv1x1_matches_reference(lib, cin, cout, npix_shape):
-    """aq_conv1x1_asm (generated assembly, 208-pixel x 384-channel tiles) vs F.conv2d on bf16-rounded operands: K = 96 (one chunk) .. 1536,
-    one / two / four channel tiles; input and output are channel slices of wider tensors; pixel counts: less than one tile, exactly one
-    tile, ragged multi-tile, more tiles than CUs (several tiles per workgroup: the loads run ahead across tile boundaries)."""
+@pytest.mark.parametrize("family", [13, 7])
+def test_asm_conv1x1_matches_reference(lib, monkeypatch, cin, cout, npix_shape, family):
+    """aq_conv1x1_asm (generated assembly; both tile heights: 208 and 112 pixels x 384 channels) vs F.conv2d on bf16-rounded operands: K = 96
+    (one chunk) .. 1536, one / two / four channel tiles; input and output are channel slices of wider tensors; pixel counts: less than one
+    tile, exactly one 208-pixel tile, ragged multi-tile, more tiles than CUs (several tiles per workgroup: the loads run ahead across tile
+    boundaries)."""
     from aquaculture_amd import engine
+    monkeypatch.setenv("AQ_C1_ASM_NB", str(family))
     B, H, W = npix_shape
     g = torch.Generator().manual_seed(cin + H)
     xw = (torch.randn(B, H, W, cin + 16, generator=g) * 0.8).bfloat16().cuda()

@@ -23,6 +23,7 @@ SHAPES = [  # (cin, cout, pixels at batch 64, layer)
     (1536, 768, 64 * 20 * 20, "model.9.cv2"),
     (768, 384, 64 * 40 * 40, "model.13.cv1|cv2"),
     (384, 384, 64 * 40 * 40, "model.6.cv1|cv2 / cv3, 13.cv3, 20.*  (direct kernel's layers)"),
+    (384, 384, 64 * 20 * 20, "model.8.m.*.cv1, model.23.m.*.cv1  (direct kernel's layers)"),
 ]
 PHASES = ["prologue", "stream", "barrier", "epilogue"]
 
@@ -32,16 +33,17 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--stamp", action="store_true")
     ap.add_argument("--only", type=int, default=-1, help="index of the one shape to time")
+    ap.add_argument("--hot", action="store_true", help="one buffer set instead of > 600 MB of them: operands stay in L2 / MALL between launches")
     a = ap.parse_args()
     lib = engine.load_library()
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator().manual_seed(1)
-    print(f"# kernel: {os.environ.get('AQ_C1_ASM_KERNEL') or 'conv1x1_asm_nb13'}")
+    print(f"# kernel: {os.environ.get('AQ_C1_ASM_KERNEL') or 'conv1x1_asm_nb13 / nb7 (AQ_C1_ASM_NB=' + os.environ.get('AQ_C1_ASM_NB', 'auto') + ')'}")
     for si, (cin, cout, npix, name) in enumerate(SHAPES):
         if a.only >= 0 and a.only != si:
             continue
         per = npix * (cin + cout) * 2
-        nbuf = max(2, int(640e6 // per) + 1)
+        nbuf = 1 if a.hot else max(2, int(640e6 // per) + 1)
         base = (torch.randn(npix, cin, generator=g) * 0.5).bfloat16().cuda()
         xs = [base.clone() for _ in range(nbuf)]
         ys = [torch.empty(npix, cout, dtype=torch.bfloat16, device="cuda") for _ in range(nbuf)]
