@@ -94,9 +94,11 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
     p.add_argument("--jpeg-decode", choices=("auto", "host", "split", "gpu"), default="auto",
                    help="split: the decode workers undo only the Huffman coding, the GPU does the inverse DCT, chroma upsampling and colour "
                         "conversion (byte-identical to libjpeg-turbo; baseline 4:2:0 JPEGs, which is what the reference's tiler writes); "
-                        "host: full software decode in the workers; auto: split when every image of the sweep qualifies; "
-                        "gpu: the Huffman stage on the GPU as well (one lane per image, super-batches of AQ_JPEG_GPU_SUPERBATCH = 1024 tiles in "
-                        "flight): the host only reads the files and strips byte stuffing, H2D carries the files' entropy-coded bytes")
+                        "host: full software decode in the workers; "
+                        "gpu: the Huffman stage on the GPU as well (one lane per image, super-batches of AQ_JPEG_GPU_SUPERBATCH = 2048 tiles in "
+                        "flight): the host only reads the files and strips byte stuffing, H2D carries the files' entropy-coded bytes; "
+                        "auto: split when every image of the sweep qualifies, gpu when this rank's share is also >= AQ_JPEG_GPU_AUTO_MIN = "
+                        "32768 images (the super-batches cost a second of start-up and pay off at 1.15-1.3 x the steady rate; same label bytes)")
     p.add_argument("--resume", action="store_true",
                    help="continue an interrupted sweep in project/name (implies --exist-ok): tiles recorded in the run directory's "
                         "done.rank*.txt manifests are skipped, also those that produced no label file")
@@ -444,13 +446,14 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                                          f"(use auto or host): {', '.join(bad[:3])}{' ...' if len(bad) > 3 else ''}")
                 if jpeg_decode == "gpu" and not split:
                     raise ValueError("--jpeg-decode gpu needs baseline 4:2:0 JPEGs throughout (use auto or host)")
+                use_gpu = jpeg_decode == "gpu" or (jpeg_decode == "auto" and split and len(sub) >= int(os.environ.get("AQ_JPEG_GPU_AUTO_MIN", 32768)))
                 if split and not split_note[0]:
                     split_note[0] = True
                     log(f"jpeg decode: split (entropy decoding in {sub.workers} worker processes, IDCT / upsampling / colour conversion on the GPU)"
-                        if jpeg_decode != "gpu" else
+                        if not use_gpu else
                         f"jpeg decode: gpu (entropy decoding on the GPU, one lane per image, super-batches of {gpu_superbatch} tiles; "
                         f"{sub.workers} reader threads strip byte stuffing; IDCT / upsampling / colour conversion on the GPU)")
-                if jpeg_decode == "gpu":
+                if use_gpu:
                     it = gpu_jpeg_source(sub)
                 else:
                     gen = sub.pinned_batches(batch_size, depth + 2, processes=0 if decode_threads else None, coef=split)     # one buffer more than the batches in flight: the workers decode one batch ahead

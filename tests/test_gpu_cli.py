@@ -424,11 +424,13 @@ def test_gpu_jpeg_decode_gives_identical_labels(workdir, lib, tmp_path):
     import shutil
     out_h, lab_h = _run(workdir, "gjpeg_host", extra=("--quiet", "--half", "--jpeg-decode", "host"))
     out_g, lab_g = _run(workdir, "gjpeg_gpu", extra=("--quiet", "--half", "--jpeg-decode", "gpu"), env={"AQ_JPEG_GPU_SUPERBATCH": "4"})
-    assert "jpeg decode: gpu" in out_g
+    # `auto` takes the GPU decoder once this rank's share reaches AQ_JPEG_GPU_AUTO_MIN images (32,768 by default: the split path below that)
+    out_a, lab_a = _run(workdir, "gjpeg_auto", extra=("--quiet", "--half"), env={"AQ_JPEG_GPU_AUTO_MIN": "1"})
+    assert "jpeg decode: gpu" in out_g and "jpeg decode: gpu" in out_a
     names = sorted(os.listdir(lab_h))
-    assert names and names == sorted(os.listdir(lab_g))
+    assert names and names == sorted(os.listdir(lab_g)) == sorted(os.listdir(lab_a))
     for n in names:
-        assert open(lab_g / n, "rb").read() == open(lab_h / n, "rb").read(), n
+        assert open(lab_g / n, "rb").read() == open(lab_h / n, "rb").read() == open(lab_a / n, "rb").read(), n
     src = tmp_path / "jpegs"
     shutil.copytree(workdir / "jpegs", src)
     victim = sorted(os.listdir(src))[5]
