@@ -9,6 +9,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 timeout -k 10 1000 python tools/profile_pmc.py --out "$OUT/pmc" > "$OUT/pmc.log" 2>&1 || echo "profile_pmc failed (see $OUT/pmc.log)"
 cp "$OUT/pmc/hbm_traffic.json" profiles/hbm_traffic_latest.json 2>/dev/null      # so that the bench lines below carry `traffic`
+if [ -z "${SKIP_E2E:-}" ]; then
 rm -f "$OUT/e2e_latest.json"
 for sz in 640 1024; do
     for jd in split gpu host; do
@@ -20,6 +21,7 @@ for jd in split gpu host; do
     timeout -k 10 300 python tools/bench_e2e.py --size 1024 --n 16384 --workers 14 --precision bf16 --jpeg-decode "$jd" --noise 10 --json "$OUT/e2e_latest.json" 2>&1 | grep -E "steady"
 done
 timeout -k 10 300 python tools/bench_e2e.py --scenes 200 --workers 14 --precision bf16 --json "$OUT/e2e_latest.json" 2>&1 | grep -E "steady"
+fi      # (SKIP_E2E=1: keep the e2e file of an earlier call of the same build)
 cp "$OUT/e2e_latest.json" profiles/e2e_latest.json 2>/dev/null                   # ... and `e2e`
 timeout -k 10 300 python bench.py > "$OUT/bench_default.json" 2>/dev/null
 AQ_PL_PM=0 timeout -k 10 300 python bench.py --no-cpu-baseline --parity-steps 0 > "$OUT/bench_default_slot_major.json" 2>/dev/null

@@ -101,7 +101,7 @@ def op_patterns(o, spec):
         return ("nms_kernel",)
     if o.level >= 0:
         return ("head_decode_kernel", "conv_igemm_kernel")
-    return ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv1x1_direct_kernel", "conv3x3_pl", "downblock_kernel")
+    return ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv1x1_direct_kernel", "conv1x1_asm", "conv3x3_pl", "downblock_kernel")
 
 
 def steps_of(disp, kernels_per_step=None):
