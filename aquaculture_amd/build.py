@@ -81,7 +81,8 @@ def _assemble_planar(verbose: bool, cc: str) -> None:
     C = 48 Bottleneck; gen_conv1x1_asm.py: the wide 1x1), assemble and link it into a gfx950 code object with the ROCm clang / lld, and write it as a byte list that the
     .hip file of the same family embeds (hipModuleLoadData)."""
     llvm = llvm_bin(cc)
-    for gen, stem in (("gen_conv3x3_pl_asm.py", "conv3x3_pl_asm"), ("gen_bottleneck_asm.py", "bottleneck_asm"), ("gen_conv1x1_asm.py", "conv1x1_asm")):
+    for gen, stem in (("gen_conv3x3_pl_asm.py", "conv3x3_pl_asm"), ("gen_bottleneck_asm.py", "bottleneck_asm"), ("gen_bottleneck96_asm.py", "bottleneck96_asm"),
+                      ("gen_conv1x1_asm.py", "conv1x1_asm")):
         src, obj, co = (os.path.join(CSRC, stem + ext) for ext in (".s", ".o", ".hsaco"))
         cmds = [[sys.executable, os.path.join(CSRC, gen), src],
                 [os.path.join(llvm, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-c", src, "-o", obj],

@@ -662,6 +662,97 @@ void btl_asm_pack(const float* w1, const float* w2, bf16_t* dst) {
             }
 }
 
+// ---- C = 96: the assembly build of round 4 (gen_bottleneck96_asm.py) -- 4 waves, one per SIMD; wave (h, q) owns three M blocks (48 output
+// channels) of one pixel half and keeps its 81 + 9 A fragments in registers (64 of them in AGPRs); 8 x 16-pixel tiles. ----
+const unsigned char kBtl96AsmCode[] = {
+#include "bottleneck96_asm_hsaco.inc"
+};
+hipModule_t g_btl96_mod[64];
+hipFunction_t g_btl96_fn[64][2];             // plain, stamped
+constexpr size_t kBtl96AsmWBytes = (size_t)2 * (9 + 81) * 1024;     // per channel half: nine A fragments of the 1x1, 81 of the 3x3
+
+int btl96_load(int dev) {
+    if (g_btl96_mod[dev]) return AQ_OK;
+    hipModule_t mod = nullptr;
+    AQ_CHECK_HIP(hipModuleLoadData(&mod, kBtl96AsmCode));
+    AQ_CHECK_HIP(hipModuleGetFunction(&g_btl96_fn[dev][0], mod, "bottleneck_asm_c96"));
+    AQ_CHECK_HIP(hipModuleGetFunction(&g_btl96_fn[dev][1], mod, "bottleneck_asm_c96_stamped"));
+    g_btl96_mod[dev] = mod;
+    return AQ_OK;
+}
+
+// Does the C = 96 assembly kernel take this launch?  (8 x 16 tiles; 32-bit buffer offsets; magic-number tile decode needs >= 2 tiles per row and image.)
+bool btl96_asm_fits(int C, int B, int H, int W, int in_ld, int out_ld) {
+    static const bool off = [] { const char* e = getenv("AQ_BTL96_ASM"); return e && *e == '0'; }();
+    if (C != 96 || off || !btl_asm_enabled() || btl_wide()) return false;
+    const long long tx = (W + 15) / 16, ty = (H + 7) / 8, tpi = tx * ty, nt = tpi * B;
+    if (tx < 2 || tpi < 2 || nt >= (1LL << 24) || nt * tpi >= (1LL << 32)) return false;
+    if ((long long)B * H * W * in_ld * 2 >= (1LL << 30) || (long long)B * H * W * out_ld * 2 >= (1LL << 31)) return false;
+    return true;
+}
+
+int launch_btl96_asm(const BtlParams& p, hipStream_t stream) {
+    int dev = 0;
+    AQ_CHECK_HIP(hipGetDevice(&dev));
+    AQ_REQUIRE(dev >= 0 && dev < 64, "bottleneck: device ordinal %d", dev);
+    { const int rc = btl96_load(dev); if (rc) return rc; }
+    BtlAsmArgs a{};
+    a.in = p.in; a.out = p.out; a.bias = p.bias;
+    a.w = p.w;                                                 // (the caller passes the assembly image: it follows the HIP kernel's in the packed buffer)
+    a.in_ld_b = p.in_ld_b; a.out_ld_b = p.out_ld_b; a.B = p.B; a.H = p.H; a.W = p.W;
+    a.tiles_x = (p.W + 15) / 16;
+    a.tpi = a.tiles_x * ((p.H + 7) / 8);
+    a.ntiles = a.tpi * p.B;
+    a.shortcut = p.shortcut;
+    long long grid = g_btl_cus;
+    if (grid > a.ntiles) grid = a.ntiles;
+    a.G = (int)grid;
+    a.magic_tpi = (unsigned)((1ULL << 32) / (unsigned)a.tpi + 1);
+    a.magic_tx = (unsigned)((1ULL << 32) / (unsigned)a.tiles_x + 1);
+    // bytes of the slices from their first channel to the end of their last pixel: loads beyond read zeros, stores beyond are dropped
+    a.in_bytes = (unsigned)(((long long)p.B * p.H * p.W - 1) * p.in_ld_b + 192);
+    a.pad = (unsigned)(((long long)p.B * p.H * p.W - 1) * p.out_ld_b + 192);          // (out_bytes in this kernel's argument block)
+    int which = 0;
+    size_t sbytes = 0;
+    unsigned long long* sbuf = aq_stamp_buffer(&sbytes);
+    if (sbuf && (size_t)grid * 4 * 64 <= sbytes) { a.debug = sbuf; which = 1; }
+    hipFunction_t fn = g_btl96_fn[dev][which];
+    const char* exp_kernel = getenv("AQ_BTL96_ASM_KERNEL");    // timing experiments: another kernel of the code object, by name (tools/time_bottleneck.py)
+    if (exp_kernel && *exp_kernel) {
+        char name[96];
+        snprintf(name, sizeof name, "%s%s", exp_kernel, which ? "_stamped" : "");
+        AQ_CHECK_HIP(hipModuleGetFunction(&fn, g_btl96_mod[dev], name));
+    }
+    size_t asz = sizeof(a);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+    AQ_CHECK_HIP(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, stream, nullptr, extra));
+    return AQ_OK;
+}
+
+// A-fragment image of the C = 96 assembly kernel: per output-channel half h, nine fragments of the 1x1 [k-step 3][M block 3], then 81 of the 3x3
+// [tap 9][k-step 3][M block 3], 64 lanes x 8 bf16 each.  Lane (r = lane & 15, kg = lane >> 4) of M block m holds input channels
+// 32 kstep + 8 kg .. + 7 of output channel 48 h + (m < 2 ? 8 (r >> 2) + 4 m + (r & 3) : 32 + 4 (r >> 2) + (r & 3)) -- the rows are permuted so
+// that a lane's twelve results of a pixel are 8 + 4 consecutive channels (16- and 8-byte stores / LDS writes).
+void btl96_asm_pack(const float* w1, const float* w2, bf16_t* dst) {
+    const int C = 96;
+    for (int h = 0; h < 2; ++h) {
+        auto chan = [&](int m, int r) { return 48 * h + (m < 2 ? 8 * (r >> 2) + 4 * m + (r & 3) : 32 + 4 * (r >> 2) + (r & 3)); };
+        for (int s = 0; s < 3; ++s)
+            for (int m = 0; m < 3; ++m)
+                for (int lane = 0; lane < 64; ++lane, dst += 8) {
+                    const int co = chan(m, lane & 15), c0 = 32 * s + 8 * (lane >> 4);
+                    for (int e = 0; e < 8; ++e) dst[e] = aq_f2bf(w1[(size_t)co * C + c0 + e]);
+                }
+        for (int tap = 0; tap < 9; ++tap)
+            for (int s = 0; s < 3; ++s)
+                for (int m = 0; m < 3; ++m)
+                    for (int lane = 0; lane < 64; ++lane, dst += 8) {
+                        const int co = chan(m, lane & 15), c0 = 32 * s + 8 * (lane >> 4);
+                        for (int e = 0; e < 8; ++e) dst[e] = aq_f2bf(w2[((size_t)co * 9 + tap) * C + c0 + e]);
+                    }
+    }
+}
+
 }  // namespace
 
 // Packs the fused fp32 weights of one Bottleneck -- w1 KRSC (C,1,1,C), w2 KRSC (C,3,3,C) -- into the A-fragment image the
@@ -674,7 +765,7 @@ extern "C" int aq_pack_bottleneck_weights(const float* w1_host, const float* w2_
     const int cb = C / 8, ks1 = (cb + 3) / 4, ks2 = (9 * cb + 3) / 4;
     const size_t frags = (size_t)sh.msplit * (ks1 + ks2) * sh.mbw;
     const size_t hip_bytes = frags * 64 * 16;
-    *bytes = hip_bytes + (C == 48 ? kBtlAsmWBytes : 0);      // C = 48: the assembly kernel's image follows the HIP kernel's
+    *bytes = hip_bytes + (C == 48 ? kBtlAsmWBytes : C == 96 ? kBtl96AsmWBytes : 0);      // C = 48 / 96: the assembly kernel's image follows the HIP kernel's
     if (!packed_dev) return AQ_OK;
     bf16_t* host = (bf16_t*)calloc(1, *bytes);
     AQ_REQUIRE(host, "pack_bottleneck: out of host memory");
@@ -697,6 +788,7 @@ extern "C" int aq_pack_bottleneck_weights(const float* w1_host, const float* w2_
                     }
                 }
     if (C == 48) btl_asm_pack(w1_host, w2_host, (bf16_t*)((char*)host + hip_bytes));
+    if (C == 96) btl96_asm_pack(w1_host, w2_host, (bf16_t*)((char*)host + hip_bytes));
     hipError_t e = hipMemcpyAsync(packed_dev, host, *bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     free(host);
@@ -738,6 +830,11 @@ extern "C" int aq_bottleneck(const void* in_dev, int in_ld, int in_choff, void* 
         btl_shape(48, &sh48);
         p.w += (size_t)sh48.msplit * ((48 / 8 + 3) / 4 + (9 * 48 / 8 + 3) / 4) * sh48.mbw * 64 * 16;      // skip the HIP kernel's image
         return launch_btl_asm(p, st);
+    }
+    if (btl96_asm_fits(C, B, H, W, in_ld, out_ld)) {
+        const int cb = 96 / 8, ks1 = (cb + 3) / 4, ks2 = (9 * cb + 3) / 4;
+        p.w += (size_t)sh.msplit * (ks1 + ks2) * sh.mbw * 64 * 16;                                       // skip the HIP kernel's image
+        return launch_btl96_asm(p, st);
     }
     switch (C) {
         case 16: return launch_btl<1, 1, 4, 32, 0, false, false>(p, st);

@@ -72,6 +72,18 @@ def main():
             us = e0.elapsed_time(e1) * 1e3 / a.iters
             flops = 2.0 * npix * c * c * 10
             print(f"C={c:3d} {B}x{H}x{W} shortcut={sc}: {us:7.1f} us  {flops / us / 1e6:7.1f} TFLOP/s  {per / us / 1e6:5.2f} TB/s (in + out once)  {name}", flush=True)
+        if a.stamp and c == 96 and os.environ.get("AQ_BTL_ASM") != "0" and os.environ.get("AQ_BTL96_ASM") != "0":
+            buf = torch.zeros(1 << 20, dtype=torch.int64, device="cuda")
+            engine._check(lib.aq_debug_conv_stamp(buf.data_ptr(), buf.numel() * 8))
+            try:
+                run(0)
+                torch.cuda.synchronize()
+            finally:
+                lib.aq_debug_conv_stamp(None, 0)
+            t = buf.cpu().view(-1, 8)[:, :4]
+            t = t[t.sum(1) > 0].double()
+            print(f"  stamped build: {t.shape[0]} waves, {t.sum(1).mean():.0f} cycles per wave | " +
+                  " ".join(f"{nm}={v:.0f}" for nm, v in zip(["prologue+phase-B", "barrier+C-setup", "C-mfma", "C-epilogue"], t.mean(0).tolist())))
         if a.stamp and c == 48 and os.environ.get("AQ_BTL_ASM") != "0":
             buf = torch.zeros(1 << 20, dtype=torch.int64, device="cuda")
             engine._check(lib.aq_debug_conv_stamp(buf.data_ptr(), buf.numel() * 8))
