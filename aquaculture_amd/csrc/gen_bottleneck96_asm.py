@@ -167,7 +167,7 @@ out = []
 _uid = [0]
 STAMPED = [False]
 PLAIN = [False]              # True while phase C's interleaved epilogue is generated: packed fp32 instructions are written as two plain ones
-OPT = dict(nosilu=False, nomfma=False, nodma=False, nold=False, nost=False, vgpra=False, nords=False, pk=False, rg=0)
+OPT = dict(nosilu=False, nomfma=False, nodma=False, nold=False, nost=False, vgpra=False, nords=False, pk=False, rg=0, bstamp=False)
 
 
 def E(line="", comment=None):
@@ -366,7 +366,11 @@ def emit_phase_b():
         if bi == 0:
             E("s_nop 15", "hz: MFMA result -> VALU read (block 0 only: later blocks' MFMAs are a whole SiLU old)")
             E("s_nop 15")
+        if OPT["bstamp"]:
+            stamp(PH_B)
         silu_store(bi)
+        if OPT["bstamp"]:
+            stamp(PH_BARRIER)
 
 
 def tap_off(t):
@@ -436,7 +440,8 @@ def emit_phase_c():
         label(skip)
 
     emit_acc_init(1, 4)
-    stamp(PH_BARRIER)                              # (stamped build: barrier wait + masks + accumulator start)
+    if not OPT["bstamp"]:
+        stamp(PH_BARRIER)                          # (stamped build: barrier wait + masks + accumulator start)
 
     # ---- the 3x3, ROW-major: output row j's 27 k-steps (81 MFMAs), then row j + 1's with row j's epilogue between them -- one wave per SIMD,
     # so the SiLU (v_exp + v_rcp at 16 cycles each) only overlaps MFMAs it is interleaved with.  B-fragment ring of NRING, read PD ahead.
@@ -582,7 +587,7 @@ def count_stores_behind_dma():
     STAMPED[0] = False
     saved_opt = dict(OPT)
     for k_ in OPT:
-        if k_ != "rg":
+        if k_ not in ("rg", "bstamp"):
             OPT[k_] = False
     emit_phase_c()
     OPT.update(saved_opt)
@@ -870,6 +875,7 @@ def main():
                      ("bottleneck_asm_c96_nost", False, dict(nost=True)), ("bottleneck_asm_c96_nost_stamped", True, dict(nost=True)),
                      ("bottleneck_asm_c96_rg4", False, dict(rg=4)), ("bottleneck_asm_c96_rg4_stamped", True, dict(rg=4)),
                      ("bottleneck_asm_c96_rg1", False, dict(rg=1)), ("bottleneck_asm_c96_rg1_stamped", True, dict(rg=1)),
+                     ("bottleneck_asm_c96_bstamp", False, dict(bstamp=True)), ("bottleneck_asm_c96_bstamp_stamped", True, dict(bstamp=True)),
                      ("bottleneck_asm_c96_pk", False, dict(pk=True)), ("bottleneck_asm_c96_pk_stamped", True, dict(pk=True)),
                      ("bottleneck_asm_c96_vgpra", False, dict(vgpra=True)), ("bottleneck_asm_c96_vgpra_stamped", True, dict(vgpra=True)),
                      ("bottleneck_asm_c96_nords", False, dict(nords=True)), ("bottleneck_asm_c96_nords_stamped", True, dict(nords=True)),

@@ -73,6 +73,14 @@ def test_engine_infer_with_and_without_head_fusion(lib, synth_ck, monkeypatch):
         if c0[bi] != c1[bi]:
             continue
         n = int(c0[bi])
-        torch.testing.assert_close(d0[bi, :n, :4], d1[bi, :n, :4], rtol=0, atol=2e-2)
-        torch.testing.assert_close(d0[bi, :n, 4], d1[bi, :n, 4], rtol=0, atol=1e-4)
-        assert torch.equal(d0[bi, :n, 5], d1[bi, :n, 5])
+        # the lists are sorted by confidence: two detections whose confidences differ by less than the two paths' rounding may swap places, so
+        # match every row to its nearest row of the other list (one to one) instead of comparing position by position
+        a, b = d0[bi, :n], d1[bi, :n]
+        dist = (a[:, None, :4] - b[None, :, :4]).abs().amax(-1)
+        nearest = dist.argmin(1)
+        assert sorted(nearest.tolist()) == list(range(n)), "not a one-to-one match"
+        b = b[nearest]
+        assert (nearest - torch.arange(n)).abs().max() <= 2          # ... and only neighbours swap
+        torch.testing.assert_close(a[:, :4], b[:, :4], rtol=0, atol=2e-2)
+        torch.testing.assert_close(a[:, 4], b[:, 4], rtol=0, atol=1e-4)
+        assert torch.equal(a[:, 5], b[:, 5])
