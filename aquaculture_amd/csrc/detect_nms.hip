@@ -128,6 +128,8 @@ struct NmsParams {
     aq_det* dets;               // [B][max_det]
     int32_t* counts;            // [B]
     unsigned long long* dbg;    // diagnostics (armed stamp buffer): 8 phase timestamps per tile, else null
+    float class_step;           // kMaxWH, or 0 for class-agnostic NMS [UPSTREAM non_max_suppression: agnostic]
+    unsigned long long cls_lo, cls_hi;   // classes kept (bit c of lo / bit c - 64 of hi) [UPSTREAM: classes]; all ones = no filter
 };
 
 // Candidates handled by the bit-matrix (fast) path: 2048 for 640-px tiles (25,200 rows, a few hundred candidates), 4096 for larger tiles
@@ -145,7 +147,8 @@ constexpr int nms_lds(int kf) { return nms_fast_lds(kf) + nms_mask_lds(kf) > kSl
 static_assert(nms_lds(kFastBig) <= 160 * 1024, "LDS");
 
 // conf = obj * cls_conf, best class = first maximum; box = xywh2xyxy (x -/+ w/2)
-__device__ __forceinline__ bool candidate_row(const float* row, int nc, float thr, float4& box, float& conf, int& cls) {
+__device__ __forceinline__ bool candidate_row(const float* row, int nc, float thr, float4& box, float& conf, int& cls,
+                                              unsigned long long cls_lo = ~0ULL, unsigned long long cls_hi = ~0ULL) {
     const float obj = row[4];
     if (!(obj > thr)) return false;
     float best = row[5] * obj;
@@ -155,6 +158,7 @@ __device__ __forceinline__ bool candidate_row(const float* row, int nc, float th
         if (v > best) { best = v; bj = c; }
     }
     if (!(best > thr)) return false;
+    if (!(((bj < 64 ? cls_lo >> bj : cls_hi >> (bj - 64)) & 1ULL))) return false;      // x = x[(x[:, 5:6] == classes).any(1)]
     const float hw = row[2] / 2.0f, hh = row[3] / 2.0f;
     box.x = row[0] - hw; box.y = row[1] - hh; box.z = row[0] + hw; box.w = row[1] + hh;
     conf = best; cls = bj;
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
     for (int t = tid; t < n0; t += kNmsThreads) {
         const int idx = p.cand ? p.cand[(long long)b * p.cap + t] : t;
         float4 box; float conf; int cls;
-        if (candidate_row(rows + (long long)t * p.no, p.nc, p.conf_thres, box, conf, cls)) {
+        if (candidate_row(rows + (long long)t * p.no, p.nc, p.conf_thres, box, conf, cls, p.cls_lo, p.cls_hi)) {
             const int pos = atomicAdd(&s_n, 1);
             keys[pos] = make_key(conf, idx, t);
         }
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
 
     auto emit = [&](int slot, int k) {   // one output row [x1, y1, x2, y2, conf, cls], boxes WITHOUT the class offset
         float4 box; float conf; int cls;
-        candidate_row(rows + (long long)slot * p.no, p.nc, p.conf_thres, box, conf, cls);
+        candidate_row(rows + (long long)slot * p.no, p.nc, p.conf_thres, box, conf, cls, p.cls_lo, p.cls_hi);
         aq_det d; d.x1 = box.x; d.y1 = box.y; d.x2 = box.z; d.y2 = box.w; d.conf = conf; d.cls = (float)cls;
         p.dets[(long long)b * p.max_det + k] = d;
     };
@@ -276,8 +280,8 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
             sslot[r] = key_slot(k);
             // C: sorted boxes + class offset (boxes + cls * max_wh, fp32)
             float4 box; float conf; int cls;
-            candidate_row(rows + (long long)key_slot(k) * p.no, p.nc, p.conf_thres, box, conf, cls);
-            const float c = (float)cls * kMaxWH;
+            candidate_row(rows + (long long)key_slot(k) * p.no, p.nc, p.conf_thres, box, conf, cls, p.cls_lo, p.cls_hi);
+            const float c = (float)cls * p.class_step;
             box.x = box.x + c; box.y = box.y + c; box.z = box.z + c; box.w = box.w + c;
             sb[r] = box;
         }
@@ -389,8 +393,8 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
     n = min(n, kMaxNms);
     for (int t = tid; t < n; t += kNmsThreads) {
         float4 box; float conf; int cls;
-        candidate_row(rows + (long long)key_slot(keys[t]) * p.no, p.nc, p.conf_thres, box, conf, cls);
-        const float c = (float)cls * kMaxWH;
+        candidate_row(rows + (long long)key_slot(keys[t]) * p.no, p.nc, p.conf_thres, box, conf, cls, p.cls_lo, p.cls_hi);
+        const float c = (float)cls * p.class_step;
         box.x = box.x + c; box.y = box.y + c; box.z = box.z + c; box.w = box.w + c;
         sbox[t] = box;
         s_supp[t] = 0;
@@ -459,6 +463,17 @@ extern "C" size_t aq_nms_scratch_bytes(int B, int N) {
 extern "C" int aq_nms(const float* rows_dev, int rows_per_tile, int B, int N, int nc, float conf_thres, float iou_thres,
                       int max_det, const int32_t* cand_dev, const int32_t* cand_count_dev, int cand_cap,
                       void* scratch_dev, aq_det* dets_dev, int32_t* counts_dev, void* stream) {
+    return aq_nms_opts(rows_dev, rows_per_tile, B, N, nc, conf_thres, iou_thres, max_det, cand_dev, cand_count_dev, cand_cap, scratch_dev, dets_dev,
+                       counts_dev, 0, ~0ULL, ~0ULL, stream);
+}
+
+// The same with upstream's two remaining options: agnostic (boxes of different classes suppress each other) and classes (keep only the
+// listed classes: bit c of classes_lo, bit c - 64 of classes_hi; all ones = every class).
+extern "C" int aq_nms_opts(const float* rows_dev, int rows_per_tile, int B, int N, int nc, float conf_thres, float iou_thres,
+                           int max_det, const int32_t* cand_dev, const int32_t* cand_count_dev, int cand_cap,
+                           void* scratch_dev, aq_det* dets_dev, int32_t* counts_dev, int agnostic, unsigned long long classes_lo,
+                           unsigned long long classes_hi, void* stream) {
+    AQ_REQUIRE(nc <= 128, "nms: the class filter covers 128 classes (nc = %d)", nc);
     AQ_REQUIRE(rows_dev && scratch_dev && dets_dev && counts_dev, "nms: null pointer");
     AQ_REQUIRE(B > 0 && N > 0 && nc >= 1 && max_det > 0, "nms: bad shape B=%d N=%d nc=%d max_det=%d", B, N, nc, max_det);
     AQ_REQUIRE(N < (1 << kIdxBits), "nms: at most %d candidates per tile are supported (got %d)", (1 << kIdxBits) - 1, N);
@@ -469,6 +484,7 @@ extern "C" int aq_nms(const float* rows_dev, int rows_per_tile, int B, int N, in
     p.rows = rows_dev; p.rows_per_tile = rows_per_tile; p.B = B; p.N = N; p.nc = nc; p.no = nc + 5;
     p.conf_thres = conf_thres; p.iou_thres = iou_thres; p.max_det = max_det;
     p.cand = cand_dev; p.cand_count = cand_count_dev; p.cap = cand_cap;
+    p.class_step = agnostic ? 0.0f : kMaxWH; p.cls_lo = classes_lo; p.cls_hi = classes_hi;
     p.npow2 = next_pow2(N);
     char* s = (char*)scratch_dev;
     p.keys = (unsigned long long*)s;

@@ -163,6 +163,8 @@ struct aq_engine {
     std::vector<aq_op_desc> ops;
     std::vector<PackedW> packed;        // per op (conv ops only)
     std::vector<int> conv_cfg;          // per op override, -1 = heuristic
+    int nms_agnostic = 0;               // aq_engine_set_nms_options
+    unsigned long long nms_cls_lo = ~0ULL, nms_cls_hi = ~0ULL;
     std::vector<int> tuned_cfg;         // per op result of aq_engine_autotune for (tuned_B, tuned_H, tuned_W)
     int tuned_B = 0, tuned_H = 0, tuned_W = 0;
     void* zero_page = nullptr;
@@ -488,8 +490,8 @@ int run_plan(aq_engine* e, const uint8_t* tiles, int B, int H, int W, void* ws, 
         }
         case AQ_OP_NMS:
             if (dets)
-                rc = aq_nms(cand_rows, e->N, B, e->N, e->desc.nc, conf, iou, max_det, cand, cand_count, e->N,
-                            (char*)ws + e->off_nms, dets, counts, stream);
+                rc = aq_nms_opts(cand_rows, e->N, B, e->N, e->desc.nc, conf, iou, max_det, cand, cand_count, e->N,
+                                 (char*)ws + e->off_nms, dets, counts, e->nms_agnostic, e->nms_cls_lo, e->nms_cls_hi, stream);
             break;
         default:
             aq_set_error("unknown op kind %d", op.kind);
@@ -933,6 +935,12 @@ extern "C" int aq_engine_tensor_ptr(aq_engine* e, int tensor, void** ptr, int* c
 }
 
 extern "C" int aq_engine_num_ops(aq_engine* e) { return e ? (int)e->ops.size() : 0; }
+
+extern "C" int aq_engine_set_nms_options(aq_engine* e, int agnostic, unsigned long long classes_lo, unsigned long long classes_hi) {
+    AQ_REQUIRE(e, "set_nms_options: null engine");
+    e->nms_agnostic = agnostic != 0; e->nms_cls_lo = classes_lo; e->nms_cls_hi = classes_hi;
+    return AQ_OK;
+}
 
 extern "C" int aq_engine_set_conv_config(aq_engine* e, int op, int cfg) {
     AQ_REQUIRE(e && op >= 0 && op < (int)e->ops.size() && e->ops[op].kind == AQ_OP_CONV, "set_conv_config: op %d is not a conv", op);

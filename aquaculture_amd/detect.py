@@ -120,8 +120,6 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     for k in UNSUPPORTED:
         if unsupported.get(k):
             raise NotImplementedError(f"--{k.replace('_', '-')} is not part of the tile-sweep path (reference README.md:77)")
-    if classes is not None or agnostic_nms:
-        raise NotImplementedError("--classes / --agnostic-nms are not used by the reference invocation and not implemented")
     if not nosave:
         log("note: annotated images are never written (the reference runs with --nosave)")
     weights = weights[0] if isinstance(weights, (list, tuple)) else weights
@@ -155,7 +153,9 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
     aqdist.on_rank0(lambda: None if tile_scenes else check_run_params(
         str(save_dir), {"weights_sha256": file_digest(weights) if os.path.isfile(str(weights)) else str(weights),
                         "conf_thres": float(conf_thres), "iou_thres": float(iou_thres), "max_det": int(max_det),
-                        "imgsz": [int(v) for v in imgsz], "precision": precision, "save_conf": bool(save_conf)}, resume))
+                        "imgsz": [int(v) for v in imgsz], "precision": precision, "save_conf": bool(save_conf),
+                        **({"classes": sorted(int(c) for c in classes)} if classes is not None else {}),
+                        **({"agnostic_nms": True} if agnostic_nms else {})}, resume))
     done_before = DoneManifest.load(str(save_dir)) if resume else set()
     manifest = DoneManifest(str(save_dir), rank)
     if not tile_scenes:
@@ -163,6 +163,8 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
 
     ck = load_checkpoint(weights)
     eng = Engine(ck, precision, dev, fp8_calibration="defer")
+    if classes is not None or agnostic_nms:
+        eng.set_nms_options(agnostic=agnostic_nms, classes=classes)            # [UPSTREAM non_max_suppression(pred, conf, iou, classes, agnostic_nms, max_det)]
     imgsz = check_img_size(list(imgsz), s=int(max(ck.stride)))
     if precision == "fp8":
         # e4m3 activation scales from THIS sweep's imagery and tile size (the engine's default calibrates on synthetic 640-px

@@ -67,7 +67,7 @@ EXPORTS = (
     "aq_engine_infer", "aq_engine_forward_raw", "aq_engine_tensor_ptr", "aq_engine_profile",
     "aq_engine_op_times", "aq_engine_num_ops", "aq_engine_set_conv_config", "aq_engine_autotune", "aq_engine_set_tuned_table",
     "aq_engine_get_conv_config", "aq_conv_num_configs", "aq_debug_conv_stamp", "aq_debug_mfma_peak",
-    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_pack_conv_weights_x3", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_stemdown_supported", "aq_stemdown", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct", "aq_conv1x1_asm_supported", "aq_pack_conv1x1_asm", "aq_conv1x1_asm",
+    "aq_conv_config_tiles", "aq_pack_conv_weights", "aq_pack_conv_weights_x3", "aq_conv2d", "aq_pack_stem_weights", "aq_stem_conv", "aq_pack_bottleneck_weights", "aq_bottleneck", "aq_pack_downblock_weights", "aq_downblock", "aq_stemdown_supported", "aq_stemdown", "aq_conv1x1_direct_supported", "aq_pack_conv1x1_direct", "aq_conv1x1_direct", "aq_conv1x1_asm_supported", "aq_pack_conv1x1_asm", "aq_conv1x1_asm", "aq_nms_opts", "aq_engine_set_nms_options",
     "aq_conv3x3s2_direct_supported", "aq_pack_conv3x3s2_direct", "aq_conv3x3s2_direct",
     "aq_conv3x3_pl_supported", "aq_conv3x3_pl_asm_family", "aq_pack_conv3x3_pl", "aq_conv3x3_pl", "aq_conv3x3_pl_s2_supported", "aq_pack_conv3x3_pl_s2", "aq_conv3x3_pl_s2", "aq_jpeg_scratch_bytes", "aq_jpeg_idct_rgb", "aq_f32_to_e4m3", "aq_conv1x1_direct_f8out", "aq_absmax_bf16", "aq_engine_calibrate_amax", "aq_engine_set_fp8_scales", "aq_engine_last_launch", "aq_conv3x3_pl_f8_supported", "aq_pack_conv3x3_pl_f8", "aq_conv3x3_pl_f8", "aq_conv3x3_pl_w8_supported", "aq_pack_conv3x3_pl_w8", "aq_conv3x3_pl_w8", "aq_head_decode_supported", "aq_pack_head_weights", "aq_head_decode", "aq_head_counts_gather", "aq_preprocess_s2d", "aq_sppf_pool",
     "aq_upsample2x", "aq_letterbox_u8", "aq_letterbox_tiles_u8", "aq_format_label_rows", "aq_detect_decode", "aq_nms_scratch_bytes", "aq_nms", "aq_jpeg_huffman_decode", "aq_write_label_files",
@@ -127,6 +127,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.aq_conv1x1_direct_supported.argtypes = [i32, i32]
     lib.aq_pack_conv1x1_direct.argtypes = [C.POINTER(f32), i32, i32, vp, C.POINTER(sz), vp]
     lib.aq_conv1x1_direct.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, C.c_longlong, i32, vp]
+    lib.aq_nms_opts.argtypes = [vp, i32, i32, i32, i32, f32, f32, i32, vp, vp, i32, vp, vp, vp, i32, C.c_ulonglong, C.c_ulonglong, vp]
+    lib.aq_engine_set_nms_options.argtypes = [vp, i32, C.c_ulonglong, C.c_ulonglong]
     lib.aq_conv1x1_asm_supported.argtypes = [i32, i32]
     lib.aq_pack_conv1x1_asm.argtypes = [C.POINTER(f32), i32, i32, vp, C.POINTER(sz), vp]
     lib.aq_conv1x1_asm.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, C.c_longlong, i32, vp]
@@ -370,6 +372,11 @@ class Engine:
     def nms(self, pred: torch.Tensor, conf_thres=0.25, iou_thres=0.45, max_det=1000) -> Tuple[torch.Tensor, torch.Tensor]:
         return nms(pred, self.ck.nc, conf_thres, iou_thres, max_det)
 
+    def set_nms_options(self, agnostic: bool = False, classes: Optional[Sequence[int]] = None) -> None:
+        """detect.py's --agnostic-nms / --classes for the NMS step of infer() [UPSTREAM non_max_suppression(classes, agnostic)]."""
+        lo, hi = class_mask(classes, self.ck.nc)
+        _check(self.lib.aq_engine_set_nms_options(self.handle, int(bool(agnostic)), lo, hi))
+
     # ---- test / tuning hooks ----
     def tensor(self, tensor_id: int, B: int) -> torch.Tensor:
         """View of plan tensor ``tensor_id`` ([B,h,w,C]) inside the workspace after a call (tests only)."""
@@ -474,8 +481,21 @@ class Engine:
 # --------------------------------------------------------------------------------------
 # individual kernels (used by the parity tests; same C entry points the engine uses)
 # --------------------------------------------------------------------------------------
-def nms(pred: torch.Tensor, nc: int, conf_thres=0.25, iou_thres=0.45, max_det=1000) -> Tuple[torch.Tensor, torch.Tensor]:
-    """non_max_suppression(pred, conf, iou, classes=None, agnostic=False, multi_label=False, max_det) on device."""
+def class_mask(classes: Optional[Sequence[int]], nc: int) -> Tuple[int, int]:
+    """--classes as the two 64-bit words aq_nms_opts takes (None = every class)."""
+    if classes is None:
+        return (1 << 64) - 1, (1 << 64) - 1
+    m = 0
+    for c in classes:
+        if not 0 <= int(c) < min(nc, 128):
+            raise ValueError(f"--classes {c}: the model has classes 0 .. {nc - 1}")
+        m |= 1 << int(c)
+    return m & ((1 << 64) - 1), m >> 64
+
+
+def nms(pred: torch.Tensor, nc: int, conf_thres=0.25, iou_thres=0.45, max_det=1000, agnostic: bool = False,
+        classes: Optional[Sequence[int]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """non_max_suppression(pred, conf, iou, classes, agnostic, multi_label=False, max_det) on device."""
     _require_gpu()
     lib = load_library()
     if pred.dtype != torch.float32 or pred.dim() != 3 or not pred.is_cuda or not pred.is_contiguous():
@@ -486,8 +506,9 @@ def nms(pred: torch.Tensor, nc: int, conf_thres=0.25, iou_thres=0.45, max_det=10
     scratch = torch.empty(lib.aq_nms_scratch_bytes(B, N), dtype=torch.uint8, device=pred.device)
     dets = torch.empty((B, max_det, 6), dtype=torch.float32, device=pred.device)
     counts = torch.empty((B,), dtype=torch.int32, device=pred.device)
-    _check(lib.aq_nms(pred.data_ptr(), N, B, N, nc, conf_thres, iou_thres, max_det, None, None, 0,
-                      scratch.data_ptr(), dets.data_ptr(), counts.data_ptr(), _stream_ptr()))
+    lo, hi = class_mask(classes, nc)
+    _check(lib.aq_nms_opts(pred.data_ptr(), N, B, N, nc, conf_thres, iou_thres, max_det, None, None, 0,
+                           scratch.data_ptr(), dets.data_ptr(), counts.data_ptr(), int(bool(agnostic)), lo, hi, _stream_ptr()))
     return dets, counts
 
 

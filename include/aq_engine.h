@@ -373,6 +373,15 @@ size_t aq_nms_scratch_bytes(int B, int N);
 int aq_nms(const float* rows_dev, int rows_per_tile, int B, int N, int nc, float conf_thres, float iou_thres,
            int max_det, const int32_t* cand_dev, const int32_t* cand_count_dev, int cand_cap,
            void* scratch_dev, aq_det* dets_dev, int32_t* counts_dev, void* stream);
+/* aq_nms with upstream's two other options: agnostic != 0 = class-agnostic suppression (no per-class box offset); classes_lo / classes_hi = bit
+ * mask of the classes kept (bit c of lo, bit c - 64 of hi; all ones = no filter), applied after the confidence threshold as upstream's
+ * `x[(x[:, 5:6] == classes).any(1)]` [UPSTREAM utils/general.py non_max_suppression(classes, agnostic)]. */
+int aq_nms_opts(const float* rows_dev, int rows_per_tile, int B, int N, int nc, float conf_thres, float iou_thres,
+                int max_det, const int32_t* cand_dev, const int32_t* cand_count_dev, int cand_cap,
+                void* scratch_dev, aq_det* dets_dev, int32_t* counts_dev, int agnostic, unsigned long long classes_lo,
+                unsigned long long classes_hi, void* stream);
+/* The engine's NMS step (aq_engine_infer) with those options; defaults: agnostic = 0, every class. */
+int aq_engine_set_nms_options(aq_engine* e, int agnostic, unsigned long long classes_lo, unsigned long long classes_hi);
 
 /* Host helper: n label rows (cls xc yc w h conf, fp32, stride 6) -> the text detect.py --save-txt [--save-conf] writes
  * ("%g" per value, one line per row).  Returns bytes written or -(bytes needed). */

@@ -270,7 +270,7 @@ def greedy_nms(boxes: np.ndarray, iou_thres: float) -> List[int]:
 
 
 def non_max_suppression(pred: np.ndarray, conf_thres: float = 0.25, iou_thres: float = 0.45,
-                        max_det: int = 1000, agnostic: bool = False) -> List[np.ndarray]:
+                        max_det: int = 1000, agnostic: bool = False, classes=None) -> List[np.ndarray]:
     """[UPSTREAM non_max_suppression(pred, conf, iou, classes=None, agnostic, multi_label=False, max_det)].
 
     Returns per image an (n,6) fp32 array [x1,y1,x2,y2,conf,cls] in descending confidence.
@@ -291,6 +291,9 @@ def non_max_suppression(pred: np.ndarray, conf_thres: float = 0.25, iou_thres: f
         conf = x[np.arange(x.shape[0]), 5 + j]
         m = conf > ct
         box, conf, j = box[m], conf[m], j[m].astype(np.float32)
+        if classes is not None:                    # [UPSTREAM: x = x[(x[:, 5:6] == torch.tensor(classes)).any(1)]]
+            m = np.isin(j, np.asarray(classes, dtype=np.float32))
+            box, conf, j = box[m], conf[m], j[m]
         if not box.shape[0]:
             out.append(np.zeros((0, 6), np.float32))
             continue

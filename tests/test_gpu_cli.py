@@ -67,6 +67,27 @@ def test_cli_writes_labels_the_consumer_can_parse(workdir, lib):
     assert total > 500 and same >= 0.995 * total
 
 
+def test_cli_classes_and_agnostic_nms(workdir, lib):
+    """--classes keeps exactly the listed classes' lines (per-class suppression does not see the other classes); --agnostic-nms lets boxes of
+    different classes suppress each other: fewer lines on the synthetic head, which stacks classes on the same spots (the kernel's agreement
+    with the oracle, bit for bit, is tests/test_gpu_nms.py).  [UPSTREAM detect.py: non_max_suppression(pred, conf, iou, classes, agnostic_nms, max_det)]"""
+    _, ref = _run(workdir, "nmsopt_ref", extra=("--half",))
+    _, flt = _run(workdir, "nmsopt_cls", extra=("--half", "--classes", "1", "3"))
+    _, agn = _run(workdir, "nmsopt_agn", extra=("--half", "--agnostic-nms"))
+    n_ref = n_agn = 0
+    assert os.listdir(ref)
+    for f in sorted(os.listdir(ref)):
+        lines = open(ref / f).read().splitlines()
+        want = [l for l in lines if l.split()[0] in ("1", "3")]
+        got = open(flt / f).read().splitlines() if os.path.exists(flt / f) else []
+        assert got == want, f
+        a = open(agn / f).read().splitlines() if os.path.exists(agn / f) else []
+        assert all(len(l.split()) == 6 for l in a), f
+        n_ref += len(lines)
+        n_agn += len(a)
+    assert 0 < n_agn < n_ref                                   # the synthetic head stacks classes on the same spots
+
+
 def test_cli_two_ranks_write_the_same_label_set(workdir, lib):
     """torchrun with 2 ranks (both on the one GPU, gloo as the rehearsal backend): strided shard + final gather;
     the union of the ranks' label files equals the single-process run byte for byte (tiles are independent)."""

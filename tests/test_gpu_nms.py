@@ -18,11 +18,11 @@ def _pred(boxes_xywh, obj, cls_conf):
     return p
 
 
-def _run(pred, conf=0.25, iou=0.45, max_det=1000):
+def _run(pred, conf=0.25, iou=0.45, max_det=1000, agnostic=False, classes=None):
     from aquaculture_amd import engine
     from oracle import yolov5_oracle as O
-    ref = O.non_max_suppression(pred, conf, iou, max_det)
-    dets, counts = engine.nms(torch.from_numpy(pred).cuda().contiguous(), NC, conf, iou, max_det)
+    ref = O.non_max_suppression(pred, conf, iou, max_det, agnostic=agnostic, classes=classes)
+    dets, counts = engine.nms(torch.from_numpy(pred).cuda().contiguous(), NC, conf, iou, max_det, agnostic=agnostic, classes=classes)
     dets, counts = dets.cpu().numpy(), counts.cpu().numpy()
     for b, r in enumerate(ref):
         assert counts[b] == r.shape[0], (counts[b], r.shape[0])
@@ -69,6 +69,28 @@ def test_cross_class_overlap_is_not_suppressed(lib):
     cls = np.array([[0.9, 0, 0, 0, 0], [0, 0.9, 0, 0, 0], [0.8, 0, 0, 0, 0]], np.float32)
     r = _run(_pred(boxes, 0.9, cls))[0]
     assert r.shape[0] == 2 and set(r[:, 5]) == {0.0, 1.0}
+
+
+def test_agnostic_and_class_filter(lib):
+    """detect.py --agnostic-nms / --classes [UPSTREAM non_max_suppression(classes, agnostic)]: with agnostic the class-0 and class-1 boxes on
+    the same spot suppress each other; a class filter removes the other classes' candidates before the suppression."""
+    boxes = [[200, 200, 50, 50], [200, 200, 50, 50], [201, 200, 50, 50], [400, 400, 30, 30]]
+    cls = np.array([[0.9, 0, 0, 0, 0], [0, 0.95, 0, 0, 0], [0.8, 0, 0, 0, 0], [0, 0, 0, 0.7, 0]], np.float32)
+    p = _pred(boxes, 0.9, cls)
+    r = _run(p, agnostic=True)[0]
+    assert r.shape[0] == 2 and list(r[:, 5]) == [1.0, 3.0]            # the class-1 box wins the spot, the far class-3 box stays
+    r = _run(p, classes=[0, 3])[0]
+    assert r.shape[0] == 2 and set(r[:, 5]) == {0.0, 3.0}
+    assert _run(p, classes=[4])[0].shape[0] == 0
+    r = _run(p, agnostic=True, classes=[0, 3])[0]
+    assert r.shape[0] == 2 and set(r[:, 5]) == {0.0, 3.0}
+    rng = np.random.default_rng(11)
+    for n in (700, 3000):                                             # both the bit-matrix path and the greedy fallback
+        q = _random_pred(rng, n, B=2)
+        q[..., 4] = rng.uniform(0.5, 1.0, q.shape[:2])
+        q[..., 5:] = rng.uniform(0.6, 1.0, q.shape[:2] + (NC,))
+        assert all(x.shape[0] > 5 for x in _run(q, agnostic=True))
+        assert all(x.shape[0] > 5 and set(x[:, 5]) <= {1.0, 2.0} for x in _run(q, classes=[1, 2]))
 
 
 def test_max_det_truncation(lib):
