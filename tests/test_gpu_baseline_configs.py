@@ -63,6 +63,9 @@ def test_configs3_fp8_engine_at_batch_128(lib, synth_ck):
     assert {fam128[i][0] for i in others} <= {"pl3x3s2", "direct3x3s2", "igemm_or_halo"}, [(eng.plan.ops[i].name, fam128[i]) for i in others]
     assert sum(fam128[i][0] == "pl3x3s2" for i in others) == 4                  # model.5 / 7 / 18 / 21 on the planar stride-2 family
     assert sum(f == "bottleneck" for f, _ in fam128) == 8 and sum(f == "downblock" for f, _ in fam128) == 1 and sum(f == "head_decode" for f, _ in fam128) == 3
+    # the eight 1x1 layers with K >= 768 (model.8 / 23 cv1|cv2 and cv3, SPPF cv1 / cv2, model.10, model.13 cv1|cv2) on the assembly 1x1 of round 4
+    wide = [i for i, o in enumerate(eng.plan.ops) if o.kind == 1 and o.k == 1 and o.level < 0 and o.src.channels >= 768]
+    assert len(wide) == 8 and all(fam128[i][0] == "asm1x1" for i in wide), [(eng.plan.ops[i].name, fam128[i]) for i in wide]
     assert int(c128.sum()) > 2000
     nms_invariants(d128, c128, 0.25, 0.45, 1000, 5)
     for rep in range(1, 8):                                                     # the 8 copies of each tile agree, box for box
