@@ -98,7 +98,8 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
                         "gpu: the Huffman stage on the GPU as well (one lane per image, super-batches of AQ_JPEG_GPU_SUPERBATCH = 2048 tiles in "
                         "flight): the host only reads the files and strips byte stuffing, H2D carries the files' entropy-coded bytes; "
                         "auto: split when every image of the sweep qualifies, gpu when this rank's share is also >= AQ_JPEG_GPU_AUTO_MIN = "
-                        "32768 images (the super-batches cost a second of start-up and pay off at 1.15-1.3 x the steady rate; same label bytes)")
+                        "131072 images (measured on 65,536 1024-px tiles: gpu 10.4 k images/s steady but 2.0 s of start-up -- pinned super-batch "
+                        "buffers, the first 53-ms decode launches -- against split's 9.3 k and 0.6 s: break-even near 120 k images; same label bytes)")
     p.add_argument("--resume", action="store_true",
                    help="continue an interrupted sweep in project/name (implies --exist-ok): tiles recorded in the run directory's "
                         "done.rank*.txt manifests are skipped, also those that produced no label file")
@@ -448,7 +449,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                                          f"(use auto or host): {', '.join(bad[:3])}{' ...' if len(bad) > 3 else ''}")
                 if jpeg_decode == "gpu" and not split:
                     raise ValueError("--jpeg-decode gpu needs baseline 4:2:0 JPEGs throughout (use auto or host)")
-                use_gpu = jpeg_decode == "gpu" or (jpeg_decode == "auto" and split and len(sub) >= int(os.environ.get("AQ_JPEG_GPU_AUTO_MIN", 32768)))
+                use_gpu = jpeg_decode == "gpu" or (jpeg_decode == "auto" and split and len(sub) >= int(os.environ.get("AQ_JPEG_GPU_AUTO_MIN", 131072)))
                 if split and not split_note[0]:
                     split_note[0] = True
                     log(f"jpeg decode: split (entropy decoding in {sub.workers} worker processes, IDCT / upsampling / colour conversion on the GPU)"
