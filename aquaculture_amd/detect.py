@@ -98,8 +98,8 @@ def parse_opt(argv: Optional[List[str]] = None) -> argparse.Namespace:
                         "gpu: the Huffman stage on the GPU as well (one lane per image, super-batches of AQ_JPEG_GPU_SUPERBATCH = 2048 tiles in "
                         "flight): the host only reads the files and strips byte stuffing, H2D carries the files' entropy-coded bytes; "
                         "auto: split when every image of the sweep qualifies, gpu when this rank's share is also >= AQ_JPEG_GPU_AUTO_MIN = "
-                        "131072 images (measured on 65,536 1024-px tiles: gpu 10.4 k images/s steady but 2.0 s of start-up -- pinned super-batch "
-                        "buffers, the first 53-ms decode launches -- against split's 9.3 k and 0.6 s: break-even near 120 k images; same label bytes)")
+                        "32768 images (measured on 65,536 1024-px tiles: gpu 10.4 k images/s steady and 0.84 s of start-up against split's 9.4 k "
+                        "and 0.48 s -- 9.19 k vs 8.81 k over the whole sweep, break-even near 35 k images; same label bytes)")
     p.add_argument("--resume", action="store_true",
                    help="continue an interrupted sweep in project/name (implies --exist-ok): tiles recorded in the run directory's "
                         "done.rank*.txt manifests are skipped, also those that produced no label file")
@@ -351,11 +351,21 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
             s_ += size
             size = min(SB, size * 2)
         NB = min(NB, len(chunks))
-        host = [torch.zeros(SB * per + 256, dtype=torch.uint8).pin_memory() for _ in range(NB)]
-        batches_h = [aqjpeg.GpuDecodeBatch(SB, H0, W0, stream_buf=h.numpy(), bytes_per_image=per) for h in host]
-        dev_streams = [torch.empty(SB * per + 256, dtype=torch.uint8, device=dev) for _ in range(NB)]
-        dev_coef = [torch.empty(SB * nco, dtype=torch.int16, device=dev) for _ in range(NB)]
-        status_h = [torch.zeros(SB * aqjpeg.GpuDecodeBatch.SEG_CAP, dtype=torch.int32).pin_memory() for _ in range(NB)]
+        # Buffer set i is created when super-batch i is first prepared -- the pool thread is already reading files into set 0 while the main
+        # thread allocates set 1 -- and sized for the largest super-batch it will ever hold (i, i + NB, ...: the ramp's small ones stay small
+        # in a short sweep).  Pinned memory is allocated as such (torch.empty(pin_memory=True)): `zeros().pin_memory()` touched and copied
+        # 2.7 GB at start-up, 1.4 of the 2.0 s the mode lost to the split path before its first batch (65 k-image sweep, round 4).
+        host, batches_h, dev_streams, dev_coef, status_h = [None] * NB, [None] * NB, [None] * NB, [None] * NB, [None] * NB
+
+        def make_set(i):
+            cap = max(len(chunks[k_]) for k_ in range(i, len(chunks), NB))
+            cap = (cap + batch_size - 1) // batch_size * batch_size
+            host[i] = torch.empty(cap * per + 256, dtype=torch.uint8, pin_memory=True)
+            host[i][-256:].zero_()
+            batches_h[i] = aqjpeg.GpuDecodeBatch(cap, H0, W0, stream_buf=host[i].numpy(), bytes_per_image=per)
+            dev_streams[i] = torch.empty(cap * per + 256, dtype=torch.uint8, device=dev)
+            dev_coef[i] = torch.empty(cap * nco, dtype=torch.int16, device=dev)
+            status_h[i] = torch.zeros(cap * aqjpeg.GpuDecodeBatch.SEG_CAP, dtype=torch.int32, pin_memory=True)
         dstreams = [torch.cuda.Stream() for _ in range(NB)]
         consumed = [[] for _ in range(NB)]                 # events of the batches that read buffer i: its next decode waits for them
         nthreads = max(2, min(sub.workers, 16))
@@ -388,6 +398,8 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
             next_prep = next_launch = 0
             for k in range(len(chunks)):
                 while next_prep < len(chunks) and next_prep < k + NB:          # (buffer next_prep % NB was last used by super-batch next_prep - NB < k)
+                    if host[next_prep % NB] is None:
+                        make_set(next_prep % NB)
                     futures[next_prep] = pool.submit(batches_h[next_prep % NB].prepare_files, chunks[next_prep], nthreads)
                     next_prep += 1
                 while next_launch < len(chunks) and next_launch <= k + D:
@@ -449,7 +461,7 @@ def run(weights, source, imgsz=(640, 640), conf_thres=0.25, iou_thres=0.45, max_
                                          f"(use auto or host): {', '.join(bad[:3])}{' ...' if len(bad) > 3 else ''}")
                 if jpeg_decode == "gpu" and not split:
                     raise ValueError("--jpeg-decode gpu needs baseline 4:2:0 JPEGs throughout (use auto or host)")
-                use_gpu = jpeg_decode == "gpu" or (jpeg_decode == "auto" and split and len(sub) >= int(os.environ.get("AQ_JPEG_GPU_AUTO_MIN", 131072)))
+                use_gpu = jpeg_decode == "gpu" or (jpeg_decode == "auto" and split and len(sub) >= int(os.environ.get("AQ_JPEG_GPU_AUTO_MIN", 32768)))
                 if split and not split_note[0]:
                     split_note[0] = True
                     log(f"jpeg decode: split (entropy decoding in {sub.workers} worker processes, IDCT / upsampling / colour conversion on the GPU)"

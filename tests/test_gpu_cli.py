@@ -445,7 +445,7 @@ def test_gpu_jpeg_decode_gives_identical_labels(workdir, lib, tmp_path):
     import shutil
     out_h, lab_h = _run(workdir, "gjpeg_host", extra=("--quiet", "--half", "--jpeg-decode", "host"))
     out_g, lab_g = _run(workdir, "gjpeg_gpu", extra=("--quiet", "--half", "--jpeg-decode", "gpu"), env={"AQ_JPEG_GPU_SUPERBATCH": "4"})
-    # `auto` takes the GPU decoder once this rank's share reaches AQ_JPEG_GPU_AUTO_MIN images (131,072 by default: the split path below that)
+    # `auto` takes the GPU decoder once this rank's share reaches AQ_JPEG_GPU_AUTO_MIN images (32,768 by default: the split path below that)
     out_a, lab_a = _run(workdir, "gjpeg_auto", extra=("--quiet", "--half"), env={"AQ_JPEG_GPU_AUTO_MIN": "1"})
     assert "jpeg decode: gpu" in out_g and "jpeg decode: gpu" in out_a
     names = sorted(os.listdir(lab_h))
