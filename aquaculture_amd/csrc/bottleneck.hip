@@ -21,6 +21,10 @@
 //     LDS traffic, but the compiler parks most of W2 in AccVGPRs and copies each fragment back before use, and a single
 //     instruction stream per SIMD serialises MFMA issue, SiLU and LDS latency -- issue-bound.
 // Both run at ~28 cycles per MFMA (16 is the pipe rate); the 12-wave shapes are a few percent faster on yolov5m.
+// Round 4: yolov5m's two widths run in generated assembly instead -- C = 48: gen_bottleneck_asm.py (8 waves, every wave all three M blocks and
+// all the weights, the two waves of a SIMD half a tile out of step); C = 96: gen_bottleneck96_asm.py (4 waves, 81 + 9 fragments per wave
+// resident, 64 of them in AGPRs) -- the "wide" idea with the registers and the instruction order assigned by hand.  Their host side is at the
+// end of this file; the HIP kernel stays as the specification and the fallback.
 // The output must not alias the input (neighbouring tiles read each other's halo): the plan ping-pongs Bottleneck pairs
 // between the C3 concat buffer and its temporary.
 #include "conv_device.h"
@@ -505,8 +509,9 @@ int g_btl_cus = 0;
 
 struct BtlShape { int mbw, msplit, nw, tw, ktail; bool w1reg, resg; };
 
-// Tile shapes.  C = 48 and 96 (yolov5m) run "one M block per wave": 12 waves (3 per SIMD, <= 168 registers each, weights in
-// plain VGPRs), every wave computes 16 output channels for the 4 rows x 16 pixels of its pixel group.  AQ_BTL_WIDE=1 selects
+// Tile shapes of the HIP-source kernel (since round 4 the fallback for C = 48 / 96: images narrower than two tiles, AQ_BTL_ASM=0 -- the
+// generated-assembly kernels further down take yolov5m's launches).  C = 48 and 96 run "one M block per wave": 12 waves (3 per SIMD, <= 168
+// registers each, weights in plain VGPRs), every wave computes 16 output channels for the 4 rows x 16 pixels of its pixel group.  AQ_BTL_WIDE=1 selects
 // the earlier 4-wave shapes (3 M blocks per wave, ~500 registers, one wave per SIMD) for A/B runs; the packed weight image
 // depends on the shape, so the choice is made once per process.
 bool btl_wide() {

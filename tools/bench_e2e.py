@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--jpeg-decode", default="auto", choices=("auto", "host", "split", "gpu"))
     ap.add_argument("--noise", type=float, default=0.0, help="Gaussian sensor noise (sigma, 8-bit levels) added before the JPEG encoder: the synthetic tiles are smooth "
                                                              "(0.3 bit per pixel at q75); sigma 10 gives 1.1 bpp, about what detailed aerial imagery compresses to")
+    ap.add_argument("--conf-thres", type=float, default=0.25, help="detect.py --conf-thres: the synthetic checkpoint yields ~340 detections per tile at the default 0.25 "
+                                                                   "(label formatting and writing then cost as much host time as the decode); real sweeps "
+                                                                   "find a handful per tile -- raise it to see the sweep without that load")
     ap.add_argument("--json", default="", help="append this run's numbers to a JSON file (profiles/e2e_latest.json: bench.py quotes it as `e2e`)")
     a = ap.parse_args()
     from aquaculture_amd import checkpoint, tiles
@@ -65,7 +68,7 @@ def main():
         checkpoint.write_synthetic_checkpoint(w, "yolov5m", 5)
     cmd = [sys.executable, os.path.join(ROOT, "yolov5", "detect.py"), "--weights", w, "--source", jp, "--nosave", "--save-txt", "--save-conf",
            "--project", os.path.join(a.dir, "runs"), "--name", "e2e", "--batch-size", str(a.batch_size), "--workers", str(a.workers),
-           "--precision", a.precision, "--quiet", "--jpeg-decode", a.jpeg_decode] + (["--decode-threads"] if a.decode_threads else []) + (["--tile-scenes"] if a.scenes else [])
+           "--precision", a.precision, "--quiet", "--jpeg-decode", a.jpeg_decode, "--conf-thres", str(a.conf_thres)] + (["--decode-threads"] if a.decode_threads else []) + (["--tile-scenes"] if a.scenes else [])
     t0 = time.perf_counter()
     r = subprocess.run(cmd, capture_output=True, text=True)
     dt = time.perf_counter() - t0
