@@ -112,6 +112,26 @@ def configure(nb):
     g["PM"] = False
     g["WFIX"] = 0
     g.update(CONFIGS[nb])
+    import os as _os0
+    # A_ACC (experiment, AQ_GEN_A_ACC=1, pixel-major bf16 families): the weight sets live in the accumulator half of the register file and
+    # the residual in VGPRs (instead of the other way round) -- the weight loads' returns then do not write the VGPR banks the MFMAs read
+    # their B operands from, and the epilogue reads the residual without v_accvgpr_read.
+    g["A_ACC"] = bool(PM and not F8 and _os0.environ.get("AQ_GEN_A_ACC", "0") == "1")
+    g["RES_ACC"] = bool((F8 or PM) and not A_ACC)          # the residual waits in the accumulator file
+    # W16 (round 4, AQ_GEN_W16=0 restores the 8-byte stores): the epilogue's output stores as 16 bytes per lane.  A wave's three stores per
+    # pixel block (8 bytes per lane: this lane's four channels of an M block) are store-ISSUE bound, not bandwidth bound -- the stamped
+    # ablations: epilogue 20.1 k cycles per wave (two tiles), without the stores 12.6 k, the stores alone 18.7 k = 240 cycles per 512-byte
+    # instruction (cdna_hip_programming.md T21 saw the same on an attention tail).  v_permlane16_swap_b32 (lanes 16-31 / 48-63 of vdst <->
+    # lanes 0-15 / 32-47 of src; tools/ubench/permlane16_swap.hip) pairs the 8-byte pieces of lanes q and q + 1 (same pixel, adjacent
+    # channels): M blocks 0 and 1 of a pixel block leave in ONE 16-byte store (even-q lanes: block 0's 16 bytes, odd-q lanes: block 1's),
+    # M block 2 of pixel blocks j and j + 1 in one more: 20 store instructions per tile instead of 39, same bytes, same addresses.
+    g["W16"] = bool((PM or S2 or F8) and _os0.environ.get("AQ_GEN_W16", "1") == "1")
+    # EP3 (experiment, AQ_GEN_EP3=1): the epilogue runs the three M blocks of a pixel block as three interleaved chains instead of two + one
+    g["EP3"] = bool(PM and not F8 and _os0.environ.get("AQ_GEN_EP3", "0") == "1")
+    # EARLY_SETUP (round 4; AQ_GEN_EARLY_SETUP=0 restores the old order): a workgroup's FIRST tile computes its addresses (some 700 VALU
+    # instructions) between the prologue's loads and the wait for them instead of behind the first barrier.  Stamped, cycles per wave:
+    # 192 ch @ 40x40 lifetime 122.1 k -> 119.1 k (tile set-up 6.9 k -> 3.9 k, prologue 5.6 k -> 6.8 k), 384 ch @ 20x20 100.1 k -> 98.8 k.
+    g["EARLY_SETUP"] = bool(_os0.environ.get("AQ_GEN_EARLY_SETUP", "1") == "1")
     g["NT"] = 5 if F8 else 9                   # MFMA steps per chunk that take their own weight fragments: taps, or (fp8) tap pairs
     g["FAMILY"] = f"nb{nb}" if isinstance(nb, int) else nb
     g["NE"] = NT * KS * NB
@@ -244,7 +264,7 @@ def allocate_registers():
     V.alloc("insp")               # in_sp (low 32 bits) as a VGPR operand of v_mad_u64_u32
     V.alloc("zero_lo")
     V.alloc("zero_hi")
-    if True:                      # (kept as a block: the weight sets come first among the big arrays)
+    if not A_ACC:                 # (kept as a block: the weight sets come first among the big arrays)
         V.alloc("A", (24 if F8 else 12 * KS) * (LOOK + 1), 4)
     V.alloc("B", (8 if F8 else 4) * (PD + 1), 4)
     V.alloc("addr", 4 * NB if S2 else 3 * NB if PM else NB)      # (stride 2: per pixel block one swizzled address per (row, column) offset of the taps; pixel-major: per column offset)
@@ -256,10 +276,12 @@ def allocate_registers():
         V.alloc("voff", NDMA)     # per LDS-DMA instruction of a chunk: this lane's byte offset into the parity plane, or beyond the descriptor
         V.alloc("bpa", 4)         # ds_bpermute addresses: lane (16 m + lane / 4) * 4, m = 0 .. 3
         V.alloc("qoff")           # 16 x the channel group this lane fetches: (lane & 3) ^ 2 ((lane >> 4) & 1)  (pixel-major: 16 (lane & 3), the swizzle bit comes with the row)
-    if RES_EARLY and not S2 and not F8 and not PM:
+    if RES_EARLY and not S2 and not RES_ACC:
         V.alloc("R", 6 * NB, 2)
     V.alloc("oo", NB)
-    V.alloc("t", 24, 4)           # temporaries
+    V.alloc("t", 36 if EP3 else 24, 4)           # temporaries
+    if W16:
+        V.alloc("cst", 4, 4)      # packed outputs of M block 2 of an even / odd pixel block, waiting for their 16-byte store
 
 
 def s(name, i=0):
@@ -293,7 +315,7 @@ def vr(name, i, cnt):
 
 def rreg(b):
     """First register of residual pair b (0 .. 3 NB - 1): its own block, or (two-workgroup families) weight set 2 and then the B ring."""
-    if F8 or PM:
+    if RES_ACC:
         return 12 * NB + 2 * b                             # (accumulator-file register number)
     if RES_EARLY:
         return V.names["R"][0] + 2 * b
@@ -307,6 +329,9 @@ def areg(set_idx, k):
         assert 0 <= set_idx <= LOOK and 0 <= k < 3
         return vr("A", 24 * set_idx + 8 * k, 8)
     assert 0 <= set_idx <= LOOK and 0 <= k < 3 * KS
+    if A_ACC:                                              # behind the accumulators
+        b = 12 * NB + 12 * KS * set_idx + 4 * k
+        return f"a[{b}:{b + 3}]"
     return vr("A", 12 * KS * set_idx + 4 * k, 4)
 
 
@@ -337,7 +362,7 @@ def emit_convert(tap, ks, i, step):
 
 
 def n_acc():
-    return 12 * NB + (6 * NB if F8 or PM else 0)
+    return 12 * NB + (6 * NB if RES_ACC else 0) + (12 * KS * (LOOK + 1) if A_ACC else 0)
 
 
 def acc(i, j):
@@ -640,7 +665,7 @@ def stamp(k):
 
 def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     """abl: timing-only ablations of the stamped build (wrong results): 1 = no weight loads in the stream, 2 = no LDS-DMA in the stream,
-    4 = no B fragment reads, 8 = no MFMAs."""
+    4 = no B fragment reads, 8 = no MFMAs, 128 = no output stores, 256 = no epilogue arithmetic (stores only)."""
     global out, W8, STEP_B
     out = []
     STAMPED[0] = stamped
@@ -766,6 +791,73 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_add_u32 {s('tile')}, {s('tile')}, {s('tmp3')}")
     E(f"s_cmp_ge_u32 {s('tile')}, {s('ntiles')}")
     E("s_cbranch_scc1 .Lend_" + name)
+    def emit_setup_addr():
+        """Per tile: n0, cbase, next_tile, rs, and this lane's fragment addresses addr[] and output offsets oo[] (VALU only, no memory)."""
+        E(f"s_lshr_b32 {s('tmp1')}, {s('tile')}, {s('mt_log2')}")
+        E(f"s_lshl_b32 {s('tmp0')}, {s('tmp1')}, {s('mt_log2')}")
+        E(f"s_sub_u32 {s('tmp2')}, {s('tile')}, {s('tmp0')}")
+        E(f"s_mul_i32 {s('n0')}, {s('tmp1')}, {NB * 16}")
+        E(f"s_add_u32 {s('next_tile')}, {s('tile')}, {s('G')}")
+        E(f"s_cmp_lt_u32 {s('next_tile')}, {s('ntiles')}")
+        E(f"s_cselect_b32 {s('has_next')}, 1, 0")
+        E(f"s_mul_i32 {s('cbase')}, {s('tmp2')}, 192")
+        E(f"s_mul_i32 {s('tmp0')}, {s('wave')}, 48")
+        E(f"s_add_u32 {s('cbase')}, {s('cbase')}, {s('tmp0')}")
+        emit_rs_of_tile(s("tile"), s("rs"))
+        # addr[j] = q PS + (pp_of(P_j) - rs - Wp - 1) * 16 + buf * CHUNK ;  oo[j] = P_j * out_ld + (cbase + 4 q) * 2 ; omask[j]
+        E(f"s_sub_u32 {s('tmp1')}, {s('npix')}, 1")
+        E(f"s_add_u32 {s('tmp2')}, {s('rs')}, {s('Wp')}")
+        E(f"s_add_u32 {s('tmp2')}, {s('tmp2')}, 1", "rs + Wp + 1")
+        E(f"s_mul_i32 {s('tmp3')}, {s('buf')}, {CHUNK}")
+        if S2:
+            E(f"s_add_u32 {s('tmp0')}, {s('dRow')}, 64", "one row down and one column right")
+        E(f"v_lshl_add_u32 {T[7]}, {v('q')}, 2, {s('cbase')}", "cbase + 4 q")
+        E(f"v_lshlrev_b32 {T[7]}, 1, {T[7]}", "bytes")
+        for j in range(NB):
+            E(f"v_add_u32 {T[4]}, {s('n0')}, {v('l15')}")
+            if j:
+                E(f"v_add_u32 {T[4]}, {16 * j}, {T[4]}")
+            E(f"v_min_i32 {T[4]}, {s('tmp1')}, {T[4]}", "clamp")
+            E(f"v_mul_lo_u32 {v('oo', j)}, {T[4]}, {s('out_ld')}")
+            E(f"v_add_u32 {v('oo', j)}, {v('oo', j)}, {T[7]}")
+            emit_pp_of(T[5], T[4], T[0], T[1], T[2], T[3])
+            E(f"v_subrev_u32 {T[5]}, {s('tmp2')}, {T[5]}")
+            if PM:
+                # three swizzled addresses per pixel block, one per column offset dx of the taps: region row (upper left neighbour) + dx, 64 B per
+                # row, channel group q at position q ^ 2 b with b = bit 2 of that row's column x - 1 + dx (a padding column holds zeros at every
+                # position); + the ring buffer.  emit_pp_of leaves rem = y W + x in T[1] and y in T[2].
+                E(f"v_mul_lo_u32 {T[0]}, {T[2]}, {s('W')}")
+                E(f"v_sub_u32 {T[0]}, {T[1]}, {T[0]}", "x")
+                E(f"v_lshl_add_u32 {T[5]}, {T[5]}, 6, {s('tmp3')}", "byte address of the row in this tile's first ring buffer")
+                for dx in range(3):
+                    E(f"v_add_u32 {T[1]}, {dx - 1}, {T[0]}")
+                    E(f"v_bfe_u32 {T[1]}, {T[1]}, 2, 1", "b")
+                    E(f"v_lshlrev_b32 {T[1]}, 5, {T[1]}")
+                    E(f"v_xor_b32 {T[1]}, {T[1]}, {v('qps')}", "16 (q ^ 2 b)")
+                    E(f"v_add_u32 {T[1]}, {T[5]}, {T[1]}")
+                    E(f"v_add_u32 {v('addr', 3 * j + dx)}, {64 * dx}, {T[1]}")
+                continue
+            if F8:
+                # linear byte address of (upper left neighbour's row, this lane's 32-byte channel half), in the tile's first ring buffer;
+                # the tap offset and the swizzle are applied where the fragment is read
+                E(f"v_lshl_add_u32 {T[5]}, {T[5]}, 6, {v('qps')}", "qps = 32 (q & 1) here")
+                E(f"v_add_u32 {v('addr', j)}, {s('tmp3')}, {T[5]}")
+                continue
+            if S2:
+                # four swizzled addresses per pixel block: region row (upper left neighbour) + (ry Wp + rx), 64 B per row, channel group q at
+                # position q ^ 2 bit2(row): byte bit 5 ^= byte bit 8; + the ring buffer
+                E(f"v_lshl_add_u32 {T[5]}, {T[5]}, 6, {v('qps')}", "linear byte address of (row, group q): qps = 16 q here")
+                for o in range(4):
+                    src = T[5]
+                    if o:
+                        E(f"v_add_u32 {T[0]}, {s('dRow') if o == 2 else (64 if o == 1 else s('tmp0'))}, {T[5]}")
+                        src = T[0]
+                    E(f"v_lshrrev_b32 {T[1]}, 3, {src}")
+                    E(f"v_and_b32 {T[1]}, 32, {T[1]}")
+                    E(f"v_xad_u32 {v('addr', 4 * j + o)}, {src}, {T[1]}, {s('tmp3')}")
+                continue
+            E(f"v_lshl_add_u32 {v('addr', j)}, {T[5]}, 4, {v('qps')}")
+            E(f"v_add_u32 {v('addr', j)}, {s('tmp3')}, {v('addr', j)}")
     # ---- prologue: weights of taps 0 and 1, chunks 0 and 1 of the region, the bias ----
     E(f"s_mov_b32 {s('c')}, 0")
     emit_a_stream_base("a_cur", s("tile"), s("c"))
@@ -814,6 +906,11 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         E(f"s_mov_b32 m0, {s('tmp0')}")
         E("s_nop 0", "hz: s_mov m0 -> LDS-DMA")
         E(f"global_load_lds_dwordx4 v[{V.names['t'][0] + 4}:{V.names['t'][0] + 5}], off")
+    if EARLY_SETUP:
+        # the first tile's address arithmetic (some 600 VALU instructions) between the prologue's loads and the wait for them
+        E(f"s_mov_b32 {s('buf')}, 0")
+        E(f"s_mov_b32 {s('first')}, 1")
+        emit_setup_addr()
     E("s_waitcnt vmcnt(0)", "weights of the first taps, chunk 0, the bias")
     emit_barrier()
     if w8:
@@ -834,76 +931,17 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             for s2i in range(PPW):
                 emit_dma(k, s2i, s("cd"), s("bd"))
     stamp(PH_PROLOGUE)
-    E(f"s_mov_b32 {s('buf')}, 0")
-    E(f"s_mov_b32 {s('first')}, 1")
+    if not EARLY_SETUP:
+        E(f"s_mov_b32 {s('buf')}, 0")
+        E(f"s_mov_b32 {s('first')}, 1")
+    else:
+        E(f"s_branch .Ltile_bias_{name}", "the first tile's addresses were computed under the prologue's loads")
 
     # =========================================== tile loop ===========================================
     label(".Ltile_" + name)
-    E(f"s_lshr_b32 {s('tmp1')}, {s('tile')}, {s('mt_log2')}")
-    E(f"s_lshl_b32 {s('tmp0')}, {s('tmp1')}, {s('mt_log2')}")
-    E(f"s_sub_u32 {s('tmp2')}, {s('tile')}, {s('tmp0')}")
-    E(f"s_mul_i32 {s('n0')}, {s('tmp1')}, {NB * 16}")
-    E(f"s_add_u32 {s('next_tile')}, {s('tile')}, {s('G')}")
-    E(f"s_cmp_lt_u32 {s('next_tile')}, {s('ntiles')}")
-    E(f"s_cselect_b32 {s('has_next')}, 1, 0")
-    E(f"s_mul_i32 {s('cbase')}, {s('tmp2')}, 192")
-    E(f"s_mul_i32 {s('tmp0')}, {s('wave')}, 48")
-    E(f"s_add_u32 {s('cbase')}, {s('cbase')}, {s('tmp0')}")
-    emit_rs_of_tile(s("tile"), s("rs"))
-    # addr[j] = q PS + (pp_of(P_j) - rs - Wp - 1) * 16 + buf * CHUNK ;  oo[j] = P_j * out_ld + (cbase + 4 q) * 2 ; omask[j]
-    E(f"s_sub_u32 {s('tmp1')}, {s('npix')}, 1")
-    E(f"s_add_u32 {s('tmp2')}, {s('rs')}, {s('Wp')}")
-    E(f"s_add_u32 {s('tmp2')}, {s('tmp2')}, 1", "rs + Wp + 1")
-    E(f"s_mul_i32 {s('tmp3')}, {s('buf')}, {CHUNK}")
-    if S2:
-        E(f"s_add_u32 {s('tmp0')}, {s('dRow')}, 64", "one row down and one column right")
-    E(f"v_lshl_add_u32 {T[7]}, {v('q')}, 2, {s('cbase')}", "cbase + 4 q")
-    E(f"v_lshlrev_b32 {T[7]}, 1, {T[7]}", "bytes")
-    for j in range(NB):
-        E(f"v_add_u32 {T[4]}, {s('n0')}, {v('l15')}")
-        if j:
-            E(f"v_add_u32 {T[4]}, {16 * j}, {T[4]}")
-        E(f"v_min_i32 {T[4]}, {s('tmp1')}, {T[4]}", "clamp")
-        E(f"v_mul_lo_u32 {v('oo', j)}, {T[4]}, {s('out_ld')}")
-        E(f"v_add_u32 {v('oo', j)}, {v('oo', j)}, {T[7]}")
-        emit_pp_of(T[5], T[4], T[0], T[1], T[2], T[3])
-        E(f"v_subrev_u32 {T[5]}, {s('tmp2')}, {T[5]}")
-        if PM:
-            # three swizzled addresses per pixel block, one per column offset dx of the taps: region row (upper left neighbour) + dx, 64 B per
-            # row, channel group q at position q ^ 2 b with b = bit 2 of that row's column x - 1 + dx (a padding column holds zeros at every
-            # position); + the ring buffer.  emit_pp_of leaves rem = y W + x in T[1] and y in T[2].
-            E(f"v_mul_lo_u32 {T[0]}, {T[2]}, {s('W')}")
-            E(f"v_sub_u32 {T[0]}, {T[1]}, {T[0]}", "x")
-            E(f"v_lshl_add_u32 {T[5]}, {T[5]}, 6, {s('tmp3')}", "byte address of the row in this tile's first ring buffer")
-            for dx in range(3):
-                E(f"v_add_u32 {T[1]}, {dx - 1}, {T[0]}")
-                E(f"v_bfe_u32 {T[1]}, {T[1]}, 2, 1", "b")
-                E(f"v_lshlrev_b32 {T[1]}, 5, {T[1]}")
-                E(f"v_xor_b32 {T[1]}, {T[1]}, {v('qps')}", "16 (q ^ 2 b)")
-                E(f"v_add_u32 {T[1]}, {T[5]}, {T[1]}")
-                E(f"v_add_u32 {v('addr', 3 * j + dx)}, {64 * dx}, {T[1]}")
-            continue
-        if F8:
-            # linear byte address of (upper left neighbour's row, this lane's 32-byte channel half), in the tile's first ring buffer;
-            # the tap offset and the swizzle are applied where the fragment is read
-            E(f"v_lshl_add_u32 {T[5]}, {T[5]}, 6, {v('qps')}", "qps = 32 (q & 1) here")
-            E(f"v_add_u32 {v('addr', j)}, {s('tmp3')}, {T[5]}")
-            continue
-        if S2:
-            # four swizzled addresses per pixel block: region row (upper left neighbour) + (ry Wp + rx), 64 B per row, channel group q at
-            # position q ^ 2 bit2(row): byte bit 5 ^= byte bit 8; + the ring buffer
-            E(f"v_lshl_add_u32 {T[5]}, {T[5]}, 6, {v('qps')}", "linear byte address of (row, group q): qps = 16 q here")
-            for o in range(4):
-                src = T[5]
-                if o:
-                    E(f"v_add_u32 {T[0]}, {s('dRow') if o == 2 else (64 if o == 1 else s('tmp0'))}, {T[5]}")
-                    src = T[0]
-                E(f"v_lshrrev_b32 {T[1]}, 3, {src}")
-                E(f"v_and_b32 {T[1]}, 32, {T[1]}")
-                E(f"v_xad_u32 {v('addr', 4 * j + o)}, {src}, {T[1]}, {s('tmp3')}")
-            continue
-        E(f"v_lshl_add_u32 {v('addr', j)}, {T[5]}, 4, {v('qps')}")
-        E(f"v_add_u32 {v('addr', j)}, {s('tmp3')}, {v('addr', j)}")
+    emit_setup_addr()
+    if EARLY_SETUP:
+        label(".Ltile_bias_" + name)
     # accumulators start from the bias: LDS reads straight into the accumulator registers (3 NB reads instead of 12 NB register moves)
     E(f"v_lshl_add_u32 {T[6]}, {v('q')}, 2, {s('cbase')}")
     E(f"v_lshlrev_b32 {T[6]}, 2, {T[6]}")
@@ -966,6 +1004,10 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     E(f"s_cmp_eq_u32 {s('first')}, 1")
     E(f"s_cselect_b32 {s('extra')}, 0, {s('extra')}")
     n_extra = 3 * NB if (RES_EARLY or not RES) else 6 * NB
+    if W16 and not w8:
+        n_extra = NB + (NB + 1) // 2      # one 16-byte store per pixel block (M blocks 0, 1) + one per pair of pixel blocks (M block 2)
+    if abl & 128:
+        n_extra = 0
     if RES and RES_EARLY:
         # The tile's whole residual rides in the LAST chunk's stream (3 loads per pixel block, spread over taps 0 .. 6, landing under
         # the MFMAs); the other chunks branch over the loads, and every weight wait of the stream picks between two hand-counted
@@ -1002,7 +1044,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
     cold = []                             # out-of-line code: (label, immediate or instruction list, label to return to)
     T7RES = RES and RES_EARLY
 
-    def epilogue_block(i, j, mode, lines, tb=0):
+    def epilogue_block(i, j, mode, lines, tb=0, dst=None):
         """Appends the instructions of one 16 x 16 output block (M block i, pixel block j): accumulators -> (x scale) -> SiLU -> + residual ->
         bf16 -> store.  mode: "act" / "noact" (the two copies behind a branch after the stream).  The caller has set EXEC to the pixel
         block's store mask."""
@@ -1020,7 +1062,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             L(f"v_pk_mul_f32 v[{X + 2}:{X + 3}], v[{X + 2}:{X + 3}], v[{sc + 2}:{sc + 3}]")
 
         def unpack():
-            if F8 or PM:                                  # the residual waits in the accumulator file
+            if RES_ACC:                                   # the residual waits in the accumulator file
                 L(f"v_accvgpr_read_b32 v{Rr + 1}, a{r0}")
                 L(f"v_accvgpr_read_b32 v{Rr + 3}, a{r0 + 1}")
                 L(f"v_lshlrev_b32 v{Rr}, 16, v{Rr + 1}")
@@ -1033,6 +1075,9 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
             L(f"v_lshlrev_b32 v{Rr + 2}, 16, v{r0 + 1}")
             L(f"v_and_b32 v{Rr + 3}, 0xffff0000, v{r0 + 1}")
 
+        if abl & 256:                                     # (timing-only ablation 256: no epilogue arithmetic, the stores alone)
+            L(f"global_store_dwordx2 {v('oo', j)}, v[{X}:{X + 1}], {s2('out')} offset:{32 * i}")
+            return
         if mode == "act":
             L(f"v_pk_mul_f32 v[{Y}:{Y + 1}], v[{X}:{X + 1}], {s2('klog2e2')}")
             L(f"v_pk_mul_f32 v[{Y + 2}:{Y + 3}], v[{X + 2}:{X + 3}], {s2('klog2e2')}")
@@ -1053,9 +1098,16 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         if RES:
             L(f"v_pk_add_f32 v[{X}:{X + 1}], v[{X}:{X + 1}], v[{Rr}:{Rr + 1}]")
             L(f"v_pk_add_f32 v[{X + 2}:{X + 3}], v[{X + 2}:{X + 3}], v[{Rr + 2}:{Rr + 3}]")
+        if dst is not None:                               # wide stores: the caller pairs this block's 8 bytes with a neighbour's
+            L(f"v_cvt_pk_bf16_f32 v{dst}, v{X}, v{X + 1}")
+            L(f"v_cvt_pk_bf16_f32 v{dst + 1}, v{X + 2}, v{X + 3}")
+            return
         L(f"v_cvt_pk_bf16_f32 v{Y}, v{X}, v{X + 1}")
         L(f"v_cvt_pk_bf16_f32 v{Y + 1}, v{X + 2}, v{X + 3}")
-        L(f"global_store_dwordx2 {v('oo', j)}, v[{Y}:{Y + 1}], {s2('out')} offset:{32 * i}")
+        if not abl & 128:                                 # (timing-only ablation 128: no output stores)
+            import os as _os1
+            pol = _os1.environ.get("AQ_GEN_ST_POLICY", "")    # experiment: cache policy of the output stores ("nt", "sc1", "sc0 sc1")
+            L(f"global_store_dwordx2 {v('oo', j)}, v[{Y}:{Y + 1}], {s2('out')} offset:{32 * i}" + (f" {pol}" if pol else ""))
 
     # first B fragments
     def b_read(n):
@@ -1210,7 +1262,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
                 if jr:
                     body.append(f"v_add_u32 {T[4]}, {16 * jr}, {T[4]}")
                 body += [f"v_min_i32 {T[4]}, {s('rlim')}, {T[4]}", f"v_mul_lo_u32 {T[4]}, {T[4]}, {s('res_ld')}", f"v_add_u32 {T[4]}, {T[4]}, {T[7]}"]
-                body += [f"global_load_dwordx2 {'a' if F8 or PM else 'v'}[{rreg(3 * jr + i)}:{rreg(3 * jr + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}" for i in range(3)]
+                body += [f"global_load_dwordx2 {'a' if RES_ACC else 'v'}[{rreg(3 * jr + i)}:{rreg(3 * jr + i) + 1}], {T[4]}, {s2('res')} offset:{32 * i}" for i in range(3)]
                 cold.append((lx, body, ld))
         # one wait per PAIR of elements (fragments n and n + 1 have landed): the stream is bound by instruction issue
         allowed = min(PD, NE - 1 - n)
@@ -1277,7 +1329,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         tail = [o for tt in range(NT) for o in tap_ops(tt, True)]
         k_res = len(tail) - 1 - max(i for i, o in enumerate(tail) if o[1] == "R")
         E(f"s_waitcnt vmcnt({k_res})", "the residual (only weight loads of the next tile's first taps are younger)")
-    SC = V.names["SC"][0] if F8 else V.names["A"][0] + 60    # fp8 weights: per-channel scales 2^e of this lane's 3 x 4 output channels
+    SC = V.names["SC"][0] if F8 else V.names["A"][0] + 60 if not A_ACC else 0    # fp8 weights: per-channel scales 2^e of this lane's 3 x 4 output channels
     if w8 or F8:
         for i in range(3):
             E(f"v_lshl_add_u32 {T[6]}, {v('q')}, 2, {s('cbase')}")
@@ -1300,20 +1352,74 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         else:
             label(lact)
         E(f"s_sub_i32 {s('lim')}, {s('npix')}, {s('n0')}")
-        for j in range(NB):
+        if W16:
+            # lanes with odd q (16-31, 48-63): the select mask of the per-lane store addresses.  SGPR pairs that are dead between the last
+            # weight load of a tile and the next chunk top: actm = the mask, a_ld = the previous pixel block's store mask, a_cur = scratch
+            E(f"s_mov_b32 {s('actm')}, 0xffff0000")
+            E(f"s_mov_b32 {s('actm', 1)}, 0xffff0000")
+        for j in range(NB if W16 else 0):
+            mode = "act" if ACT else "noact"
+            P = V.names["t"][0] + 16                      # chain 1's work registers: dead when the two chains reach their conversions
+            CS = V.names["cst"][0]
+            TA, TB = V.names["t"][0], V.names["t"][0] + 1
+            E(f"v_cmp_gt_i32 {s2('t64')}, {s('lim')}, {v('l15')}", "pixel n0 + 16 j + l15 inside the batch?")
+            E(f"s_sub_i32 {s('lim')}, {s('lim')}, 16")
+            E(f"s_mov_b64 exec, {s2('t64')}")
+            la, lb, lc = [], [], []
+            epilogue_block(0, j, mode, la, 0, dst=P)
+            epilogue_block(1, j, mode, lb, 12, dst=P + 2)
+            epilogue_block(2, j, mode, lc, 0, dst=CS + 2 * (j & 1))
+            for k in range(max(len(la), len(lb))):
+                if k < len(la):
+                    E(la[k])
+                if k < len(lb):
+                    E(lb[k])
+            # M blocks 0 and 1: even-q lanes store bytes 0 .. 15 of block 0 (their own 8 and lane q + 1's), odd-q lanes bytes 0 .. 15 of block 1
+            # (lane q - 1's 8 and their own), i.e. 32 - 8 = 24 bytes beyond their own offset.  (hz: VALU write -> v_permlane read, 2 wait
+            # states: the two address instructions sit in between)
+            E(f"v_cndmask_b32 v{TA}, 0, 24, {s2('actm')}")
+            E(f"v_add_u32 v{TA}, v{TA}, {v('oo', j)}")
+            E(f"v_permlane16_swap_b32 v{P}, v{P + 2}")
+            E(f"v_permlane16_swap_b32 v{P + 1}, v{P + 3}")
+            if not abl & 128:
+                E(f"global_store_dwordx4 v{TA}, v[{P}:{P + 3}], {s2('out')}")
+            for l in lc:
+                E(l)
+            if j % 2 == 0 and j + 1 < NB:
+                E(f"s_mov_b64 {s2('a_ld')}, {s2('t64')}", "this block's mask: its M block 2 leaves with the next block's")
+            elif j % 2 == 0:
+                if not abl & 128:                         # the last pixel block of an odd count: its M block 2 alone, 8 bytes per lane
+                    E(f"global_store_dwordx2 {v('oo', j)}, v[{CS}:{CS + 1}], {s2('out')} offset:64")
+            else:
+                # M block 2 of pixel blocks j - 1 (even-q lanes) and j (odd-q lanes).  Every lane pair of a pixel that either block stores
+                # must swap: block j - 1's mask is the superset
+                E(f"s_mov_b64 exec, {s2('a_ld')}")
+                E(f"v_add_u32 v{TB}, 8, {v('oo', j - 1)}")
+                E(f"v_cndmask_b32 v{TA}, v{TB}, {v('oo', j)}, {s2('actm')}", "even q: own offset + 64; odd q: own offset + 64 - 8 (lane q - 1's piece first)")
+                E(f"v_permlane16_swap_b32 v{CS}, v{CS + 2}")
+                E(f"v_permlane16_swap_b32 v{CS + 1}, v{CS + 3}")
+                E(f"s_andn2_b64 {s2('a_cur')}, {s2('a_ld')}, {s2('actm')}")
+                E(f"s_and_b64 {s2('t64')}, {s2('t64')}, {s2('actm')}")
+                E(f"s_or_b64 exec, {s2('a_cur')}, {s2('t64')}")
+                if not abl & 128:
+                    E(f"global_store_dwordx4 v{TA}, v[{CS}:{CS + 3}], {s2('out')} offset:56")
+            E("s_mov_b64 exec, -1")
+        for j in range(0 if W16 else NB):
             E(f"v_cmp_gt_i32 {s2('t64')}, {s('lim')}, {v('l15')}", "pixel n0 + 16 j + l15 inside the batch?")
             E(f"s_sub_i32 {s('lim')}, {s('lim')}, 16")
             E(f"s_mov_b64 exec, {s2('t64')}")
             la, lb, lc = [], [], []
             epilogue_block(0, j, "act" if ACT else "noact", la, 0)
             epilogue_block(1, j, "act" if ACT else "noact", lb, 12)
-            epilogue_block(2, j, "act" if ACT else "noact", lc, 0)
+            epilogue_block(2, j, "act" if ACT else "noact", lc, 24 if EP3 else 0)
             for k in range(max(len(la), len(lb))):
                 if k < len(la):
                     E(la[k])
                 if k < len(lb):
                     E(lb[k])
-            for l in lc:
+                if EP3 and k < len(lc):                  # all three M blocks of the pixel block in lock step, on three sets of temporaries
+                    E(lc[k])
+            for l in () if EP3 else lc:
                 E(l)
             E("s_mov_b64 exec, -1")
         if ACT:
@@ -1504,7 +1610,7 @@ def main():
         if nb == 13:
             variants += [(False, False, 0, True), (True, False, 0, True), (True, True, 0, True)]     # fp8-weight stream
         if DIAG and nb == "pm13w40":
-            variants += [(True, True, a, False) for a in (1, 2, 4, 8, 64)]
+            variants += [(True, True, a, False) for a in (1, 2, 4, 8, 64, 128, 256)]
         if DIAG and nb in (7, 13):
             variants += [(True, True, a, False) for a in (1, 2, 3, 4, 7, 8) + ((16, 32) if nb == 13 else ())]
         for RES, stamped, abl, w8 in variants:
