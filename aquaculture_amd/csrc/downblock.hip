@@ -390,13 +390,25 @@ __global__ __launch_bounds__(kNW * 64) void downblock_kernel(const DownParams p)
             for (int j = 0; j < 4; ++j) acc[j] = acc[j] + bav;
         }
         const int x = x0 + l15;
+        // 16-byte stores (round 4): 8-byte stores per lane are store-ISSUE bound (cdna_hip_programming.md T21; measured on the planar 3x3
+        // kernels: 240 cycles per 512-byte instruction).  v_permlane16_swap pairs the 8-byte pieces of lanes g and g + 1 (same pixel,
+        // adjacent channel quads) of output rows j and j + 1: afterwards even-g lanes hold row j's 16 bytes (their own quad and lane
+        // g + 1's), odd-g lanes row j + 1's (lane g - 1's quad and their own) -- two store instructions per tile instead of four.
+        uint2 pk[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int y = y0 + ty + j;
             f32x4 v = acc[j];
             if (FUSE || p.act) v = down_silu4(v);
+            pk[j] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+        const int odd = g & 1;
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            const auto r0 = __builtin_amdgcn_permlane16_swap(pk[j].x, pk[j + 1].x, false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(pk[j].y, pk[j + 1].y, false, false);
+            const int y = y0 + ty + j + odd;
             if (y < Ho && x < Wo)
-                *(uint2*)(p.out + ((long long)(b * Ho + y) * Wo + x) * p.out_ld_b + cbase * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                *(uint4*)(p.out + ((long long)(b * Ho + y) * Wo + x) * p.out_ld_b + (cbase - 4 * odd) * 2) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
         }
     }
 }

@@ -113,10 +113,12 @@ def configure(nb):
     g["WFIX"] = 0
     g.update(CONFIGS[nb])
     import os as _os0
-    # A_ACC (experiment, AQ_GEN_A_ACC=1, pixel-major bf16 families): the weight sets live in the accumulator half of the register file and
-    # the residual in VGPRs (instead of the other way round) -- the weight loads' returns then do not write the VGPR banks the MFMAs read
-    # their B operands from, and the epilogue reads the residual without v_accvgpr_read.
-    g["A_ACC"] = bool(PM and not F8 and _os0.environ.get("AQ_GEN_A_ACC", "0") == "1")
+    # A_ACC (round 4; AQ_GEN_A_ACC=0 restores the old assignment; pixel-major bf16 families): the weight sets live in the accumulator half of
+    # the register file (MFMA takes srcA from there at no cost) and the residual in VGPRs, instead of the other way round: the epilogue reads
+    # the residual without v_accvgpr_read (78 instructions per tile) and the weight loads' returns no longer write the VGPR banks the MFMAs
+    # read B from.  Stamped, with the 16-byte stores: 192 ch @ 40x40 lifetime 114.1 k -> 112.6 k cycles (stream 84.3 k -> 83.5 k, epilogue
+    # 14.76 k -> 14.17 k), 384 ch @ 20x20 96.4 k -> 96.2 k.
+    g["A_ACC"] = bool(PM and not F8 and _os0.environ.get("AQ_GEN_A_ACC", "1") == "1")
     g["RES_ACC"] = bool((F8 or PM) and not A_ACC)          # the residual waits in the accumulator file
     # W16 (round 4, AQ_GEN_W16=0 restores the 8-byte stores): the epilogue's output stores as 16 bytes per lane.  A wave's three stores per
     # pixel block (8 bytes per lane: this lane's four channels of an M block) are store-ISSUE bound, not bandwidth bound -- the stamped
