@@ -148,3 +148,34 @@ def test_generated_planar_assembly_fits_its_occupancy(tmp_path):
         assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) == 0      # no scratch: every memory operation is counted by hand
     # every hand-counted wait fits the 6-bit vmcnt field, and no kernel relies on a compiler: there is none
     assert all(int(n) <= 63 for n in re.findall(r"s_waitcnt vmcnt\((\d+)\)", text))
+
+
+# The 16-byte output stores of the pixel-major / stride-2 / fp8 families (gen_conv3x3_pl_asm.py W16): 13 + 6 stores of
+# 16 bytes and one of 8 per tile and activation branch instead of 39 of 8, and the hazards the assembler does not pad -- a VALU write
+# of either operand is at least two instructions ahead of the v_permlane16_swap that reads it, and the data registers of a 16-byte
+# store are not written by the instruction right behind it.
+def test_generated_planar_assembly_wide_stores(tmp_path):
+    import sys
+    src = tmp_path / "pl.s"
+    gen = os.path.join(ROOT, "aquaculture_amd", "csrc", "gen_conv3x3_pl_asm.py")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("AQ_GEN_")}
+    subprocess.run([sys.executable, gen, str(src)], check=True, capture_output=True, env=env)
+    text = src.read_text()
+    for fam, copies in (("pm13w40_res1", 2), ("pm13w20_res0", 2), ("s2nb13_res0", 2), ("f8nb13_res1", 2)):
+        body = text.split(f"\nconv3x3_pl_asm_{fam}:\n", 1)[1].split("s_endpgm", 1)[0].split("\n")
+        ins = [l.split(";")[0].strip() for l in body if l.startswith("\t")]
+        out_stores = [l for l in ins if l.startswith("global_store_dwordx") and "offset:" in l or l.startswith("global_store_dwordx4")]
+        assert sum(l.startswith("global_store_dwordx4") for l in out_stores) == 19 * copies, fam          # (act / no-act copies of the epilogue)
+        assert sum(l.startswith("global_store_dwordx2") for l in ins) == 1 * copies, fam
+        for i, l in enumerate(ins):
+            if l.startswith("v_permlane16_swap_b32"):
+                ops = _regs(l)
+                for back in (1, 2):
+                    prev = ins[i - back]
+                    if prev.startswith(("v_", "ds_read", "global_load")) and not prev.startswith("v_permlane16_swap"):
+                        dst = re.match(r"\S+ (v\d+|v\[\d+:\d+\])", prev)
+                        assert not dst or not (_regs(dst.group(1)) & ops), f"{fam}: '{prev}' writes an operand of '{l}' {back} instruction(s) ahead"
+            if l.startswith("global_store_dwordx4"):
+                data = _regs(l.split(",")[1])
+                nxt = re.match(r"v_\S+ (v\d+|v\[\d+:\d+\])", ins[i + 1])
+                assert not nxt or not (_regs(nxt.group(1)) & data), f"{fam}: '{ins[i + 1]}' rewrites the data of '{l}'"
