@@ -73,6 +73,13 @@ class Regs:
         return base
 
 
+import os as _os
+# W16 (experiment, AQ_GEN_BTL_W16=1; parity-green): 16-byte output stores as in the planar 3x3 families (three store instructions per tile and wave
+# instead of six).  MEASURED, no gain: HBM-cold 169.8-176.9 / 154.3-155.4 us (shortcut / none) -> 173.0-177.0 / 151.2-152.1; in the engine model.2.m.0 /
+# m.1 127.9 / 122.8 -> 128.9 / 123.3 us (three interleaved bench runs each): with two waves per SIMD the partner's work already covers a wave's store issue.
+# Off: the shipped kernel keeps its 8-byte stores.  (First build wrong in row 0's channels 2, 3 of every second quad: gfx940+ needs TWO wait states
+# between a store of more than 8 bytes and a VALU write of its data registers -- row 1's SiLU starts in them; hence the s_nop.)
+W16 = _os.environ.get("AQ_GEN_BTL_W16", "0") == "1"
 V = Regs("v", 256)
 S = Regs("s", 100)
 
@@ -163,7 +170,7 @@ PH_PROLOGUE, PH_DMA, PH_B, PH_C_MFMA, PH_C_EPI, PH_BARRIER = range(6)      # (PH
 def E(line="", comment=None):
     if OPT["nomfma"] and line.startswith("v_mfma"):
         return
-    if (OPT["nodma"] and line.startswith("buffer_load_dwordx4")) or (OPT["nold"] and line.startswith("global_load_dwordx2")) or (OPT["nost"] and line.startswith("global_store_dwordx2")):
+    if (OPT["nodma"] and line.startswith("buffer_load_dwordx4")) or (OPT["nold"] and line.startswith("global_load_dwordx2")) or (OPT["nost"] and line.startswith("global_store_dwordx")):
         return
     if OPT["nosilu"] and line.split(" ")[0] in ("v_exp_f32", "v_rcp_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_mul_f32", "v_add_f32"):
         return
@@ -183,7 +190,7 @@ def E(line="", comment=None):
                 b_ = f"s{int(r3.group(1)) + h}"
             out.append(f"\t{op}_e64 v{d + h}, v{a + h}, {b_}")
         return
-    if (OPT["ntst"] and line.startswith("global_store_dwordx2")) or (OPT["ntld"] and line.startswith("global_load_dwordx2")):
+    if (OPT["ntst"] and line.startswith("global_store_dwordx")) or (OPT["ntld"] and line.startswith("global_load_dwordx2")):
         line += " nt"                      # experiment: streaming hint on the output stores / the shortcut loads (neither is read again by this kernel)
     out.append(("\t" + line if line and not line.endswith(":") else line) + (f"\t; {comment}" if comment else ""))
 
@@ -488,6 +495,11 @@ def emit_phase_c(dma_inside):
     # ---- epilogue, one output row (12 accumulator registers) at a time: SiLU, shortcut, bf16, store.  Two copies behind ONE branch. ----
     temps = [P0 + 12 + i for i in range(12)]
     plain, done = uid("pl"), uid("dn")
+    if W16:
+        E(f"s_mov_b32 {s('sa')}, 0xffff0000", "lanes with odd q")
+        E(f"s_mov_b32 {s('sa', 1)}, 0xffff0000")
+        E(f"s_mul_i32 {s('tmp4')}, {s('W')}, {s('out_ld')}")
+        E(f"s_add_u32 {s('tmp4')}, {s('tmp4')}, {64 - 8 - 64}", "row 1's block 2 from row 0's address: + one image row - 8 (the store's own offset is 64)")
     E(f"s_cmp_eq_u32 {s('shortcut')}, 0")
     E(f"s_cbranch_scc1 {plain}")
     for with_sc in (True, False):
@@ -507,6 +519,37 @@ def emit_phase_c(dma_inside):
                     E(f"v_and_b32 v{temps[4 * m + 3]}, 0xffff0000, v{sc + 1}")
                 for k in range(0, 12, 2):
                     E(f"v_pk_add_f32 v[{regs[k]}:{regs[k] + 1}], v[{regs[k]}:{regs[k] + 1}], v[{temps[k]}:{temps[k] + 1}]")
+            if W16:
+                # 16-byte stores (gen_conv3x3_pl_asm.py W16): v_permlane16_swap pairs the 8-byte pieces of lanes q and q + 1 of a
+                # pixel; M blocks 0 and 1 of a row leave in one store (even-q lanes: block 0's 16 bytes, odd-q lanes: block 1's, 24 bytes beyond
+                # their own offset), M block 2 of rows 0 and 1 in one more -- three store instructions per tile instead of six.  Row 0's block 2
+                # waits in its own (dead) accumulator registers A0, A0 + 1; row 1's goes to A0 + 2, A0 + 3.
+                for k in range(4):
+                    E(f"v_cvt_pk_bf16_f32 v{temps[k]}, v{regs[2 * k]}, v{regs[2 * k] + 1}")
+                for k in (4, 5):
+                    E(f"v_cvt_pk_bf16_f32 v{A0 + 2 * j + k - 4}, v{regs[2 * k]}, v{regs[2 * k] + 1}")
+                E(f"v_cndmask_b32 v{temps[6]}, 0, 24, {s2('sa')}")
+                E(f"v_add_u32 v{temps[6]}, v{temps[6]}, {v('vout')}")
+                E(f"v_permlane16_swap_b32 v{temps[0]}, v{temps[2]}")
+                E(f"v_permlane16_swap_b32 v{temps[1]}, v{temps[3]}")
+                E(f"s_mov_b64 exec, {s2('mask' + str(j))}")
+                E(f"global_store_dwordx4 v{temps[6]}, v[{temps[0]}:{temps[3]}], {s2('orow' + str(j))}")
+                E("s_mov_b64 exec, -1")
+                if j == 0:
+                    E("s_nop 0", "hz: store of more than 8 bytes -> VALU write of its data registers, 2 wait states on gfx940+ (row 1's SiLU starts in them)")
+                if j == 1:
+                    # even-q lanes: row 0's block 2 at their own offset + 64; odd-q lanes: row 1's, one image row further and 8 bytes back
+                    E(f"v_mov_b32 v{temps[7]}, {s('tmp4')}")
+                    E(f"v_cndmask_b32 v{temps[7]}, 0, v{temps[7]}, {s2('sa')}")
+                    E(f"v_add_u32 v{temps[7]}, v{temps[7]}, {v('vout')}")
+                    E(f"v_permlane16_swap_b32 v{A0}, v{A0 + 2}")
+                    E(f"v_permlane16_swap_b32 v{A0 + 1}, v{A0 + 3}")
+                    E(f"s_andn2_b64 {s2('t64')}, {s2('mask0')}, {s2('sa')}")
+                    E(f"s_and_b64 {s2('colmask')}, {s2('mask1')}, {s2('sa')}")
+                    E(f"s_or_b64 exec, {s2('t64')}, {s2('colmask')}")
+                    E(f"global_store_dwordx4 v{temps[7]}, v[{A0}:{A0 + 3}], {s2('orow0')} offset:64")
+                    E("s_mov_b64 exec, -1")
+                continue
             for k in range(6):
                 E(f"v_cvt_pk_bf16_f32 v{temps[k]}, v{regs[2 * k]}, v{regs[2 * k] + 1}")
             E(f"s_mov_b64 exec, {s2('mask' + str(j))}")
@@ -702,7 +745,7 @@ def gen_kernel(name, stamped=False, **opt):
     E("s_waitcnt vmcnt(0)")
     E(f"s_branch {join}")
     label(full)
-    E("s_waitcnt vmcnt(6)")
+    E(f"s_waitcnt vmcnt({3 if W16 else 6})")
     E(f"s_branch {join}")
     label(g1)
     emit_dma()

@@ -177,5 +177,6 @@ def test_generated_planar_assembly_wide_stores(tmp_path):
                         assert not dst or not (_regs(dst.group(1)) & ops), f"{fam}: '{prev}' writes an operand of '{l}' {back} instruction(s) ahead"
             if l.startswith("global_store_dwordx4"):
                 data = _regs(l.split(",")[1])
-                nxt = re.match(r"v_\S+ (v\d+|v\[\d+:\d+\])", ins[i + 1])
-                assert not nxt or not (_regs(nxt.group(1)) & data), f"{fam}: '{ins[i + 1]}' rewrites the data of '{l}'"
+                for ahead in (1, 2):                     # gfx940+: two wait states between a store of more than 8 bytes and a VALU write of its data
+                    nxt = re.match(r"v_\S+ (v\d+|v\[\d+:\d+\])", ins[i + ahead])
+                    assert not nxt or not (_regs(nxt.group(1)) & data), f"{fam}: '{ins[i + ahead]}' rewrites the data of '{l}'"
