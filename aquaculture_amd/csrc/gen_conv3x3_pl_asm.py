@@ -13,6 +13,9 @@ Here every register is assigned by hand:
   v[B]   4 (PD + 1)      rotating B fragments, read PD elements ahead of their MFMAs
   v[R]   6 NB            the tile's whole residual, fetched at the top of its LAST chunk (lands under that chunk's MFMAs)
   v[addr] NB             LDS byte address of this lane's B fragment per pixel block, advanced in place from tap to tap
+  (pixel-major families since round 4's second session: the 72 weight registers sit BEHIND the accumulators in the accumulator file --
+   MFMA reads srcA from there at no cost -- and the residual in VGPRs: A_ACC below; v[cst] 4 registers hold M block 2's packed outputs of
+   two pixel blocks for their shared 16-byte store: W16 below)
 
 and every s_waitcnt vmcnt(N) is exact (N = vector-memory operations issued after the awaited one; the only run-time dependence, "+3 NB
 at taps 0 and 1 after an epilogue or a residual fetch", is a scalar branch between two immediates).
@@ -246,8 +249,8 @@ def allocate_registers():
     if KS == 2 and not F8 and not PM:
         S.alloc("dbase1", 2, 2)   # ... and of its second plane (32-channel chunks: one base, the planes are immediate offsets)
     S.alloc("t64", 2, 2)
-    S.alloc("actm", 2, 2)         # all ones when the layer has an activation (read by the removed SPLIT epilogue only; kept, with its two
-                                  # prologue instructions, so that the shipped kernels stay byte-identical)
+    S.alloc("actm", 2, 2)         # prologue: all ones when the layer has an activation (read by the removed SPLIT epilogue only); W16 epilogue:
+                                  # the lanes with odd q (0xffff0000 twice), the select mask of the paired stores' per-lane addresses
     S.alloc("st_acc", 12, 2)      # stamped build only: cycle sums of six phases
     if S2:                        # (arguments the stride-2 kernels never read: no shortcut, channel groups 16 bytes apart)
         S.names["st_last"], S.names["st_rt0"] = S.names["res"], S.names["in_ss"]
@@ -909,7 +912,7 @@ def gen_kernel(name, RES, stamped=False, abl=0, w8=False):
         E("s_nop 0", "hz: s_mov m0 -> LDS-DMA")
         E(f"global_load_lds_dwordx4 v[{V.names['t'][0] + 4}:{V.names['t'][0] + 5}], off")
     if EARLY_SETUP:
-        # the first tile's address arithmetic (some 600 VALU instructions) between the prologue's loads and the wait for them
+        # the first tile's address arithmetic (some 700 VALU instructions) between the prologue's loads and the wait for them
         E(f"s_mov_b32 {s('buf')}, 0")
         E(f"s_mov_b32 {s('first')}, 1")
         emit_setup_addr()
